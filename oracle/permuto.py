@@ -1,0 +1,250 @@
+"""ORACLE (test infrastructure only — never imported by the product path).
+
+CPU restatement of the permutohedral-lattice arithmetic behind the operators that
+temporal_latticenet calls through `latticenet` / `latticenet_py` (un-vendored CUDA
+dependency, README.md:47 of the reference; call sites seq_lattice/models.py:298,
+353, 398, 465 and seq_lattice/lattice_modules.py:285-304, 440, 573).
+
+PARITY UNPINNED at this boundary: the reference ships neither source, tests nor
+golden vectors for these ops.  This file restates the *published*
+algorithm (Adams, Baek, Davis 2010, "Fast High-Dimensional Filtering Using the
+Permutohedral Lattice"; Rosu et al. RSS 2020 "LatticeNet") and fixes, once, every
+free choice.  The fixed choices are listed in DESIGN.md §"Lattice specification";
+the HIP kernels must match this file bit-exactly on every integer output.
+
+Everything here is numpy on float32/int32/int64 with NO fused multiply-add, so the
+float sequence is reproducible on any IEEE machine.
+"""
+import math
+import numpy as np
+
+F32 = np.float32
+
+
+# --------------------------------------------------------------------------
+# S1. scale factors  (Adams 2010 §3.1 without the blur-variance factor)
+# --------------------------------------------------------------------------
+def scale_factors(sigmas):
+    """scale[i] = float32( 1 / (sigma_i * sqrt((i+1)(i+2))) ), computed in double."""
+    return np.array(
+        [1.0 / (float(s) * math.sqrt(float((i + 1) * (i + 2)))) for i, s in enumerate(sigmas)],
+        dtype=np.float64,
+    ).astype(F32)
+
+
+# --------------------------------------------------------------------------
+# S2. elevate -> enclosing simplex -> barycentric -> keys   (Adams 2010 §3.1)
+# --------------------------------------------------------------------------
+def elevate(pos, scale):
+    """pos [N,d] f32 -> elevated [N,d+1] f32 on the hyperplane sum(x)=0."""
+    pos = np.ascontiguousarray(pos, dtype=F32)
+    n, d = pos.shape
+    cf = pos * scale.astype(F32)[None, :]          # one rounding
+    elev = np.empty((n, d + 1), F32)
+    sm = np.zeros(n, F32)
+    for i in range(d, 0, -1):
+        t = F32(i) * cf[:, i - 1]                   # one rounding
+        elev[:, i] = sm - t                         # one rounding
+        sm = sm + cf[:, i - 1]
+    elev[:, 0] = sm
+    return elev
+
+
+def simplex(elev):
+    """elevated [N,d+1] -> rem0 [N,d+1] i32, rank [N,d+1] i32, bary [N,d+2] f32."""
+    n, d1 = elev.shape
+    d = d1 - 1
+    inv = F32(1.0 / d1)
+    v = elev * inv
+    up = np.ceil(v) * F32(d1)
+    down = np.floor(v) * F32(d1)
+    take_up = (up - elev) < (elev - down)
+    rem0f = np.where(take_up, up, down).astype(F32)
+    rem0 = rem0f.astype(np.int32)
+    ssum = rem0.sum(axis=1) // d1                   # exact: sum is a multiple of d1
+
+    diff = elev - rem0f                             # f32
+    rank = np.zeros((n, d1), np.int32)
+    for i in range(d):
+        for j in range(i + 1, d1):
+            lt = diff[:, i] < diff[:, j]
+            rank[:, i] += lt
+            rank[:, j] += ~lt
+
+    s = ssum[:, None]
+    pos_fix = (s > 0) & (rank >= d1 - s)
+    neg_fix = (s < 0) & (rank < -s)
+    rem0 = rem0 - d1 * pos_fix + d1 * neg_fix
+    rank = rank + s - d1 * pos_fix + d1 * neg_fix
+
+    # barycentric (sequential over i, exactly as the kernels do it)
+    rem0f = rem0.astype(F32)
+    bary = np.zeros((n, d + 2), F32)
+    rows = np.arange(n)
+    for i in range(d1):
+        delta = (elev[:, i] - rem0f[:, i]) * inv
+        bary[rows, d - rank[:, i]] = bary[rows, d - rank[:, i]] + delta
+        bary[rows, d + 1 - rank[:, i]] = bary[rows, d + 1 - rank[:, i]] - delta
+    bary[:, 0] = bary[:, 0] + (F32(1.0) + bary[:, d + 1])
+    return rem0, rank, bary
+
+
+def simplex_keys(rem0, rank):
+    """keys [N, d+1 (remainder r), d] i32: first d coordinates of vertex r."""
+    n, d1 = rem0.shape
+    d = d1 - 1
+    keys = np.empty((n, d1, d), np.int32)
+    for r in range(d1):
+        keys[:, r, :] = rem0[:, :d] + r - d1 * (rank[:, :d] > d - r)
+    return keys
+
+
+# --------------------------------------------------------------------------
+# S3. the vertex table: append-only, first-touch numbering
+# --------------------------------------------------------------------------
+KEY_BIAS = 1 << 20
+
+
+def pack_keys(keys):
+    """[...,3] i32 -> [...] i64 (21 bits per coordinate, biased). d=3 only."""
+    k = keys.astype(np.int64) + KEY_BIAS
+    assert k.min() >= 0 and k.max() < (1 << 21), "key out of the 21-bit range"
+    return (k[..., 0] << 42) | (k[..., 1] << 21) | k[..., 2]
+
+
+class VertexTable:
+    """Sequential semantics of the hash table: a vertex gets index = number of
+    distinct keys inserted before it; rows are visited in increasing row id."""
+
+    def __init__(self, pos_dim, capacity):
+        assert pos_dim == 3
+        self.d = pos_dim
+        self.capacity = int(capacity)
+        self.map = {}
+        self.keys = np.zeros((0, pos_dim), np.int32)
+
+    @property
+    def nr_vertices(self):
+        return self.keys.shape[0]
+
+    def clear(self):
+        self.map = {}
+        self.keys = np.zeros((0, self.d), np.int32)
+
+    def insert(self, keys, valid=None):
+        """keys [R,d] i32 in row order; returns indices [R] i32 (-1 = rejected)."""
+        packed = pack_keys(keys)
+        if valid is None:
+            valid = np.ones(packed.shape[0], bool)
+        rows = np.nonzero(valid)[0]
+        out = np.full(packed.shape[0], -1, np.int32)
+        if rows.size == 0:
+            return out
+        uniq, first = np.unique(packed[rows], return_index=True)
+        order = np.argsort(first, kind="stable")       # first-touch order
+        new_keys = []
+        count = self.keys.shape[0]
+        for u, f in zip(uniq[order].tolist(), first[order].tolist()):
+            if u not in self.map and count < self.capacity:
+                self.map[u] = count                    # rejected keys are NOT remembered
+                count += 1
+                new_keys.append(keys[rows[f]])
+        if new_keys:
+            self.keys = np.concatenate([self.keys, np.asarray(new_keys, np.int32)], 0)
+        lut = np.array([self.map.get(u, -1) for u in uniq.tolist()], np.int32)
+        out[rows] = lut[np.searchsorted(uniq, packed[rows])]
+        return out
+
+    def lookup(self, keys):
+        packed = pack_keys(keys).reshape(-1)
+        res = np.array([self.map.get(int(u), -1) for u in packed.tolist()], np.int32)
+        return res.reshape(keys.shape[:-1])
+
+
+# --------------------------------------------------------------------------
+# S4. neighbourhood (one hop, d=3 -> 8 neighbours + centre LAST)
+#     order: k = 2a   -> key + off_a ,  k = 2a+1 -> key - off_a ,  a = 0..d
+#     off_a = (1,..,1) with -d at axis a (all d+1 coordinates; first d are stored)
+# --------------------------------------------------------------------------
+def axis_offsets(d):
+    off = np.ones((d + 1, d + 1), np.int32)
+    for a in range(d + 1):
+        off[a, a] = -d
+    return off[:, :d]                                # first d coordinates
+
+
+def neighbour_keys(keys):
+    """keys [V,d] -> [V, 2(d+1)+1, d] with the centre last."""
+    v, d = keys.shape
+    off = axis_offsets(d)
+    out = np.empty((v, 2 * (d + 1) + 1, d), np.int32)
+    for a in range(d + 1):
+        out[:, 2 * a, :] = keys + off[a]
+        out[:, 2 * a + 1, :] = keys - off[a]
+    out[:, -1, :] = keys
+    return out
+
+
+def neighbour_table(table, query_keys=None):
+    """[V,9] i32 indices into `table` (centre = own index when query is the table)."""
+    if query_keys is None:
+        query_keys = table.keys
+    nk = neighbour_keys(query_keys)
+    return table.lookup(nk)
+
+
+# --------------------------------------------------------------------------
+# S5. coarsening: integer-only embedding of fine vertices at half resolution
+# --------------------------------------------------------------------------
+def coarse_simplex_int(fkeys):
+    """fine keys [V,d] -> (ckeys [V,d+1,d] i32, bnum [V,d+1] i32) where bnum are the
+    barycentric numerators in units of 1/(2(d+1)) of f/2 inside the coarse lattice."""
+    v, d = fkeys.shape
+    d1 = d + 1
+    m = 2 * d1
+    e = np.empty((v, d1), np.int64)
+    e[:, :d] = fkeys
+    e[:, d] = -fkeys.sum(axis=1)
+    down = np.floor_divide(e, m) * m
+    up = np.where(e % m != 0, down + m, down)
+    r = np.where((up - e) < (e - down), up, down)
+    ssum = r.sum(axis=1) // m
+    diff = e - r
+    rank = np.zeros((v, d1), np.int64)
+    for i in range(d):
+        for j in range(i + 1, d1):
+            lt = diff[:, i] < diff[:, j]
+            rank[:, i] += lt
+            rank[:, j] += ~lt
+    s = ssum[:, None]
+    pos_fix = (s > 0) & (rank >= d1 - s)
+    neg_fix = (s < 0) & (rank < -s)
+    r = r - m * pos_fix + m * neg_fix
+    rank = rank + s - d1 * pos_fix + d1 * neg_fix
+    bn = np.zeros((v, d + 2), np.int64)
+    rows = np.arange(v)
+    for i in range(d1):
+        delta = e[:, i] - r[:, i]
+        np.add.at(bn, (rows, d - rank[:, i]), delta)
+        np.add.at(bn, (rows, d + 1 - rank[:, i]), -delta)
+    bn[:, 0] += m + bn[:, d + 1]
+    rem0 = r // 2
+    ck = np.empty((v, d1, d), np.int32)
+    for rr in range(d1):
+        ck[:, rr, :] = rem0[:, :d] + rr - d1 * (rank[:, :d] > d - rr)
+    return ck, bn[:, :d1].astype(np.int32)
+
+
+def coarsen_insert(coarse_table, fine_keys_new):
+    """Insert into `coarse_table` the coarse vertices with non-zero weight for each
+    NEW fine vertex, in (fine index, remainder) order."""
+    ck, bn = coarse_simplex_int(fine_keys_new)
+    v, d1, d = ck.shape
+    coarse_table.insert(ck.reshape(v * d1, d), valid=(bn.reshape(-1) > 0))
+
+
+def finefy_centres(fine_keys):
+    """Nearest coarse vertex (largest barycentric numerator, ties -> smallest r)."""
+    ck, bn = coarse_simplex_int(fine_keys)
+    best = np.argmax(bn, axis=1)                      # first max -> smallest r
+    return ck[np.arange(ck.shape[0]), best]

@@ -1,0 +1,86 @@
+"""ctypes binding of libtln_hip.so (the C ABI declared in include/tln.h).
+
+There is no CPU fallback: if the library is missing or a call fails, an exception is raised.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtln_hip.so")
+
+
+class TlnError(RuntimeError):
+    pass
+
+
+class GemmSrc(C.Structure):
+    _fields_ = [
+        ("d_src", C.c_void_p), ("src_rows", C.c_int64), ("ld", C.c_int64), ("cin", C.c_int), ("taps", C.c_int),
+        ("d_table", C.c_void_p), ("pad_value", C.c_float), ("d_scale", C.c_void_p), ("d_shift", C.c_void_p),
+        ("relu", C.c_int),
+    ]
+
+
+_vp, _i64, _i, _f = C.c_void_p, C.c_int64, C.c_int, C.c_float
+_PROTOS = {
+    "tln_last_error": (C.c_char_p, []),
+    "tln_version": (_i, []),
+    "tln_lattice_create": (_i, [C.POINTER(_vp), _i, C.POINTER(C.c_double), _i64]),
+    "tln_lattice_destroy": (_i, [_vp]),
+    "tln_lattice_clear": (_i, [_vp, _vp]),
+    "tln_lattice_nr_vertices": (_i64, [_vp]),
+    "tln_lattice_capacity": (_i64, [_vp]),
+    "tln_lattice_level": (_i, [_vp]),
+    "tln_lattice_overflow_rows": (_i64, [_vp]),
+    "tln_lattice_keys": (_i, [_vp, _vp, _i64, _vp]),
+    "tln_lattice_insert_keys": (_i, [_vp, _vp, _i64, _vp, _vp]),
+    "tln_distribute": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp]),
+    "tln_build_csr": (_i, [_vp, _vp, _i64, _vp]),
+    "tln_pointnet_pool": (_i, [_vp, _vp, _i64, _i, _i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i), _i, _vp, _vp]),
+    "tln_neighbour_table": (_i, [_vp, C.POINTER(_vp), _vp]),
+    "tln_coarsen": (_i, [_vp, C.POINTER(_vp), _vp]),
+    "tln_coarse_to_fine_table": (_i, [_vp, C.POINTER(_vp), _vp]),
+    "tln_fine_to_coarse_table": (_i, [_vp, C.POINTER(_vp), _vp]),
+    "tln_gather_gemm": (_i, [_i64, _i, C.POINTER(GemmSrc), C.POINTER(GemmSrc), _vp, _i, _vp, _vp, _i64, _i, _vp, _i64, _vp]),
+    "tln_gemm_force_tiles": (None, [_i, _i]),
+    "tln_im2row": (_i, [_vp, _i64, _i, _vp, _i64, _vp, _vp]),
+    "tln_groupnorm_ws_bytes": (_i64, [_i64, _i]),
+    "tln_groupnorm_stats": (_i, [_vp, _i64, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _i64, _vp]),
+    "tln_affine_act": (_i, [_vp, _i64, _i, _vp, _vp, _i, _vp, _vp]),
+    "tln_gru_cell": (_i, [_vp, _vp, _i64, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "tln_aflow": (_i, [_vp, _vp, _i64, _i64, _i, _vp, _f, _f, _f, _i, _vp, _vp, _vp, _vp, _vp]),
+    "tln_slice_gather": (_i, [_vp, _i64, _i, _vp, _vp, _i64, _vp, _vp]),
+    "tln_slice": (_i, [_vp, _i64, _i, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "tln_splat": (_i, [_vp, _vp, _i, _vp, _i64, _vp, _vp]),
+    "tln_scatter_max": (_i, [_vp, _vp, _i64, _i, _i64, _vp, _vp, _vp, _i64, _vp]),
+    "tln_scatter_add": (_i, [_vp, _vp, _i64, _i, _i64, _vp, _vp]),
+}
+
+_lib = None
+
+
+def exported_symbols():
+    return sorted(_PROTOS)
+
+
+def lib():
+    """Loads the shared library once; raises TlnError if it was not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise TlnError(
+                "libtln_hip.so is missing (%s). Build it with `python -m temporal_latticenet_amd.build`; "
+                "there is no CPU fallback." % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(l, name)          # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().tln_last_error()
+        raise TlnError("%s failed with code %d: %s" % (what or "tln call", rc, (msg or b"").decode()))

@@ -1,0 +1,76 @@
+"""Builds libtln_hip.so (gfx950) in-tree with hipcc.  No JIT cache: the .so travels with the tree."""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "_obj")
+LIB = os.path.join(HERE, "libtln_hip.so")
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
+
+SOURCES = {
+    # file -> extra flags.  lattice.hip must not contract a*b+c: its integer outputs are bit-exact vs the oracle
+    "lattice.hip": ["-ffp-contract=off"],
+    "pool.hip": [],
+    "gemm.hip": [],
+    "fused.hip": [],
+}
+COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-I" + INCLUDE, "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(INCLUDE, "tln.h"), os.path.abspath(__file__)]
+    hipcc = _hipcc()
+    jobs = []
+    for src, extra in SOURCES.items():
+        s = os.path.join(CSRC, src)
+        o = os.path.join(OBJ, src.replace(".hip", ".o"))
+        if force or _stale(o, [s] + headers):
+            jobs.append((src, [hipcc] + COMMON + extra + ["-c", s, "-o", o]))
+
+    def run(job):
+        name, cmd = job
+        if verbose:
+            print("[tln build]", " ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        return name, r
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        for name, r in ex.map(run, jobs):
+            if r.returncode != 0:
+                sys.stderr.write(r.stdout + r.stderr)
+                raise RuntimeError("hipcc failed on " + name)
+            if verbose and r.stderr.strip():
+                sys.stderr.write(r.stderr)
+    objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in SOURCES]
+    if force or jobs or _stale(LIB, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print("[tln build]", " ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            sys.stderr.write(r.stdout + r.stderr)
+            raise RuntimeError("link failed")
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(LIB)

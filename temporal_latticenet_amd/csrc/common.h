@@ -1,0 +1,93 @@
+// Shared helpers for the gfx950 kernels (wave64 everywhere).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/tln.h"
+
+#define TLN_WAVE 64
+
+void tln_set_error(const char* fmt, ...);
+
+#define TLN_HIP(call)                                                                   \
+  do {                                                                                  \
+    hipError_t _e = (call);                                                             \
+    if (_e != hipSuccess) {                                                             \
+      tln_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(_e)); \
+      return TLN_E_HIP;                                                                 \
+    }                                                                                   \
+  } while (0)
+
+#define TLN_REQUIRE(cond, ...)            \
+  do {                                    \
+    if (!(cond)) {                        \
+      tln_set_error(__VA_ARGS__);         \
+      return TLN_E_INVALID;               \
+    }                                     \
+  } while (0)
+
+#define TLN_LAUNCH_CHECK()                                                              \
+  do {                                                                                  \
+    hipError_t _e = hipGetLastError();                                                  \
+    if (_e != hipSuccess) {                                                             \
+      tln_set_error("%s:%d: launch -> %s", __FILE__, __LINE__, hipGetErrorString(_e));  \
+      return TLN_E_HIP;                                                                 \
+    }                                                                                   \
+  } while (0)
+
+static inline int64_t tln_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- device helpers -------------------------------------------------------------------
+__device__ __forceinline__ int tln_lane() { return threadIdx.x & 63; }
+
+__device__ __forceinline__ double tln_wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float tln_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ int tln_wave_sum(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// order-preserving map float -> uint32 (larger float => larger uint)
+__device__ __forceinline__ uint32_t tln_f2ord(float f) {
+  uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float tln_ord2f(uint32_t o) {
+  uint32_t u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+  return __uint_as_float(u);
+}
+
+// ---- key packing / hashing (d = 3) ------------------------------------------------------
+#define TLN_KEY_BIAS (1 << 20)
+#define TLN_KEY_EMPTY 0xFFFFFFFFFFFFFFFFull
+
+__host__ __device__ __forceinline__ bool tln_key_in_range(int k0, int k1, int k2) {
+  const int lim = TLN_KEY_BIAS;
+  return k0 >= -lim && k0 < lim && k1 >= -lim && k1 < lim && k2 >= -lim && k2 < lim;
+}
+__host__ __device__ __forceinline__ uint64_t tln_pack_key(int k0, int k1, int k2) {
+  return ((uint64_t)(uint32_t)(k0 + TLN_KEY_BIAS) << 42) | ((uint64_t)(uint32_t)(k1 + TLN_KEY_BIAS) << 21) |
+         (uint64_t)(uint32_t)(k2 + TLN_KEY_BIAS);
+}
+__host__ __device__ __forceinline__ void tln_unpack_key(uint64_t p, int& k0, int& k1, int& k2) {
+  k0 = (int)((p >> 42) & 0x1FFFFF) - TLN_KEY_BIAS;
+  k1 = (int)((p >> 21) & 0x1FFFFF) - TLN_KEY_BIAS;
+  k2 = (int)(p & 0x1FFFFF) - TLN_KEY_BIAS;
+}
+__host__ __device__ __forceinline__ uint64_t tln_mix64(uint64_t k) {
+  k ^= k >> 33;
+  k *= 0xff51afd7ed558ccdull;
+  k ^= k >> 33;
+  k *= 0xc4ceb9fe1a85ec53ull;
+  k ^= k >> 33;
+  return k;
+}

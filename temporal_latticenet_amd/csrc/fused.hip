@@ -1,0 +1,385 @@
+// K7 GroupNorm statistics, K9 GRU gates, K10 AFlow correlation, K8 slice, torch_scatter equivalents.
+#include "common.h"
+#include <math.h>
+
+// =======================================================================================
+// K7  GroupNorm over the lattice: statistics over (all vertices x channels of the group)
+//     (Gn / GnRelu1x1 / GnReluConv / GnReluCoarsen / GnReluFinefy; reference use lm:75, lm:100)
+// Two deterministic passes: per-row-block (sum, sumsq) in double, then a fixed-order combine.
+// The result is per-CHANNEL scale/shift consumed by the gather-GEMM prologue.
+// =======================================================================================
+#define GN_ROWS_PER_BLOCK 128
+#define GN_MAX_CT 8  // C <= 512
+
+__global__ void __launch_bounds__(256) k_gn_partial(const float* __restrict__ x, int64_t V, int C,
+                                                    double2* __restrict__ partial) {
+  __shared__ double2 red[4][64 * GN_MAX_CT];
+  const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+  const int64_t r0 = (int64_t)blockIdx.x * GN_ROWS_PER_BLOCK;
+  const int64_t r1 = (r0 + GN_ROWS_PER_BLOCK < V) ? r0 + GN_ROWS_PER_BLOCK : V;
+  const int nct = (C + 63) >> 6;
+  double s[GN_MAX_CT], q[GN_MAX_CT];
+#pragma unroll
+  for (int t = 0; t < GN_MAX_CT; ++t) s[t] = q[t] = 0.0;
+  for (int64_t r = r0 + ly; r < r1; r += 4) {
+    const float* row = x + r * C;
+#pragma unroll
+    for (int t = 0; t < GN_MAX_CT; ++t) {
+      const int c = t * 64 + lx;
+      if (t < nct && c < C) {
+        const double v = (double)row[c];
+        s[t] += v;
+        q[t] += v * v;
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < GN_MAX_CT; ++t)
+    if (t < nct) red[ly][t * 64 + lx] = make_double2(s[t], q[t]);
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    double2 a = red[0][c];
+    for (int w = 1; w < 4; ++w) {
+      a.x += red[w][c].x;
+      a.y += red[w][c].y;
+    }
+    partial[(int64_t)blockIdx.x * C + c] = a;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_gn_finalize(const double2* __restrict__ partial, int nblk, int64_t V, int C,
+                                                     int groups, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float eps,
+                                                     float* __restrict__ scale, float* __restrict__ shift) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int cpg = C / groups;
+  for (int g = blockIdx.x * 4 + wid; g < groups; g += gridDim.x * 4) {
+    double s = 0.0, q = 0.0;
+    const int64_t items = (int64_t)nblk * cpg;
+    for (int64_t i = lane; i < items; i += 64) {
+      const int64_t b = i / cpg;
+      const int c = g * cpg + (int)(i - b * cpg);
+      const double2 p = partial[b * C + c];
+      s += p.x;
+      q += p.y;
+    }
+    s = tln_wave_sum(s);
+    q = tln_wave_sum(q);
+    const double cnt = (double)V * (double)cpg;
+    const double mean = s / cnt;
+    double var = q / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    for (int c = g * cpg + lane; c < (g + 1) * cpg; c += 64) {
+      const double gm = gamma ? (double)gamma[c] : 1.0;
+      const double bt = beta ? (double)beta[c] : 0.0;
+      scale[c] = (float)(gm * rstd);
+      shift[c] = (float)(bt - mean * rstd * gm);
+    }
+  }
+}
+
+extern "C" int64_t tln_groupnorm_ws_bytes(int64_t V, int C) {
+  return tln_cdiv(V, GN_ROWS_PER_BLOCK) * (int64_t)C * (int64_t)sizeof(double2);
+}
+
+extern "C" int tln_groupnorm_stats(const float* d_x, int64_t V, int C, int groups, const float* d_gamma,
+                                   const float* d_beta, float eps, float* d_scale, float* d_shift, void* d_ws,
+                                   int64_t ws_bytes, void* stream_) {
+  TLN_REQUIRE(d_x && d_scale && d_shift && d_ws, "null argument");
+  TLN_REQUIRE(V > 0 && C > 0 && C <= 64 * GN_MAX_CT && groups > 0 && C % groups == 0, "bad groupnorm shape V=%lld C=%d G=%d",
+              (long long)V, C, groups);
+  TLN_REQUIRE(ws_bytes >= tln_groupnorm_ws_bytes(V, C), "groupnorm workspace too small");
+  hipStream_t s = (hipStream_t)stream_;
+  const int nblk = (int)tln_cdiv(V, GN_ROWS_PER_BLOCK);
+  hipLaunchKernelGGL(k_gn_partial, dim3(nblk), dim3(256), 0, s, d_x, V, C, (double2*)d_ws);
+  hipLaunchKernelGGL(k_gn_finalize, dim3((unsigned)tln_cdiv(groups, 4)), dim3(256), 0, s, (const double2*)d_ws, nblk, V,
+                     C, groups, d_gamma, d_beta, eps, d_scale, d_shift);
+  TLN_LAUNCH_CHECK();
+  return TLN_OK;
+}
+
+__global__ void __launch_bounds__(256) k_affine_act(const float* __restrict__ x, int64_t total, int C,
+                                                    const float* __restrict__ scale, const float* __restrict__ shift,
+                                                    int relu, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % C);
+  float v = fmaf(x[i], scale[c], shift[c]);
+  if (relu) v = fmaxf(v, 0.f);
+  out[i] = v;
+}
+
+extern "C" int tln_affine_act(const float* d_x, int64_t V, int C, const float* d_scale, const float* d_shift, int relu,
+                              float* d_out, void* stream_) {
+  TLN_REQUIRE(d_x && d_scale && d_shift && d_out, "null argument");
+  const int64_t total = V * C;
+  if (total <= 0) return TLN_OK;
+  hipLaunchKernelGGL(k_affine_act, dim3((unsigned)tln_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream_, d_x, total,
+                     C, d_scale, d_shift, relu, d_out);
+  TLN_LAUNCH_CHECK();
+  return TLN_OK;
+}
+
+// =======================================================================================
+// K9  GRU gates (torch.nn.GRUCell semantics, reference lm:62):
+//   r = sig(gi_r + gh_r), z = sig(gi_z + gh_z), n = tanh(gi_n + r * gh_n), h' = (1-z)*n + z*h
+// gi = x W_ih^T + b_ih and gh = h W_hh^T + b_hh come from two gather-GEMM launches; rows of h
+// beyond Vh are the zero padding of lm:59-60.
+// =======================================================================================
+__global__ void __launch_bounds__(256) k_gru_gates(const float* __restrict__ gi, const float* __restrict__ gh,
+                                                   const float* __restrict__ h, int64_t V, int64_t Vh, int C,
+                                                   float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= V * C) return;
+  const int64_t v = i / C;
+  const int c = (int)(i - v * C);
+  const float* a = gi + v * 3 * C;
+  const float* b = gh + v * 3 * C;
+  const float r = 1.0f / (1.0f + expf(-(a[c] + b[c])));
+  const float z = 1.0f / (1.0f + expf(-(a[C + c] + b[C + c])));
+  const float n = tanhf(a[2 * C + c] + r * b[2 * C + c]);
+  const float hp = (v < Vh) ? h[v * C + c] : 0.0f;
+  out[i] = (1.0f - z) * n + z * hp;
+}
+
+extern "C" int tln_gru_cell(const float* d_x, const float* d_h, int64_t V, int64_t Vh, int C, const float* d_w_ih,
+                            const float* d_w_hh, const float* d_b_ih, const float* d_b_hh, float* d_out, float* d_ws,
+                            int64_t ws_floats, void* stream_) {
+  TLN_REQUIRE(d_x && d_h && d_w_ih && d_w_hh && d_out && d_ws, "null argument");
+  TLN_REQUIRE(V > 0 && Vh >= 0 && Vh <= V && C > 0, "bad GRU shape V=%lld Vh=%lld C=%d", (long long)V, (long long)Vh, C);
+  TLN_REQUIRE(ws_floats >= V * 6 * (int64_t)C, "GRU workspace too small");
+  float* gi = d_ws;
+  float* gh = d_ws + V * 3 * (int64_t)C;
+  tln_gemm_src sx{};
+  sx.d_src = d_x;
+  sx.src_rows = V;
+  sx.ld = C;
+  sx.cin = C;
+  sx.taps = 1;
+  tln_gemm_src sh = sx;
+  sh.d_src = d_h;
+  sh.src_rows = Vh;
+  sh.pad_value = 0.0f;
+  int rc = tln_gather_gemm(V, 3 * C, &sx, nullptr, d_w_ih, 1, d_b_ih, nullptr, 0, 0, gi, 3 * C, stream_);
+  if (rc) return rc;
+  rc = tln_gather_gemm(V, 3 * C, &sh, nullptr, d_w_hh, 1, d_b_hh, nullptr, 0, 0, gh, 3 * C, stream_);
+  if (rc) return rc;
+  const int64_t total = V * C;
+  hipLaunchKernelGGL(k_gru_gates, dim3((unsigned)tln_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream_, gi, gh, d_h,
+                     V, Vh, C, d_out);
+  TLN_LAUNCH_CHECK();
+  return TLN_OK;
+}
+
+// =======================================================================================
+// K10 AFlow correlation (CustomKernelConvLatticeIm2RowModule.forward, reference lm:298-339).
+// One wave per vertex: distances of the 9 (padded) hidden-state rows to the current centre feature,
+// mask, row-normalise, w = (alpha - min(d, alpha)) * beta, mask, weighted sum of the rows, + bias.
+// =======================================================================================
+__device__ __forceinline__ float aflow_row_elem(const float* __restrict__ h, int64_t Vh, int C, int idx, int c,
+                                                float pad) {
+  if (idx < 0) return 0.0f;             // im2row zero row for a missing neighbour
+  if (idx >= Vh) return pad;            // hidden state padded for vertices born in this frame (lm:215)
+  return h[(int64_t)idx * C + c];
+}
+
+__global__ void __launch_bounds__(256) k_aflow(const float* __restrict__ x, const float* __restrict__ h, int64_t V,
+                                               int64_t Vh, int C, const int32_t* __restrict__ table, float alpha,
+                                               float beta, float pad, int use_center, const float* __restrict__ bias,
+                                               float* __restrict__ out, float* __restrict__ weights,
+                                               int32_t* __restrict__ nbr_idx) {
+  const int64_t v = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (v >= V) return;
+  const int lane = threadIdx.x & 63;
+  int idx[TLN_TAPS];
+  float dist[TLN_TAPS];
+#pragma unroll
+  for (int t = 0; t < TLN_TAPS; ++t) idx[t] = table[v * TLN_TAPS + t];
+#pragma unroll
+  for (int t = 0; t < TLN_TAPS; ++t) {
+    float acc = 0.0f;
+    for (int c = lane; c < C; c += 64) {
+      const float d = aflow_row_elem(h, Vh, C, idx[t], c, pad) - x[v * C + c];
+      acc = fmaf(d, d, acc);
+    }
+    acc = tln_wave_sum(acc);
+    dist[t] = sqrtf(acc) * ((idx[t] != -1) ? 1.0f : 0.0f);
+  }
+  if (!use_center) dist[TLN_TAPS - 1] = dist[TLN_TAPS - 1] * 0.0f;
+  float rs = 0.0f;
+#pragma unroll
+  for (int t = 0; t < TLN_TAPS; ++t) rs += dist[t];
+  float w[TLN_TAPS];
+#pragma unroll
+  for (int t = 0; t < TLN_TAPS; ++t) {
+    const float dn = dist[t] * 1.0f / rs;  // (d * 1) / sum, as written at lm:321 (0/0 -> NaN is kept)
+    float wt = (alpha - fminf(dn, alpha)) * beta;
+    // torch.min propagates NaN, fminf does not
+    if (dn != dn) wt = dn;
+    wt = wt * ((idx[t] != -1) ? 1.0f : 0.0f);
+    w[t] = wt;
+  }
+  if (!use_center) w[TLN_TAPS - 1] = w[TLN_TAPS - 1] * 0.0f;
+  for (int c = lane; c < C; c += 64) {
+    float acc = 0.0f;
+#pragma unroll
+    for (int t = 0; t < TLN_TAPS; ++t) acc += aflow_row_elem(h, Vh, C, idx[t], c, pad) * w[t];
+    if (bias) acc += bias[c];
+    out[v * C + c] = acc;
+  }
+  if (lane < TLN_TAPS) {
+    float wl = w[0];
+    int il = idx[0];
+#pragma unroll
+    for (int t = 1; t < TLN_TAPS; ++t)
+      if (lane == t) {
+        wl = w[t];
+        il = idx[t];
+      }
+    weights[v * TLN_TAPS + lane] = wl;
+    nbr_idx[v * TLN_TAPS + lane] = il;
+  }
+}
+
+extern "C" int tln_aflow(const float* d_x, const float* d_h, int64_t V, int64_t Vh, int C, const int32_t* d_table,
+                         float alpha, float beta, float pad_value, int use_center, const float* d_bias, float* d_out,
+                         float* d_weights, int32_t* d_nbr_idx, void* stream_) {
+  TLN_REQUIRE(d_x && d_h && d_table && d_out && d_weights && d_nbr_idx, "null argument");
+  TLN_REQUIRE(V > 0 && Vh >= 0 && C > 0, "bad AFlow shape");
+  hipLaunchKernelGGL(k_aflow, dim3((unsigned)tln_cdiv(V * 64, 256)), dim3(256), 0, (hipStream_t)stream_, d_x, d_h, V, Vh,
+                     C, d_table, alpha, beta, pad_value, use_center, d_bias, d_out, d_weights, d_nbr_idx);
+  TLN_LAUNCH_CHECK();
+  return TLN_OK;
+}
+
+// =======================================================================================
+// K8 slice (SliceFastCUDALatticeModule models.py:465, SliceLatticeModule)
+// =======================================================================================
+__global__ void __launch_bounds__(256) k_slice_gather(const float* __restrict__ lv, int64_t V, int cb,
+                                                      const int32_t* __restrict__ indices,
+                                                      const float* __restrict__ weights, int64_t n,
+                                                      float* __restrict__ out) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int per = 4 * (cb + 1);
+  const int64_t p = gid / per;
+  if (p >= n) return;
+  const int k = (int)(gid - p * per);
+  const int r = k / (cb + 1), c = k - r * (cb + 1);
+  const int idx = indices[4 * p + r];
+  const float w = weights[4 * p + r];
+  float v = 0.0f;
+  if (idx >= 0 && idx < V) v = (c < cb) ? w * lv[(int64_t)idx * cb + c] : w;
+  out[gid] = v;
+}
+
+extern "C" int tln_slice_gather(const float* d_lv, int64_t V, int cb, const int32_t* d_indices, const float* d_weights,
+                                int64_t n, float* d_out, void* stream_) {
+  TLN_REQUIRE(d_lv && d_indices && d_weights && d_out && cb > 0, "null argument");
+  if (n <= 0) return TLN_OK;
+  const int64_t total = n * 4 * (cb + 1);
+  hipLaunchKernelGGL(k_slice_gather, dim3((unsigned)tln_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream_, d_lv, V,
+                     cb, d_indices, d_weights, n, d_out);
+  TLN_LAUNCH_CHECK();
+  return TLN_OK;
+}
+
+__global__ void __launch_bounds__(256) k_slice(const float* __restrict__ lv, int64_t V, int C,
+                                               const int32_t* __restrict__ indices, const float* __restrict__ weights,
+                                               const float* __restrict__ delta, int64_t n, float* __restrict__ out) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t p = gid / C;
+  if (p >= n) return;
+  const int c = (int)(gid - p * C);
+  float acc = 0.0f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int idx = indices[4 * p + r];
+    float w = weights[4 * p + r];
+    if (delta) w += delta[4 * p + r];
+    if (idx >= 0 && idx < V) acc = fmaf(w, lv[(int64_t)idx * C + c], acc);
+  }
+  out[gid] = acc;
+}
+
+extern "C" int tln_slice(const float* d_lv, int64_t V, int C, const int32_t* d_indices, const float* d_weights,
+                         const float* d_delta, int64_t n, float* d_out, void* stream_) {
+  TLN_REQUIRE(d_lv && d_indices && d_weights && d_out && C > 0, "null argument");
+  if (n <= 0) return TLN_OK;
+  const int64_t total = n * C;
+  hipLaunchKernelGGL(k_slice, dim3((unsigned)tln_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream_, d_lv, V, C,
+                     d_indices, d_weights, d_delta, n, d_out);
+  TLN_LAUNCH_CHECK();
+  return TLN_OK;
+}
+
+// =======================================================================================
+// torch_scatter 2.0.4 equivalents (reference lm:485-520, models.py:454); dim=0 only
+// =======================================================================================
+__global__ void __launch_bounds__(256) k_scatter_max_pack(const float* __restrict__ src,
+                                                          const int64_t* __restrict__ index, int64_t rows, int C,
+                                                          int64_t out_rows, unsigned long long* __restrict__ packed) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t r = gid / C;
+  if (r >= rows) return;
+  const int c = (int)(gid - r * C);
+  const int64_t o = index[r];
+  if (o < 0 || o >= out_rows) return;
+  const unsigned long long p = ((unsigned long long)tln_f2ord(src[gid]) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)r);
+  atomicMax(&packed[o * C + c], p);
+}
+
+__global__ void __launch_bounds__(256) k_scatter_max_unpack(const unsigned long long* __restrict__ packed, int64_t total,
+                                                            int64_t rows, float* __restrict__ out,
+                                                            int64_t* __restrict__ argmax) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= total) return;
+  const unsigned long long p = packed[gid];
+  if (p == 0ull) {
+    out[gid] = 0.0f;
+    if (argmax) argmax[gid] = rows;
+  } else {
+    out[gid] = tln_ord2f((uint32_t)(p >> 32));
+    if (argmax) argmax[gid] = (int64_t)(0xFFFFFFFFu - (uint32_t)(p & 0xFFFFFFFFull));
+  }
+}
+
+extern "C" int tln_scatter_max(const float* d_src, const int64_t* d_index, int64_t rows, int C, int64_t out_rows,
+                               float* d_out, int64_t* d_argmax, void* d_ws, int64_t ws_bytes, void* stream_) {
+  TLN_REQUIRE(d_src && d_index && d_out && d_ws && C > 0, "null argument");
+  TLN_REQUIRE(ws_bytes >= out_rows * C * 8, "scatter_max workspace too small");
+  TLN_REQUIRE(rows < (1ll << 32), "too many rows");
+  hipStream_t s = (hipStream_t)stream_;
+  const int64_t total = out_rows * C;
+  if (total <= 0) return TLN_OK;
+  TLN_HIP(hipMemsetAsync(d_ws, 0, (size_t)total * 8, s));
+  if (rows > 0)
+    hipLaunchKernelGGL(k_scatter_max_pack, dim3((unsigned)tln_cdiv(rows * C, 256)), dim3(256), 0, s, d_src, d_index,
+                       rows, C, out_rows, (unsigned long long*)d_ws);
+  hipLaunchKernelGGL(k_scatter_max_unpack, dim3((unsigned)tln_cdiv(total, 256)), dim3(256), 0, s,
+                     (const unsigned long long*)d_ws, total, rows, d_out, d_argmax);
+  TLN_LAUNCH_CHECK();
+  return TLN_OK;
+}
+
+__global__ void __launch_bounds__(256) k_scatter_add(const float* __restrict__ src, const int64_t* __restrict__ index,
+                                                     int64_t rows, int C, int64_t out_rows, float* __restrict__ out) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t r = gid / C;
+  if (r >= rows) return;
+  const int c = (int)(gid - r * C);
+  const int64_t o = index[r];
+  if (o < 0 || o >= out_rows) return;
+  atomicAdd(&out[o * C + c], src[gid]);
+}
+
+// d_out must be zero-initialised (or hold the `out=` tensor of torch_scatter) by the caller
+extern "C" int tln_scatter_add(const float* d_src, const int64_t* d_index, int64_t rows, int C, int64_t out_rows,
+                               float* d_out, void* stream_) {
+  TLN_REQUIRE(d_src && d_index && d_out && C > 0, "null argument");
+  if (rows <= 0) return TLN_OK;
+  hipLaunchKernelGGL(k_scatter_add, dim3((unsigned)tln_cdiv(rows * C, 256)), dim3(256), 0, (hipStream_t)stream_, d_src,
+                     d_index, rows, C, out_rows, d_out);
+  TLN_LAUNCH_CHECK();
+  return TLN_OK;
+}

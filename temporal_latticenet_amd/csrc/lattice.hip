@@ -1,0 +1,830 @@
+// Lattice structure for gfx950: hash table with deterministic first-touch numbering,
+// K1 distribute, vertex-sorted row list (CSR), neighbour and cross-level tables.
+//
+// Replaces latticenet.Lattice + DistributeLatticeModule + the structural half of
+// GnReluCoarsen/GnReluFinefy (reference call sites: train_ln.py:106,239; models.py:298,353,398;
+// lattice_modules.py:285-304).  The arithmetic follows oracle/permuto.py step by step and must
+// produce bit-identical integer outputs; this file is therefore compiled with FP contraction OFF.
+#pragma clang fp contract(off)
+#include "common.h"
+#include <hipcub/hipcub.hpp>
+#include <stdarg.h>
+#include <string.h>
+#include <math.h>
+
+// ---------------------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void tln_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* tln_last_error(void) { return g_err; }
+extern "C" int tln_version(void) { return 1; }
+
+// ---------------------------------------------------------------------------------------
+// handle
+// ---------------------------------------------------------------------------------------
+enum { CTR_NV = 0, CTR_NEW = 1, CTR_OVERFLOW = 2, CTR_PROBE_FAIL = 3, CTR_VOLD = 4, CTR_COUNT = 8 };
+#define TLN_MAX_PROBES 8192
+#define TLN_SCAN_BLOCK 1024
+
+struct tln_lattice {
+  int pos_dim = 3, level = 0;
+  int64_t capacity = 0, nslots = 0;
+  double sigmas[3] = {1, 1, 1};
+  float scale[3] = {1, 1, 1};
+  uint64_t* slot_key = nullptr;
+  int32_t* slot_val = nullptr;
+  uint32_t* slot_touch = nullptr;
+  int32_t* vkeys = nullptr;  // [capacity][4]
+  int32_t* d_ctr = nullptr;
+  int32_t* h_ctr = nullptr;
+  int64_t nr_vertices = 0, overflow_rows = 0;
+  // tables (owned)
+  int32_t* nbr = nullptr;
+  int64_t nbr_built_for = -1;
+  tln_lattice* coarse = nullptr;
+  tln_lattice* parent = nullptr;
+  int32_t* c2f = nullptr;
+  int64_t c2f_vc = -1, c2f_vf = -1;
+  int32_t* f2c = nullptr;
+  int64_t f2c_vc = -1, f2c_vf = -1;
+  int64_t embedded_fine = 0;
+  // per-call row workspace
+  int64_t rows_cap = 0;
+  int32_t* row_slot = nullptr;
+  int32_t* block_cnt = nullptr;
+  int32_t *sk_in = nullptr, *sk_out = nullptr, *sv_in = nullptr, *sv_out = nullptr;
+  void* sort_temp = nullptr;
+  size_t sort_temp_bytes = 0;
+  int32_t* seg_start = nullptr;  // [capacity+2]
+  int64_t csr_rows = -1;
+  // pool workspace
+  unsigned long long* pool_packed = nullptr;
+  int64_t pool_packed_elems = 0;
+};
+
+// accessors for the other translation units
+const int32_t* tln_lat_order(const tln_lattice* l) { return l->sv_out; }
+const int32_t* tln_lat_sorted_vertex(const tln_lattice* l) { return l->sk_out; }
+const int32_t* tln_lat_seg_start(const tln_lattice* l) { return l->seg_start; }
+int64_t tln_lat_csr_rows(const tln_lattice* l) { return l->csr_rows; }
+int tln_lat_pool_ws(tln_lattice* l, int64_t elems, unsigned long long** out) {
+  if (elems > l->pool_packed_elems) {
+    if (l->pool_packed) (void)hipFree(l->pool_packed);
+    l->pool_packed = nullptr;
+    l->pool_packed_elems = 0;
+    TLN_HIP(hipMalloc(&l->pool_packed, (size_t)elems * sizeof(unsigned long long)));
+    l->pool_packed_elems = elems;
+  }
+  *out = l->pool_packed;
+  return TLN_OK;
+}
+
+static int bits_for(int64_t v) {
+  int b = 1;
+  while ((1ll << b) <= v) ++b;
+  return b;
+}
+
+static int ensure_rows(tln_lattice* l, int64_t rows) {
+  if (rows <= l->rows_cap) return TLN_OK;
+  int64_t cap = 1;
+  while (cap < rows) cap <<= 1;
+  void* ptrs[] = {l->row_slot, l->block_cnt, l->sk_in, l->sk_out, l->sv_in, l->sv_out, l->sort_temp};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  l->row_slot = l->block_cnt = l->sk_in = l->sk_out = l->sv_in = l->sv_out = nullptr;
+  l->sort_temp = nullptr;
+  l->rows_cap = 0;
+  TLN_HIP(hipMalloc(&l->row_slot, cap * sizeof(int32_t)));
+  TLN_HIP(hipMalloc(&l->block_cnt, (cap / TLN_SCAN_BLOCK + 2) * sizeof(int32_t)));
+  TLN_HIP(hipMalloc(&l->sk_in, cap * sizeof(int32_t)));
+  TLN_HIP(hipMalloc(&l->sk_out, cap * sizeof(int32_t)));
+  TLN_HIP(hipMalloc(&l->sv_in, cap * sizeof(int32_t)));
+  TLN_HIP(hipMalloc(&l->sv_out, cap * sizeof(int32_t)));
+  size_t bytes = 0;
+  TLN_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, l->sk_in, l->sk_out, l->sv_in, l->sv_out, (int)cap, 0, 32,
+                                             (hipStream_t)0));
+  TLN_HIP(hipMalloc(&l->sort_temp, bytes + 256));
+  l->sort_temp_bytes = bytes + 256;
+  l->rows_cap = cap;
+  return TLN_OK;
+}
+
+static int lattice_alloc(tln_lattice** out, int pos_dim, const double* sigmas, int64_t capacity, int level) {
+  TLN_REQUIRE(pos_dim == 3, "pos_dim %d unsupported (only 3)", pos_dim);
+  TLN_REQUIRE(capacity >= 16 && capacity <= (1ll << 26), "capacity %lld out of range", (long long)capacity);
+  tln_lattice* l = new tln_lattice();
+  l->pos_dim = pos_dim;
+  l->level = level;
+  l->capacity = capacity;
+  int64_t ns = 1;
+  while (ns < 2 * capacity) ns <<= 1;
+  l->nslots = ns;
+  for (int i = 0; i < 3; ++i) {
+    l->sigmas[i] = sigmas[i];
+    l->scale[i] = (float)(1.0 / (sigmas[i] * sqrt((double)((i + 1) * (i + 2)))));
+  }
+  TLN_HIP(hipMalloc(&l->slot_key, ns * sizeof(uint64_t)));
+  TLN_HIP(hipMalloc(&l->slot_val, ns * sizeof(int32_t)));
+  TLN_HIP(hipMalloc(&l->slot_touch, ns * sizeof(uint32_t)));
+  TLN_HIP(hipMalloc(&l->vkeys, capacity * 4 * sizeof(int32_t)));
+  TLN_HIP(hipMalloc(&l->d_ctr, CTR_COUNT * sizeof(int32_t)));
+  TLN_HIP(hipHostMalloc(&l->h_ctr, CTR_COUNT * sizeof(int32_t)));
+  TLN_HIP(hipMalloc(&l->seg_start, (capacity + 2) * sizeof(int32_t)));
+  *out = l;
+  return TLN_OK;
+}
+
+extern "C" int tln_lattice_clear(tln_lattice_t* l, void* stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  for (tln_lattice* p = l; p; p = p->coarse) {
+    TLN_HIP(hipMemsetAsync(p->slot_key, 0xFF, p->nslots * sizeof(uint64_t), s));
+    TLN_HIP(hipMemsetAsync(p->slot_val, 0xFF, p->nslots * sizeof(int32_t), s));
+    TLN_HIP(hipMemsetAsync(p->slot_touch, 0xFF, p->nslots * sizeof(uint32_t), s));
+    TLN_HIP(hipMemsetAsync(p->d_ctr, 0, CTR_COUNT * sizeof(int32_t), s));
+    p->nr_vertices = 0;
+    p->overflow_rows = 0;
+    p->nbr_built_for = -1;
+    p->c2f_vc = p->c2f_vf = p->f2c_vc = p->f2c_vf = -1;
+    p->embedded_fine = 0;
+    p->csr_rows = -1;
+  }
+  return TLN_OK;
+}
+
+extern "C" int tln_lattice_create(tln_lattice_t** out, int pos_dim, const double* sigmas, int64_t capacity) {
+  TLN_REQUIRE(out && sigmas, "null argument");
+  int rc = lattice_alloc(out, pos_dim, sigmas, capacity, 0);
+  if (rc) return rc;
+  rc = tln_lattice_clear(*out, nullptr);
+  if (rc) return rc;
+  TLN_HIP(hipStreamSynchronize(nullptr));
+  return TLN_OK;
+}
+
+extern "C" int tln_lattice_destroy(tln_lattice_t* l) {
+  if (!l) return TLN_OK;
+  if (l->coarse) tln_lattice_destroy(l->coarse);
+  void* ptrs[] = {l->slot_key, l->slot_val, l->slot_touch, l->vkeys, l->d_ctr, l->nbr, l->c2f, l->f2c,
+                  l->row_slot, l->block_cnt, l->sk_in, l->sk_out, l->sv_in, l->sv_out, l->sort_temp,
+                  l->seg_start, l->pool_packed};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  if (l->h_ctr) (void)hipHostFree(l->h_ctr);
+  delete l;
+  return TLN_OK;
+}
+
+extern "C" int64_t tln_lattice_nr_vertices(const tln_lattice_t* l) { return l ? l->nr_vertices : -1; }
+extern "C" int64_t tln_lattice_capacity(const tln_lattice_t* l) { return l ? l->capacity : -1; }
+extern "C" int tln_lattice_level(const tln_lattice_t* l) { return l ? l->level : -1; }
+extern "C" int64_t tln_lattice_overflow_rows(const tln_lattice_t* l) { return l ? l->overflow_rows : -1; }
+
+// ---------------------------------------------------------------------------------------
+// device: table access
+// ---------------------------------------------------------------------------------------
+struct TableRef {
+  uint64_t* slot_key;
+  int32_t* slot_val;
+  uint32_t* slot_touch;
+  uint64_t mask;
+};
+static TableRef table_ref(const tln_lattice* l) {
+  return TableRef{l->slot_key, l->slot_val, l->slot_touch, (uint64_t)(l->nslots - 1)};
+}
+
+// find-or-claim the slot of key K; records the smallest row id touching a not-yet-numbered slot
+__device__ __forceinline__ int probe_insert(const TableRef& t, uint64_t K, uint32_t id) {
+  uint64_t slot = tln_mix64(K) & t.mask;
+  for (int probe = 0; probe < TLN_MAX_PROBES; ++probe) {
+    uint64_t cur = t.slot_key[slot];
+    if (cur == TLN_KEY_EMPTY) {
+      cur = atomicCAS((unsigned long long*)&t.slot_key[slot], (unsigned long long)TLN_KEY_EMPTY, (unsigned long long)K);
+      if (cur == TLN_KEY_EMPTY) cur = K;
+    }
+    if (cur == K) {
+      if (t.slot_val[slot] < 0) {
+        if (t.slot_touch[slot] > id) atomicMin(&t.slot_touch[slot], id);
+      }
+      return (int)slot;
+    }
+    slot = (slot + 1) & t.mask;
+  }
+  return -1;
+}
+
+// read-only lookup -> vertex index or -1
+__device__ __forceinline__ int probe_find(const TableRef& t, uint64_t K) {
+  uint64_t slot = tln_mix64(K) & t.mask;
+  for (int probe = 0; probe < TLN_MAX_PROBES; ++probe) {
+    uint64_t cur = t.slot_key[slot];
+    if (cur == K) return t.slot_val[slot];
+    if (cur == TLN_KEY_EMPTY) return -1;
+    slot = (slot + 1) & t.mask;
+  }
+  return -1;
+}
+
+// ---------------------------------------------------------------------------------------
+// device: simplex arithmetic (oracle/permuto.py S2 and S5)
+// ---------------------------------------------------------------------------------------
+// point -> rem0[4], rank[4], bary[4]   (d = 3)
+__device__ __forceinline__ void point_simplex(float x, float y, float z, float s0, float s1, float s2, int rem0[4],
+                                              int rank[4], float bary[4]) {
+  const float cf0 = x * s0, cf1 = y * s1, cf2 = z * s2;
+  float e[4];
+  float sm = 0.0f;
+  e[3] = sm - 3.0f * cf2;
+  sm = sm + cf2;
+  e[2] = sm - 2.0f * cf1;
+  sm = sm + cf1;
+  e[1] = sm - 1.0f * cf0;
+  sm = sm + cf0;
+  e[0] = sm;
+  float rf[4];
+  int ssum = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float v = e[i] * 0.25f;
+    const float up = ceilf(v) * 4.0f, down = floorf(v) * 4.0f;
+    rf[i] = ((up - e[i]) < (e[i] - down)) ? up : down;
+    rem0[i] = (int)rf[i];
+    ssum += rem0[i];
+    rank[i] = 0;
+  }
+  ssum /= 4;  // exact: the sum is a multiple of 4
+  float df[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) df[i] = e[i] - rf[i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = i + 1; j < 4; ++j) {
+      const bool lt = df[i] < df[j];
+      rank[i] += lt ? 1 : 0;
+      rank[j] += lt ? 0 : 1;
+    }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const bool pf = (ssum > 0) && (rank[i] >= 4 - ssum);
+    const bool nf = (ssum < 0) && (rank[i] < -ssum);
+    rem0[i] += (nf ? 4 : 0) - (pf ? 4 : 0);
+    rank[i] += ssum + (nf ? 4 : 0) - (pf ? 4 : 0);
+  }
+  float b[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float delta = (e[i] - (float)rem0[i]) * 0.25f;
+    const int a = 3 - rank[i], c = 4 - rank[i];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      if (j == a) b[j] = b[j] + delta;
+      if (j == c) b[j] = b[j] - delta;
+    }
+  }
+  b[0] = b[0] + (1.0f + b[4]);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) bary[j] = b[j];
+}
+
+__device__ __forceinline__ void vertex_key(const int rem0[4], const int rank[4], int r, int& k0, int& k1, int& k2) {
+  k0 = rem0[0] + r - ((rank[0] > 3 - r) ? 4 : 0);
+  k1 = rem0[1] + r - ((rank[1] > 3 - r) ? 4 : 0);
+  k2 = rem0[2] + r - ((rank[2] > 3 - r) ? 4 : 0);
+}
+
+// fine key -> the coarse simplex around f/2 (integer arithmetic in units of 1/2)
+__device__ __forceinline__ void coarse_simplex(int f0, int f1, int f2, int rem0[4], int rank[4], int bn[4]) {
+  int e[4] = {f0, f1, f2, -(f0 + f1 + f2)};
+  int r[4];
+  int ssum = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int down = e[i] & ~7;  // floor to a multiple of 8
+    const int up = (e[i] != down) ? down + 8 : down;
+    r[i] = ((up - e[i]) < (e[i] - down)) ? up : down;
+    ssum += r[i];
+    rank[i] = 0;
+  }
+  ssum /= 8;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = i + 1; j < 4; ++j) {
+      const bool lt = (e[i] - r[i]) < (e[j] - r[j]);
+      rank[i] += lt ? 1 : 0;
+      rank[j] += lt ? 0 : 1;
+    }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const bool pf = (ssum > 0) && (rank[i] >= 4 - ssum);
+    const bool nf = (ssum < 0) && (rank[i] < -ssum);
+    r[i] += (nf ? 8 : 0) - (pf ? 8 : 0);
+    rank[i] += ssum + (nf ? 4 : 0) - (pf ? 4 : 0);
+  }
+  int b[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int delta = e[i] - r[i];
+    const int a = 3 - rank[i], c = 4 - rank[i];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      if (j == a) b[j] += delta;
+      if (j == c) b[j] -= delta;
+    }
+  }
+  b[0] += 8 + b[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    rem0[i] = r[i] / 2;
+    bn[i] = b[i];
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// phase A kernels: compute keys, claim slots
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_distribute_insert(const float* __restrict__ pos, const float* __restrict__ val,
+                                                           int64_t n, int val_dim, float s0, float s1, float s2,
+                                                           TableRef t, int32_t* __restrict__ row_slot,
+                                                           float* __restrict__ weights, float* __restrict__ dist) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const float x = pos[3 * p], y = pos[3 * p + 1], z = pos[3 * p + 2];
+  int rem0[4], rank[4];
+  float bary[4];
+  point_simplex(x, y, z, s0, s1, s2, rem0, rank, bary);
+  const int cols = 3 + val_dim + 1;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    int k0, k1, k2;
+    vertex_key(rem0, rank, r, k0, k1, k2);
+    const uint32_t id = (uint32_t)(4 * p + r);
+    int slot = -1;
+    if (tln_key_in_range(k0, k1, k2)) slot = probe_insert(t, tln_pack_key(k0, k1, k2), id);
+    row_slot[id] = slot;
+    weights[id] = bary[r];
+    float* row = dist + (int64_t)id * cols;
+    row[0] = x;
+    row[1] = y;
+    row[2] = z;
+    for (int c = 0; c < val_dim; ++c) row[3 + c] = val[p * val_dim + c];
+    row[3 + val_dim] = bary[r];
+  }
+}
+
+// coarse embedding of the fine vertices [first, first+count)
+__global__ void __launch_bounds__(256) k_coarsen_insert(const int32_t* __restrict__ fine_keys, int64_t first,
+                                                        int64_t count, TableRef t, int32_t* __restrict__ row_slot) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const int32_t* fk = fine_keys + 4 * (first + i);
+  int rem0[4], rank[4], bn[4];
+  coarse_simplex(fk[0], fk[1], fk[2], rem0, rank, bn);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const uint32_t id = (uint32_t)(4 * i + r);
+    int slot = -1;
+    if (bn[r] > 0) {
+      int k0, k1, k2;
+      vertex_key(rem0, rank, r, k0, k1, k2);
+      if (tln_key_in_range(k0, k1, k2)) slot = probe_insert(t, tln_pack_key(k0, k1, k2), id);
+    }
+    row_slot[id] = slot;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_insert_keys(const int32_t* __restrict__ keys, int64_t n, TableRef t,
+                                                     int32_t* __restrict__ row_slot) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int k0 = keys[3 * i], k1 = keys[3 * i + 1], k2 = keys[3 * i + 2];
+  int slot = -1;
+  if (tln_key_in_range(k0, k1, k2)) slot = probe_insert(t, tln_pack_key(k0, k1, k2), (uint32_t)i);
+  row_slot[i] = slot;
+}
+
+// ---------------------------------------------------------------------------------------
+// phase B: number the new slots in first-touch order (ballot + prefix sums)
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ bool is_first_touch(const TableRef& t, const int32_t* row_slot, int64_t id, int64_t rows,
+                                               int& slot) {
+  slot = -1;
+  if (id >= rows) return false;
+  slot = row_slot[id];
+  if (slot < 0) return false;
+  return t.slot_val[slot] < 0 && t.slot_touch[slot] == (uint32_t)id;
+}
+
+__global__ void __launch_bounds__(TLN_SCAN_BLOCK) k_count_new(TableRef t, const int32_t* __restrict__ row_slot,
+                                                              int64_t rows, int32_t* __restrict__ block_cnt) {
+  __shared__ int wave_cnt[TLN_SCAN_BLOCK / 64];
+  const int64_t id = (int64_t)blockIdx.x * TLN_SCAN_BLOCK + threadIdx.x;
+  int slot;
+  const bool f = is_first_touch(t, row_slot, id, rows, slot);
+  const unsigned long long m = __ballot(f);
+  if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = __popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int s = 0;
+    for (int w = 0; w < TLN_SCAN_BLOCK / 64; ++w) s += wave_cnt[w];
+    block_cnt[blockIdx.x] = s;
+  }
+}
+
+// single block: exclusive scan of block_cnt (in place), update the vertex counter
+__global__ void __launch_bounds__(1024) k_scan_blocks(int32_t* __restrict__ block_cnt, int nblocks,
+                                                      int32_t* __restrict__ ctr, int capacity) {
+  __shared__ int wave_tot[16];
+  __shared__ int carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  for (int base = 0; base < nblocks; base += 1024) {
+    const int i = base + threadIdx.x;
+    const int v = (i < nblocks) ? block_cnt[i] : 0;
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int u = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += u;
+    }
+    if (lane == 63) wave_tot[wid] = incl;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wid; ++w) woff += wave_tot[w];
+    const int carry = carry_s;
+    if (i < nblocks) block_cnt[i] = carry + woff + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry_s = carry + woff + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const int total = carry_s;
+    const int vold = ctr[CTR_NV];
+    ctr[CTR_VOLD] = vold;
+    ctr[CTR_NEW] = total;
+    long long vnew = (long long)vold + total;
+    ctr[CTR_NV] = (int)(vnew < capacity ? vnew : capacity);
+  }
+}
+
+__global__ void __launch_bounds__(TLN_SCAN_BLOCK) k_assign_new(TableRef t, const int32_t* __restrict__ row_slot,
+                                                               int64_t rows, const int32_t* __restrict__ block_off,
+                                                               const int32_t* __restrict__ ctr, int capacity,
+                                                               int32_t* __restrict__ vkeys) {
+  __shared__ int wave_cnt[TLN_SCAN_BLOCK / 64];
+  const int64_t id = (int64_t)blockIdx.x * TLN_SCAN_BLOCK + threadIdx.x;
+  int slot;
+  const bool f = is_first_touch(t, row_slot, id, rows, slot);
+  const unsigned long long m = __ballot(f);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) wave_cnt[wid] = __popcll(m);
+  __syncthreads();
+  if (!f) return;
+  int woff = 0;
+  for (int w = 0; w < wid; ++w) woff += wave_cnt[w];
+  const int rank = block_off[blockIdx.x] + woff + __popcll(m & ((1ull << lane) - 1ull));
+  const long long v = (long long)ctr[CTR_VOLD] + rank;
+  if (v < capacity) {
+    t.slot_val[slot] = (int)v;
+    int k0, k1, k2;
+    tln_unpack_key(t.slot_key[slot], k0, k1, k2);
+    int4 kk = make_int4(k0, k1, k2, -(k0 + k1 + k2));
+    *reinterpret_cast<int4*>(vkeys + 4 * v) = kk;
+  } else {
+    t.slot_touch[slot] = 0xFFFFFFFFu;  // stays un-numbered; may be retried by a later insertion
+  }
+}
+
+// phase C: per-row vertex index (+ sort input for the CSR)
+__global__ void __launch_bounds__(256) k_row_indices(TableRef t, const int32_t* __restrict__ row_slot, int64_t rows,
+                                                     int32_t* __restrict__ indices, int32_t* __restrict__ ctr,
+                                                     int32_t* __restrict__ sk_in, int32_t* __restrict__ sv_in) {
+  const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= rows) return;
+  const int slot = row_slot[id];
+  int idx = -1;
+  if (slot >= 0) idx = t.slot_val[slot];
+  if (indices) indices[id] = idx;
+  if (idx < 0) atomicAdd(&ctr[CTR_OVERFLOW], 1);
+  if (sk_in) {
+    sk_in[id] = idx < 0 ? ctr[CTR_NV] : idx;  // tail bucket V for rejected rows
+    sv_in[id] = (int32_t)id;
+  }
+}
+
+static int number_new(tln_lattice* l, int64_t rows, hipStream_t s) {
+  const int nblocks = (int)tln_cdiv(rows, TLN_SCAN_BLOCK);
+  TableRef t = table_ref(l);
+  hipLaunchKernelGGL(k_count_new, dim3(nblocks), dim3(TLN_SCAN_BLOCK), 0, s, t, l->row_slot, rows, l->block_cnt);
+  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, l->block_cnt, nblocks, l->d_ctr, (int)l->capacity);
+  hipLaunchKernelGGL(k_assign_new, dim3(nblocks), dim3(TLN_SCAN_BLOCK), 0, s, t, l->row_slot, rows, l->block_cnt,
+                     l->d_ctr, (int)l->capacity, l->vkeys);
+  TLN_LAUNCH_CHECK();
+  return TLN_OK;
+}
+
+static int fetch_counters(tln_lattice* l, hipStream_t s) {
+  TLN_HIP(hipMemcpyAsync(l->h_ctr, l->d_ctr, CTR_COUNT * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  TLN_HIP(hipStreamSynchronize(s));
+  l->nr_vertices = l->h_ctr[CTR_NV];
+  return TLN_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// CSR: rows sorted by vertex (stable), segment starts by binary search
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_seg_start(const int32_t* __restrict__ sorted_keys, int64_t rows, int64_t nv,
+                                                   int32_t* __restrict__ seg_start) {
+  const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v > nv + 1) return;
+  if (v == nv + 1) {
+    seg_start[v] = (int32_t)rows;
+    return;
+  }
+  int64_t lo = 0, hi = rows;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (sorted_keys[mid] < (int32_t)v) lo = mid + 1;
+    else hi = mid;
+  }
+  seg_start[v] = (int32_t)lo;
+}
+
+static int build_csr_sorted(tln_lattice* l, int64_t rows, hipStream_t s) {
+  const int end_bit = bits_for(l->nr_vertices + 1);
+  size_t bytes = l->sort_temp_bytes;
+  TLN_HIP(hipcub::DeviceRadixSort::SortPairs(l->sort_temp, bytes, l->sk_in, l->sk_out, l->sv_in, l->sv_out, (int)rows,
+                                             0, end_bit, s));
+  const int64_t nv = l->nr_vertices;
+  hipLaunchKernelGGL(k_seg_start, dim3((unsigned)tln_cdiv(nv + 2, 256)), dim3(256), 0, s, l->sk_out, rows, nv,
+                     l->seg_start);
+  TLN_LAUNCH_CHECK();
+  l->csr_rows = rows;
+  return TLN_OK;
+}
+
+__global__ void __launch_bounds__(256) k_csr_input(const int32_t* __restrict__ indices, int64_t rows, int32_t nv,
+                                                   int32_t* __restrict__ sk_in, int32_t* __restrict__ sv_in) {
+  const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= rows) return;
+  const int idx = indices[id];
+  sk_in[id] = (idx < 0 || idx >= nv) ? nv : idx;
+  sv_in[id] = (int32_t)id;
+}
+
+extern "C" int tln_build_csr(tln_lattice_t* l, const int32_t* d_indices, int64_t rows, void* stream_) {
+  TLN_REQUIRE(l && d_indices && rows > 0 && rows < (1ll << 31), "bad csr arguments");
+  hipStream_t s = (hipStream_t)stream_;
+  int rc = ensure_rows(l, rows);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_csr_input, dim3((unsigned)tln_cdiv(rows, 256)), dim3(256), 0, s, d_indices, rows,
+                     (int32_t)l->nr_vertices, l->sk_in, l->sv_in);
+  TLN_LAUNCH_CHECK();
+  return build_csr_sorted(l, rows, s);
+}
+
+// ---------------------------------------------------------------------------------------
+// K1 phase D: local mean per vertex (double accumulation, fixed tree) and subtraction
+// one wave per vertex; rows of the vertex come from the CSR
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_subtract_mean(const float* __restrict__ pos, const int32_t* __restrict__ order,
+                                                       const int32_t* __restrict__ seg_start, int64_t nv, int cols,
+                                                       float* __restrict__ dist) {
+  const int64_t v = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (v >= nv) return;
+  const int lane = threadIdx.x & 63;
+  const int b = seg_start[v], e = seg_start[v + 1];
+  if (b == e) return;
+  double sx = 0, sy = 0, sz = 0;
+  for (int j = b + lane; j < e; j += 64) {
+    const int64_t p = order[j] >> 2;
+    sx += (double)pos[3 * p];
+    sy += (double)pos[3 * p + 1];
+    sz += (double)pos[3 * p + 2];
+  }
+  sx = tln_wave_sum(sx);
+  sy = tln_wave_sum(sy);
+  sz = tln_wave_sum(sz);
+  const double cnt = (double)(e - b);
+  const float mx = (float)(sx / cnt), my = (float)(sy / cnt), mz = (float)(sz / cnt);
+  for (int j = b + lane; j < e; j += 64) {
+    const int64_t row = order[j];
+    const int64_t p = row >> 2;
+    float* d = dist + row * cols;
+    d[0] = pos[3 * p] - mx;
+    d[1] = pos[3 * p + 1] - my;
+    d[2] = pos[3 * p + 2] - mz;
+  }
+}
+
+extern "C" int tln_distribute(tln_lattice_t* l, const float* d_positions, const float* d_values, int64_t n,
+                              int val_dim, int subtract_mean, float* d_distributed, int32_t* d_indices,
+                              float* d_weights, void* stream_) {
+  TLN_REQUIRE(l && d_positions && d_distributed && d_indices && d_weights, "null argument");
+  TLN_REQUIRE(n > 0 && 4 * n < (1ll << 31), "nr of points %lld out of range", (long long)n);
+  TLN_REQUIRE(val_dim >= 0 && val_dim <= 16 && (val_dim == 0 || d_values), "bad val_dim %d", val_dim);
+  hipStream_t s = (hipStream_t)stream_;
+  const int64_t rows = 4 * n;
+  int rc = ensure_rows(l, rows);
+  if (rc) return rc;
+  TableRef t = table_ref(l);
+  TLN_HIP(hipMemsetAsync(l->d_ctr + CTR_OVERFLOW, 0, sizeof(int32_t), s));
+  hipLaunchKernelGGL(k_distribute_insert, dim3((unsigned)tln_cdiv(n, 256)), dim3(256), 0, s, d_positions, d_values, n,
+                     val_dim, l->scale[0], l->scale[1], l->scale[2], t, l->row_slot, d_weights, d_distributed);
+  TLN_LAUNCH_CHECK();
+  rc = number_new(l, rows, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_row_indices, dim3((unsigned)tln_cdiv(rows, 256)), dim3(256), 0, s, t, l->row_slot, rows,
+                     d_indices, l->d_ctr, l->sk_in, l->sv_in);
+  TLN_LAUNCH_CHECK();
+  rc = fetch_counters(l, s);
+  if (rc) return rc;
+  l->overflow_rows = l->h_ctr[CTR_OVERFLOW];
+  rc = build_csr_sorted(l, rows, s);
+  if (rc) return rc;
+  if (subtract_mean && l->nr_vertices > 0) {
+    const int64_t nv = l->nr_vertices;
+    hipLaunchKernelGGL(k_subtract_mean, dim3((unsigned)tln_cdiv(nv * 64, 256)), dim3(256), 0, s, d_positions,
+                       l->sv_out, l->seg_start, nv, 3 + val_dim + 1, d_distributed);
+    TLN_LAUNCH_CHECK();
+  }
+  return TLN_OK;
+}
+
+extern "C" int tln_lattice_insert_keys(tln_lattice_t* l, const int32_t* d_keys, int64_t n, int32_t* d_indices_out,
+                                       void* stream_) {
+  TLN_REQUIRE(l && d_keys && n > 0 && n < (1ll << 31), "bad insert_keys arguments");
+  hipStream_t s = (hipStream_t)stream_;
+  int rc = ensure_rows(l, n);
+  if (rc) return rc;
+  TableRef t = table_ref(l);
+  TLN_HIP(hipMemsetAsync(l->d_ctr + CTR_OVERFLOW, 0, sizeof(int32_t), s));
+  hipLaunchKernelGGL(k_insert_keys, dim3((unsigned)tln_cdiv(n, 256)), dim3(256), 0, s, d_keys, n, t, l->row_slot);
+  TLN_LAUNCH_CHECK();
+  rc = number_new(l, n, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_row_indices, dim3((unsigned)tln_cdiv(n, 256)), dim3(256), 0, s, t, l->row_slot, n,
+                     d_indices_out, l->d_ctr, (int32_t*)nullptr, (int32_t*)nullptr);
+  TLN_LAUNCH_CHECK();
+  l->csr_rows = -1;
+  return fetch_counters(l, s);
+}
+
+__global__ void __launch_bounds__(256) k_copy_keys(const int32_t* __restrict__ vkeys, int64_t nv,
+                                                   int32_t* __restrict__ out) {
+  const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= nv) return;
+  out[3 * v] = vkeys[4 * v];
+  out[3 * v + 1] = vkeys[4 * v + 1];
+  out[3 * v + 2] = vkeys[4 * v + 2];
+}
+
+extern "C" int tln_lattice_keys(const tln_lattice_t* l, int32_t* d_keys_out, int64_t max_rows, void* stream_) {
+  TLN_REQUIRE(l && d_keys_out, "null argument");
+  const int64_t nv = l->nr_vertices < max_rows ? l->nr_vertices : max_rows;
+  if (nv <= 0) return TLN_OK;
+  hipLaunchKernelGGL(k_copy_keys, dim3((unsigned)tln_cdiv(nv, 256)), dim3(256), 0, (hipStream_t)stream_, l->vkeys, nv,
+                     d_keys_out);
+  TLN_LAUNCH_CHECK();
+  return TLN_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// neighbour tables.  tap order (oracle/permuto.py S4): k=2a -> key+off_a, k=2a+1 -> key-off_a,
+// off_a = (1,1,1,1) with -3 at axis a; centre LAST (reference lattice_modules.py:320).
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void tap_key(int k0, int k1, int k2, int tap, int& n0, int& n1, int& n2) {
+  if (tap == 8) {
+    n0 = k0; n1 = k1; n2 = k2;
+    return;
+  }
+  const int a = tap >> 1;
+  const int sgn = (tap & 1) ? -1 : 1;
+  n0 = k0 + sgn * (a == 0 ? -3 : 1);
+  n1 = k1 + sgn * (a == 1 ? -3 : 1);
+  n2 = k2 + sgn * (a == 2 ? -3 : 1);
+}
+
+// mode 0: same level (query = own keys); mode 1: coarse->fine (query = 2*key into `t` = fine table);
+// mode 2: fine->coarse (query = finefy centre of the fine key into `t` = coarse table)
+__global__ void __launch_bounds__(256) k_neighbour_table(const int32_t* __restrict__ qkeys, int64_t nq, TableRef t,
+                                                         int mode, int32_t* __restrict__ table) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t v = gid / TLN_TAPS;
+  const int tap = (int)(gid - v * TLN_TAPS);
+  if (v >= nq) return;
+  int k0 = qkeys[4 * v], k1 = qkeys[4 * v + 1], k2 = qkeys[4 * v + 2];
+  if (mode == 1) {
+    k0 *= 2; k1 *= 2; k2 *= 2;
+  } else if (mode == 2) {
+    int rem0[4], rank[4], bn[4];
+    coarse_simplex(k0, k1, k2, rem0, rank, bn);
+    int best = 0;
+#pragma unroll
+    for (int r = 1; r < 4; ++r)
+      if (bn[r] > bn[best]) best = r;
+    vertex_key(rem0, rank, best, k0, k1, k2);
+  }
+  int n0, n1, n2;
+  tap_key(k0, k1, k2, tap, n0, n1, n2);
+  int res = -1;
+  if (mode == 0 && tap == 8) res = (int)v;
+  else if (tln_key_in_range(n0, n1, n2)) res = probe_find(t, tln_pack_key(n0, n1, n2));
+  table[gid] = res;
+}
+
+static int ensure_table(int32_t** p, int64_t capacity) {
+  if (*p) return TLN_OK;
+  TLN_HIP(hipMalloc(p, capacity * TLN_TAPS * sizeof(int32_t)));
+  return TLN_OK;
+}
+
+extern "C" int tln_neighbour_table(tln_lattice_t* l, const int32_t** d_table_out, void* stream_) {
+  TLN_REQUIRE(l && d_table_out, "null argument");
+  int rc = ensure_table(&l->nbr, l->capacity);
+  if (rc) return rc;
+  if (l->nbr_built_for != l->nr_vertices && l->nr_vertices > 0) {
+    const int64_t total = l->nr_vertices * TLN_TAPS;
+    hipLaunchKernelGGL(k_neighbour_table, dim3((unsigned)tln_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream_,
+                       l->vkeys, l->nr_vertices, table_ref(l), 0, l->nbr);
+    TLN_LAUNCH_CHECK();
+    l->nbr_built_for = l->nr_vertices;
+  }
+  *d_table_out = l->nbr;
+  return TLN_OK;
+}
+
+extern "C" int tln_coarsen(tln_lattice_t* fine, tln_lattice_t** coarse_out, void* stream_) {
+  TLN_REQUIRE(fine && coarse_out, "null argument");
+  hipStream_t s = (hipStream_t)stream_;
+  if (!fine->coarse) {
+    double sg[3] = {fine->sigmas[0] * 2, fine->sigmas[1] * 2, fine->sigmas[2] * 2};
+    tln_lattice* c = nullptr;
+    int rc = lattice_alloc(&c, fine->pos_dim, sg, fine->capacity, fine->level + 1);
+    if (rc) return rc;
+    c->parent = fine;
+    fine->coarse = c;
+    rc = tln_lattice_clear(c, s);
+    if (rc) return rc;
+  }
+  tln_lattice* c = fine->coarse;
+  const int64_t first = c->embedded_fine, count = fine->nr_vertices - first;
+  if (count > 0) {
+    const int64_t rows = 4 * count;
+    int rc = ensure_rows(c, rows);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_coarsen_insert, dim3((unsigned)tln_cdiv(count, 256)), dim3(256), 0, s, fine->vkeys, first,
+                       count, table_ref(c), c->row_slot);
+    TLN_LAUNCH_CHECK();
+    rc = number_new(c, rows, s);
+    if (rc) return rc;
+    rc = fetch_counters(c, s);
+    if (rc) return rc;
+    c->embedded_fine = fine->nr_vertices;
+    c->csr_rows = -1;
+  }
+  *coarse_out = c;
+  return TLN_OK;
+}
+
+extern "C" int tln_coarse_to_fine_table(tln_lattice_t* c, const int32_t** d_table_out, void* stream_) {
+  TLN_REQUIRE(c && c->parent && d_table_out, "not a coarse level");
+  tln_lattice* f = c->parent;
+  int rc = ensure_table(&c->c2f, c->capacity);
+  if (rc) return rc;
+  if ((c->c2f_vc != c->nr_vertices || c->c2f_vf != f->nr_vertices) && c->nr_vertices > 0) {
+    const int64_t total = c->nr_vertices * TLN_TAPS;
+    hipLaunchKernelGGL(k_neighbour_table, dim3((unsigned)tln_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream_,
+                       c->vkeys, c->nr_vertices, table_ref(f), 1, c->c2f);
+    TLN_LAUNCH_CHECK();
+    c->c2f_vc = c->nr_vertices;
+    c->c2f_vf = f->nr_vertices;
+  }
+  *d_table_out = c->c2f;
+  return TLN_OK;
+}
+
+extern "C" int tln_fine_to_coarse_table(tln_lattice_t* c, const int32_t** d_table_out, void* stream_) {
+  TLN_REQUIRE(c && c->parent && d_table_out, "not a coarse level");
+  tln_lattice* f = c->parent;
+  int rc = ensure_table(&c->f2c, f->capacity);
+  if (rc) return rc;
+  if ((c->f2c_vc != c->nr_vertices || c->f2c_vf != f->nr_vertices) && f->nr_vertices > 0) {
+    const int64_t total = f->nr_vertices * TLN_TAPS;
+    hipLaunchKernelGGL(k_neighbour_table, dim3((unsigned)tln_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream_,
+                       f->vkeys, f->nr_vertices, table_ref(c), 2, c->f2c);
+    TLN_LAUNCH_CHECK();
+    c->f2c_vc = c->nr_vertices;
+    c->f2c_vf = f->nr_vertices;
+  }
+  *d_table_out = c->f2c;
+  return TLN_OK;
+}

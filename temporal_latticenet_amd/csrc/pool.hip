@@ -1,0 +1,246 @@
+// K2 PointNet pool + K11 splat on the vertex-sorted row list (CSR) left by tln_distribute.
+//
+// Mirrors PointNetSeqModule.forward, reference seq_lattice/lattice_modules.py:448-530:
+//   per-row MLP (lm:460-473) -> scatter_max with argmax (lm:512) -> argmax clamp quirk (lm:513-514)
+//   -> points-per-vertex (lm:519-521) -> barycentric of the argmax row (lm:522-525) -> <4 mask (lm:527-530)
+// without materialising the [4N,64] activations: a wave takes 64 consecutive SORTED rows, every lane runs the
+// MLP of its row with wave-uniform weights, the 64x64 result is transposed through LDS and each lane then owns
+// one channel and walks the rows once, flushing (max, argmax-row) per vertex segment with one 64-bit atomicMax
+// per channel (512 contiguous bytes per wave-instruction).
+#include "common.h"
+
+struct tln_lattice;
+const int32_t* tln_lat_order(const tln_lattice* l);
+const int32_t* tln_lat_sorted_vertex(const tln_lattice* l);
+const int32_t* tln_lat_seg_start(const tln_lattice* l);
+int64_t tln_lat_csr_rows(const tln_lattice* l);
+int tln_lat_pool_ws(tln_lattice* l, int64_t elems, unsigned long long** out);
+
+struct MlpParams {
+  const float* w[3];
+  const float* b[3];
+};
+
+// one dense layer, weights broadcast from LDS (all lanes read the same address)
+template <int CIN, int COUT, bool RELU>
+__device__ __forceinline__ void dense(const float* __restrict__ w, const float* __restrict__ b, const float (&in)[CIN],
+                                      float (&out)[COUT]) {
+#pragma unroll
+  for (int o = 0; o < COUT; ++o) {
+    float acc = b[o];
+#pragma unroll
+    for (int i = 0; i < CIN; ++i) acc = fmaf(w[o * CIN + i], in[i], acc);
+    out[o] = RELU ? fmaxf(acc, 0.0f) : acc;
+  }
+}
+
+// CIN -> H1 -> (H2 ->) COUT ; H2 == 0 means a two-layer MLP; H1 == 0 means identity (COUT == CIN)
+template <int CIN, int H1, int H2, int COUT>
+__global__ void __launch_bounds__(256) k_pool_chunks(const float* __restrict__ dist, int cols,
+                                                     const int32_t* __restrict__ order,
+                                                     const int32_t* __restrict__ sorted_vertex, int64_t rows, int nv,
+                                                     MlpParams mp, unsigned long long* __restrict__ packed) {
+  constexpr int NW1 = H1 * CIN, NW2 = (H2 ? H2 : COUT) * H1, NW3 = H2 ? COUT * H2 : 0;
+  constexpr int NB1 = H1, NB2 = (H2 ? H2 : COUT), NB3 = H2 ? COUT : 0;
+  constexpr int TS = COUT + 1;  // padded tile stride
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* w1 = smem;
+  float* w2 = w1 + NW1;
+  float* w3 = w2 + NW2;
+  float* b1 = w3 + NW3;
+  float* b2 = b1 + NB1;
+  float* b3 = b2 + NB2;
+  float* tiles = b3 + NB3;
+  const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float* tile = tiles + wid * (64 * TS + 128);
+  int* tv = reinterpret_cast<int*>(tile + 64 * TS);
+  int* tr = tv + 64;
+
+  if (H1) {
+    for (int i = threadIdx.x; i < NW1; i += 256) w1[i] = mp.w[0][i];
+    for (int i = threadIdx.x; i < NW2; i += 256) w2[i] = mp.w[1][i];
+    for (int i = threadIdx.x; i < NW3; i += 256) w3[i] = mp.w[2][i];
+    for (int i = threadIdx.x; i < NB1; i += 256) b1[i] = mp.b[0][i];
+    for (int i = threadIdx.x; i < NB2; i += 256) b2[i] = mp.b[1][i];
+    for (int i = threadIdx.x; i < NB3; i += 256) b3[i] = mp.b[2][i];
+  }
+  __syncthreads();
+
+  const int64_t chunk = (int64_t)blockIdx.x * 4 + wid;
+  const int64_t j0 = chunk * 64;
+  if (j0 >= rows) return;  // no barrier below
+  const int cnt = (int)((rows - j0) < 64 ? (rows - j0) : 64);
+
+  if (lane < cnt) {
+    const int row = order[j0 + lane];
+    int v = sorted_vertex[j0 + lane];
+    if (v >= nv) v = 0;  // rows without a vertex fold into vertex 0 (lm:480)
+    float x[CIN];
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) x[c] = dist[(int64_t)row * cols + c];
+    float y[COUT];
+    if constexpr (H1 == 0) {
+#pragma unroll
+      for (int c = 0; c < COUT; ++c) y[c] = x[c];
+    } else if constexpr (H2 == 0) {
+      float h1[H1];
+      dense<CIN, H1, true>(w1, b1, x, h1);
+      dense<H1, COUT, false>(w2, b2, h1, y);
+    } else {
+      float h1[H1], h2[H2];
+      dense<CIN, H1, true>(w1, b1, x, h1);
+      dense<H1, H2, true>(w2, b2, h1, h2);
+      dense<H2, COUT, false>(w3, b3, h2, y);
+    }
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) tile[lane * TS + c] = y[c];
+    tv[lane] = v;
+    tr[lane] = row;
+  }
+  // wave-private tile: LDS writes above are visible to the wave's own later reads after the wait below
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  for (int c = lane; c < COUT; c += 64) {
+    int cur = tv[0];
+    float best = tile[c];
+    int brow = tr[0];
+    for (int j = 1; j < cnt; ++j) {
+      const int v = tv[j];
+      const float val = tile[j * TS + c];
+      if (v != cur) {
+        const unsigned long long p = ((unsigned long long)tln_f2ord(best) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)brow);
+        atomicMax(&packed[(int64_t)cur * COUT + c], p);
+        cur = v;
+        best = val;
+        brow = tr[j];
+      } else if (val > best) {  // rows ascend inside a segment: strict '>' keeps the smallest row on ties
+        best = val;
+        brow = tr[j];
+      }
+    }
+    const unsigned long long p = ((unsigned long long)tln_f2ord(best) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)brow);
+    atomicMax(&packed[(int64_t)cur * COUT + c], p);
+  }
+}
+
+__global__ void __launch_bounds__(256) k_pool_finalize(const unsigned long long* __restrict__ packed,
+                                                       const int32_t* __restrict__ seg_start, int nv, int cout,
+                                                       const float* __restrict__ dist, int cols, int64_t rows,
+                                                       int min_points, float* __restrict__ out) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t v = gid / cout;
+  const int c = (int)(gid - v * cout);
+  if (v >= nv) return;
+  int count = seg_start[v + 1] - seg_start[v];
+  if (v == 0) count += seg_start[nv + 1] - seg_start[nv];  // folded rows (index -1)
+  const unsigned long long p = packed[gid];
+  float val = 0.0f;          // torch_scatter: empty segment -> 0
+  int64_t arg = rows;        // torch_scatter: empty segment -> src.size(0)
+  if (p != 0ull) {
+    val = tln_ord2f((uint32_t)(p >> 32));
+    arg = (int64_t)(0xFFFFFFFFu - (uint32_t)(p & 0xFFFFFFFFull));
+  }
+  if (arg > (int64_t)nv) arg = 0;  // lm:514 compares row ids against the number of vertices
+  if (arg >= rows) arg = 0;        // (the reference would raise an index error here: rows <= V)
+  float bary = dist[arg * cols + (cols - 1)];
+  if (count < min_points) {
+    val = 0.0f;
+    bary = 0.0f;
+  }
+  out[v * (2 * cout) + c] = val;
+  out[v * (2 * cout) + cout + c] = bary;
+}
+
+template <int CIN, int H1, int H2, int COUT>
+static int launch_pool(tln_lattice* l, const float* d_dist, int64_t rows, int cols, const float* const* w,
+                       const float* const* b, int nv, unsigned long long* packed, hipStream_t s) {
+  constexpr int NW = H1 * CIN + (H2 ? H2 : COUT) * H1 + (H2 ? COUT * H2 : 0);
+  constexpr int NB = H1 + (H2 ? H2 : COUT) + (H2 ? COUT : 0);
+  const size_t lds = (size_t)((H1 ? NW + NB : 0) + 4 * (64 * (COUT + 1) + 128)) * sizeof(float);
+  MlpParams mp{};
+  for (int i = 0; i < 3; ++i) {
+    mp.w[i] = (H1 && w) ? w[i < (H2 ? 3 : 2) ? i : 0] : nullptr;
+    mp.b[i] = (H1 && b) ? b[i < (H2 ? 3 : 2) ? i : 0] : nullptr;
+  }
+  const int64_t chunks = tln_cdiv(rows, 64);
+  auto kern = k_pool_chunks<CIN, H1, H2, COUT>;
+  TLN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3((unsigned)tln_cdiv(chunks, 4)), dim3(256), lds, s, d_dist, cols, tln_lat_order(l),
+                     tln_lat_sorted_vertex(l), rows, nv, mp, packed);
+  TLN_LAUNCH_CHECK();
+  return TLN_OK;
+}
+
+extern "C" int tln_pointnet_pool(tln_lattice_t* l, const float* d_distributed, int64_t rows, int dist_cols,
+                                 int nr_layers, const float* const* d_w, const float* const* d_b, const int* dims,
+                                 int min_points, float* d_out, void* stream_) {
+  TLN_REQUIRE(l && d_distributed && d_out && dims, "null argument");
+  TLN_REQUIRE(tln_lat_csr_rows(l) == rows, "pool needs the CSR of a distribute/build_csr call over the same %lld rows",
+              (long long)rows);
+  hipStream_t s = (hipStream_t)stream_;
+  const int nv = (int)tln_lattice_nr_vertices(l);
+  if (nv <= 0) return TLN_OK;
+  const int cin = dims[0], cout = dims[nr_layers];
+  TLN_REQUIRE(cin <= dist_cols, "MLP input %d wider than the distributed rows %d", cin, dist_cols);
+  unsigned long long* packed = nullptr;
+  int rc = tln_lat_pool_ws(l, (int64_t)nv * cout, &packed);
+  if (rc) return rc;
+  TLN_HIP(hipMemsetAsync(packed, 0, (size_t)nv * cout * sizeof(unsigned long long), s));
+#define POOL_CASE(CI, A, B, CO) rc = launch_pool<CI, A, B, CO>(l, d_distributed, rows, dist_cols, d_w, d_b, nv, packed, s)
+  if (nr_layers == 3 && cin == 4 && dims[1] == 16 && dims[2] == 32 && dims[3] == 64) POOL_CASE(4, 16, 32, 64);
+  else if (nr_layers == 2 && cin == 4 && dims[1] == 16 && dims[2] == 32) POOL_CASE(4, 16, 0, 32);
+  else if (nr_layers == 3 && cin == 3 && dims[1] == 16 && dims[2] == 32 && dims[3] == 64) POOL_CASE(3, 16, 32, 64);
+  else if (nr_layers == 0 && cin == 4) POOL_CASE(4, 0, 0, 4);
+  else if (nr_layers == 0 && cin == 3) POOL_CASE(3, 0, 0, 3);
+  else {
+    tln_set_error("unsupported PointNet shape: %d layers, cin %d (supported: 4-16-32-64, 4-16-32, 3-16-32-64, identity)",
+                  nr_layers, cin);
+    return TLN_E_INVALID;
+  }
+#undef POOL_CASE
+  if (rc) return rc;
+  const int64_t total = (int64_t)nv * cout;
+  hipLaunchKernelGGL(k_pool_finalize, dim3((unsigned)tln_cdiv(total, 256)), dim3(256), 0, s, packed,
+                     tln_lat_seg_start(l), nv, cout, d_distributed, dist_cols, rows, min_points, d_out);
+  TLN_LAUNCH_CHECK();
+  return TLN_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// K11 plain splat: out[v] = sum_rows w * [values, 1]   (wave per vertex, rows in sorted order,
+// double accumulation with a fixed reduction tree => run-to-run reproducible)
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_splat(const float* __restrict__ values, int val_dim,
+                                               const float* __restrict__ weights, const int32_t* __restrict__ order,
+                                               const int32_t* __restrict__ seg_start, int64_t nv,
+                                               float* __restrict__ out) {
+  const int64_t v = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (v >= nv) return;
+  const int lane = threadIdx.x & 63;
+  const int b = seg_start[v], e = seg_start[v + 1];
+  for (int c = 0; c <= val_dim; ++c) {
+    double acc = 0.0;
+    for (int j = b + lane; j < e; j += 64) {
+      const int64_t row = order[j];
+      const float w = weights[row];
+      const float x = (c < val_dim) ? values[(row >> 2) * val_dim + c] : 1.0f;
+      acc += (double)(w * x);
+    }
+    acc = tln_wave_sum(acc);
+    if (lane == 0) out[v * (val_dim + 1) + c] = (float)acc;
+  }
+}
+
+extern "C" int tln_splat(tln_lattice_t* l, const float* d_values, int val_dim, const float* d_weights, int64_t rows,
+                         float* d_out, void* stream_) {
+  TLN_REQUIRE(l && d_weights && d_out && (val_dim == 0 || d_values), "null argument");
+  TLN_REQUIRE(tln_lat_csr_rows(l) == rows, "splat needs the CSR of the last distribute over %lld rows", (long long)rows);
+  const int64_t nv = tln_lattice_nr_vertices(l);
+  if (nv <= 0) return TLN_OK;
+  hipLaunchKernelGGL(k_splat, dim3((unsigned)tln_cdiv(nv * 64, 256)), dim3(256), 0, (hipStream_t)stream_, d_values,
+                     val_dim, d_weights, tln_lat_order(l), tln_lat_seg_start(l), nv, d_out);
+  TLN_LAUNCH_CHECK();
+  return TLN_OK;
+}

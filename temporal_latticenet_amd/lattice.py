@@ -1,0 +1,241 @@
+"""Host-side mirror of `latticenet.Lattice` / `latticenet.ModelParams` (un-vendored pybind module of the
+reference, README.md:47) over the C ABI of libtln_hip.so.
+
+Only the surface the reference touches is reproduced (call sites: train_ln.py:80,106,220,239;
+seq_lattice/lattice_modules.py:38,64,284-304; seq_lattice/models.py:29-37,63-64,298,460).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from . import cfg as _cfg
+
+__all__ = ["Lattice", "ModelParams", "HashTable", "stream_ptr"]
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class _DevView:
+    """zero-copy torch view of handle-owned device memory via __cuda_array_interface__"""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2}
+
+
+class HashTable:
+    """imported but unused by the reference (lattice_modules.py:7); kept so the import resolves"""
+
+
+class Lattice:
+    """One level of the permutohedral lattice.  Level 0 owns the native handle; coarser levels are children
+    of it and live as long as it does (append-only numbering at every level is what the temporal fusion
+    modules rely on, lattice_modules.py:59-60, 213-215)."""
+
+    def __init__(self, handle, sigmas, capacity, root=None, name="lattice"):
+        self._h = handle
+        self._root = root            # keeps level 0 (and thus the native memory) alive
+        self._owner = root is None
+        self._sigmas = list(sigmas)
+        self._capacity = int(capacity)
+        self._values = None
+        self._coarse = None
+        self._csr_key = None         # (indices tensor, _version) the native CSR was built from
+        self.name = name
+
+    # ---- construction -----------------------------------------------------------------
+    @staticmethod
+    def create(config_file, name="lattice"):
+        """Lattice.create(cfg, "lattice") of the reference (train_ln.py:106): reads `lattice_gpu`."""
+        lg = _cfg.load(config_file)["lattice_gpu"]
+        nr_sigmas = int(lg["nr_sigmas"])
+        sigmas = []
+        for i in range(nr_sigmas):
+            val, extent = str(lg["sigma_%d" % i]).split()
+            sigmas += [float(val)] * int(extent)
+        return Lattice.from_params(sigmas, int(lg["hash_table_capacity"]), name)
+
+    @staticmethod
+    def from_params(sigmas, capacity, name="lattice"):
+        if not torch.cuda.is_available():
+            raise _lib.TlnError("Lattice needs a HIP device (torch.cuda.is_available() is False)")
+        sigmas = [float(s) for s in sigmas]
+        if len(sigmas) != 3:
+            raise _lib.TlnError("only pos_dim == 3 is supported, got %d sigmas" % len(sigmas))
+        torch.cuda.current_stream()  # make sure the HIP context of the current device exists
+        h = C.c_void_p()
+        arr = (C.c_double * 3)(*sigmas)
+        _lib.check(_lib.lib().tln_lattice_create(C.byref(h), 3, arr, int(capacity)), "tln_lattice_create")
+        return Lattice(h, sigmas, capacity, None, name)
+
+    def __del__(self):
+        try:
+            if self._owner and self._h:
+                _lib.lib().tln_lattice_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # ---- the API the reference uses -----------------------------------------------------
+    def set_values(self, t):
+        self._values = t            # aliasing, not copying (lm:284 then lm:290)
+
+    def values(self):
+        return self._values
+
+    def val_dim(self):
+        return int(self._values.shape[1]) if self._values is not None else 0
+
+    def pos_dim(self):
+        return 3
+
+    def get_filter_extent(self, neighbourhood_size):
+        return 2 * (self.pos_dim() + 1) * int(neighbourhood_size) + 1
+
+    def nr_lattice_vertices(self):
+        return int(_lib.lib().tln_lattice_nr_vertices(self._h))
+
+    def capacity(self):
+        return self._capacity
+
+    def lvl(self):
+        return int(_lib.lib().tln_lattice_level(self._h))
+
+    def sigmas(self):
+        return list(self._sigmas)
+
+    def overflow_rows(self):
+        return int(_lib.lib().tln_lattice_overflow_rows(self._h))
+
+    def clear(self):
+        _lib.check(_lib.lib().tln_lattice_clear(self._h, stream_ptr()), "tln_lattice_clear")
+        self._csr_key = None
+        c = self._coarse
+        while c is not None:
+            c._csr_key = None
+            c._values = None
+            c = c._coarse
+
+    # ---- structure ------------------------------------------------------------------------
+    def keys(self):
+        v = self.nr_lattice_vertices()
+        out = torch.empty((v, 3), dtype=torch.int32, device="cuda")
+        if v:
+            _lib.check(_lib.lib().tln_lattice_keys(self._h, _ptr(out), v, stream_ptr()), "tln_lattice_keys")
+        return out
+
+    def insert_keys(self, keys):
+        keys = keys.contiguous()
+        out = torch.empty((keys.shape[0],), dtype=torch.int32, device="cuda")
+        _lib.check(_lib.lib().tln_lattice_insert_keys(self._h, _ptr(keys), keys.shape[0], _ptr(out), stream_ptr()),
+                   "tln_lattice_insert_keys")
+        self._csr_key = None
+        return out
+
+    def _table(self, fn, rows):
+        p = C.c_void_p()
+        _lib.check(fn(self._h, C.byref(p), stream_ptr()), "neighbour table")
+        return p, rows
+
+    def neighbour_table_ptr(self):
+        return self._table(_lib.lib().tln_neighbour_table, self.nr_lattice_vertices())[0]
+
+    def coarse_to_fine_table_ptr(self):
+        return self._table(_lib.lib().tln_coarse_to_fine_table, self.nr_lattice_vertices())[0]
+
+    def fine_to_coarse_table_ptr(self):
+        """valid on a COARSE level: [V_fine, 9] rows into this level"""
+        return self._table(_lib.lib().tln_fine_to_coarse_table, 0)[0]
+
+    @staticmethod
+    def _table_tensor(ptr, rows):
+        if rows == 0:
+            return torch.empty((0, 9), dtype=torch.int32, device="cuda")
+        return torch.as_tensor(_DevView(ptr.value, (rows, 9), "<i4"), device="cuda").clone()
+
+    def neighbour_table(self):
+        return self._table_tensor(self.neighbour_table_ptr(), self.nr_lattice_vertices())
+
+    def coarse_to_fine_table(self):
+        return self._table_tensor(self.coarse_to_fine_table_ptr(), self.nr_lattice_vertices())
+
+    def fine_to_coarse_table(self, nr_fine):
+        return self._table_tensor(self.fine_to_coarse_table_ptr(), nr_fine)
+
+    def coarsen(self):
+        """The persistent coarse level, extended by the vertices added since the last call."""
+        p = C.c_void_p()
+        _lib.check(_lib.lib().tln_coarsen(self._h, C.byref(p), stream_ptr()), "tln_coarsen")
+        if self._coarse is None:
+            self._coarse = Lattice(p, [2 * s for s in self._sigmas], self._capacity,
+                                   self._root if self._root is not None else self, self.name + "_c")
+        return self._coarse
+
+    # ---- K1 -----------------------------------------------------------------------------
+    def distribute(self, positions, values, reset_hashmap=True, subtract_mean=True):
+        positions = positions.contiguous().float()
+        n = positions.shape[0]
+        if positions.dim() != 2 or positions.shape[1] != 3:
+            raise _lib.TlnError("positions must be [N,3], got %s" % (tuple(positions.shape),))
+        if values is None or values.numel() == 0:
+            values, val_dim = None, 0
+        else:
+            values = values.contiguous().float()
+            if values.shape[0] != n:
+                raise _lib.TlnError("positions/values row mismatch")
+            val_dim = values.shape[1]
+        if reset_hashmap:
+            self.clear()
+        cols = 3 + val_dim + 1
+        distributed = torch.empty((4 * n, cols), dtype=torch.float32, device="cuda")
+        indices = torch.empty((4 * n,), dtype=torch.int32, device="cuda")
+        weights = torch.empty((4 * n,), dtype=torch.float32, device="cuda")
+        _lib.check(_lib.lib().tln_distribute(self._h, _ptr(positions), _ptr(values), n, val_dim,
+                                             1 if subtract_mean else 0, _ptr(distributed), _ptr(indices),
+                                             _ptr(weights), stream_ptr()), "tln_distribute")
+        self._csr_key = (indices, indices._version)
+        return distributed, indices, weights
+
+    def ensure_csr(self, indices):
+        k = self._csr_key
+        if k is not None and k[0] is indices and k[1] == indices._version:
+            return
+        idx = indices.contiguous().to(torch.int32)
+        _lib.check(_lib.lib().tln_build_csr(self._h, _ptr(idx), idx.shape[0], stream_ptr()), "tln_build_csr")
+        self._csr_key = (indices, indices._version)
+
+
+class ModelParams:
+    """latticenet.ModelParams (reference getters used at models.py:29-37, 63-64, 488-524): the `model`
+    section of the cfg."""
+
+    def __init__(self, d):
+        self._d = dict(d)
+
+    @staticmethod
+    def create(config_file):
+        return ModelParams(_cfg.load(config_file)["model"])
+
+    def _get(self, k, default=None):
+        return self._d.get(k, default)
+
+    def positions_mode(self): return self._get("positions_mode", "xyz")
+    def values_mode(self): return self._get("values_mode", "none")
+    def pointnet_layers(self): return list(self._get("pointnet_layers", [16, 32, 64]))
+    def pointnet_start_nr_channels(self): return int(self._get("pointnet_start_nr_channels", 64))
+    def nr_downsamples(self): return int(self._get("nr_downsamples", 2))
+    def nr_blocks_down_stage(self): return list(self._get("nr_blocks_down_stage", [2, 2, 2]))
+    def nr_blocks_bottleneck(self): return int(self._get("nr_blocks_bottleneck", 3))
+    def nr_blocks_up_stage(self): return list(self._get("nr_blocks_up_stage", [1, 2, 2]))
+    def nr_levels_down_with_normal_resnet(self): return int(self._get("nr_levels_down_with_normal_resnet", 3))
+    def nr_levels_up_with_normal_resnet(self): return int(self._get("nr_levels_up_with_normal_resnet", 3))
+    def compression_factor(self): return float(self._get("compression_factor", 1.0))
+    def dropout_last_layer(self): return float(self._get("dropout_last_layer", 0.0))
+    def experiment(self): return self._get("experiment", "none")

@@ -1,0 +1,191 @@
+"""Functional wrappers over the C ABI (include/tln.h).  PyTorch supplies device memory and the stream;
+every op here launches hand-written gfx950 kernels and raises if the library is unavailable."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .lattice import Lattice, stream_ptr, _ptr
+
+__all__ = ["gemm_src", "gather_gemm", "groupnorm_stats", "affine_act", "pointnet_pool", "gru_cell", "aflow",
+           "slice_gather", "slice_blend", "splat", "im2row", "scatter_max", "scatter_add"]
+
+_keep = []  # not needed: ctypes structs only live for the duration of the call
+
+
+def _f32c(t):
+    if t is None:
+        return None
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        t = t.float().contiguous()
+    if not t.is_cuda:
+        raise _lib.TlnError("tensor must live on the HIP device")
+    return t
+
+
+def gemm_src(src, table_ptr=None, taps=1, src_rows=None, pad_value=0.0, scale=None, shift=None, relu=False):
+    """Describes one A-operand source of gather_gemm; returns (struct, keepalive)."""
+    src = _f32c(src)
+    s = _lib.GemmSrc()
+    s.d_src = src.data_ptr()
+    s.src_rows = src.shape[0] if src_rows is None else int(src_rows)
+    s.ld = src.stride(0)
+    s.cin = src.shape[1]
+    s.taps = taps
+    s.d_table = table_ptr.value if table_ptr is not None else None
+    s.pad_value = float(pad_value)
+    scale, shift = _f32c(scale), _f32c(shift)
+    s.d_scale = scale.data_ptr() if scale is not None else None
+    s.d_shift = shift.data_ptr() if shift is not None else None
+    s.relu = 1 if relu else 0
+    return s, (src, scale, shift)
+
+
+def gather_gemm(M, weight, s0, s1=None, w_is_nk=False, bias=None, residual=None, relu=False, out=None):
+    """out[M,N] = epi( [gather(s0) | gather(s1)] @ W ).  weight: [K,N] (w_is_nk False) or [N,K]."""
+    weight = _f32c(weight)
+    N = weight.shape[0] if w_is_nk else weight.shape[1]
+    K = weight.shape[1] if w_is_nk else weight.shape[0]
+    k_expected = s0[0].taps * s0[0].cin + (s1[0].taps * s1[0].cin if s1 is not None else 0)
+    if K != k_expected:
+        raise _lib.TlnError("gather_gemm: weight K=%d but sources give K=%d" % (K, k_expected))
+    bias, residual = _f32c(bias), _f32c(residual)
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device="cuda")
+    if residual is not None and tuple(residual.shape) != (M, N):
+        raise _lib.TlnError("gather_gemm: residual shape %s != (%d,%d)" % (tuple(residual.shape), M, N))
+    if bias is not None and bias.numel() != N:
+        raise _lib.TlnError("gather_gemm: bias has %d entries, N=%d" % (bias.numel(), N))
+    rc = _lib.lib().tln_gather_gemm(M, N, C.byref(s0[0]), C.byref(s1[0]) if s1 is not None else None, _ptr(weight),
+                                    1 if w_is_nk else 0, _ptr(bias), _ptr(residual),
+                                    residual.stride(0) if residual is not None else 0, 1 if relu else 0, _ptr(out),
+                                    out.stride(0), stream_ptr())
+    _lib.check(rc, "tln_gather_gemm")
+    return out
+
+
+def groupnorm_stats(x, groups, gamma, beta, eps=1e-5):
+    """per-channel (scale, shift) such that x*scale+shift == GroupNorm_over_all_vertices(x)*gamma+beta"""
+    x = _f32c(x)
+    V, Cn = x.shape
+    scale = torch.empty((Cn,), dtype=torch.float32, device="cuda")
+    shift = torch.empty((Cn,), dtype=torch.float32, device="cuda")
+    ws_bytes = int(_lib.lib().tln_groupnorm_ws_bytes(V, Cn))
+    ws = torch.empty((max(ws_bytes, 16) // 8,), dtype=torch.float64, device="cuda")
+    gamma, beta = _f32c(gamma), _f32c(beta)
+    _lib.check(_lib.lib().tln_groupnorm_stats(_ptr(x), V, Cn, groups, _ptr(gamma), _ptr(beta), float(eps),
+                                              _ptr(scale), _ptr(shift), _ptr(ws), ws_bytes, stream_ptr()),
+               "tln_groupnorm_stats")
+    return scale, shift
+
+
+def affine_act(x, scale, shift, relu=False):
+    x = _f32c(x)
+    out = torch.empty_like(x)
+    _lib.check(_lib.lib().tln_affine_act(_ptr(x), x.shape[0], x.shape[1], _ptr(_f32c(scale)), _ptr(_f32c(shift)),
+                                         1 if relu else 0, _ptr(out), stream_ptr()), "tln_affine_act")
+    return out
+
+
+def pointnet_pool(lattice: Lattice, distributed, indices, weights, biases, min_points=4):
+    """Fused per-row MLP + segment max (+argmax barycentric) of PointNetSeqModule (lm:448-530)."""
+    distributed = _f32c(distributed)
+    lattice.ensure_csr(indices)
+    rows, cols = distributed.shape
+    nl = len(weights)
+    ws = [_f32c(w) for w in weights]
+    bs = [_f32c(b) for b in biases]
+    dims = [ws[0].shape[1]] + [w.shape[0] for w in ws] if nl else [cols - 1]
+    V = lattice.nr_lattice_vertices()
+    out = torch.empty((V, 2 * dims[-1]), dtype=torch.float32, device="cuda")
+    warr = (C.c_void_p * max(nl, 1))(*[w.data_ptr() for w in ws])
+    barr = (C.c_void_p * max(nl, 1))(*[b.data_ptr() for b in bs])
+    darr = (C.c_int * (nl + 1))(*dims)
+    _lib.check(_lib.lib().tln_pointnet_pool(lattice._h, _ptr(distributed), rows, cols, nl, warr, barr, darr,
+                                            int(min_points), _ptr(out), stream_ptr()), "tln_pointnet_pool")
+    return out
+
+
+def gru_cell(x, h, w_ih, w_hh, b_ih, b_hh):
+    """GRUCell(x, pad(h)) with h zero-padded to x.shape[0] rows (lm:59-62)."""
+    x, h = _f32c(x), _f32c(h)
+    V, Cn = x.shape
+    out = torch.empty_like(x)
+    ws = torch.empty((V * 6 * Cn,), dtype=torch.float32, device="cuda")
+    _lib.check(_lib.lib().tln_gru_cell(_ptr(x), _ptr(h), V, h.shape[0], Cn, _ptr(_f32c(w_ih)), _ptr(_f32c(w_hh)),
+                                       _ptr(_f32c(b_ih)), _ptr(_f32c(b_hh)), _ptr(out), _ptr(ws), ws.numel(),
+                                       stream_ptr()), "tln_gru_cell")
+    return out
+
+
+def aflow(x, h, table_ptr, alpha, beta, bias=None, pad_value=-999999.0, use_center=True):
+    x, h = _f32c(x), _f32c(h)
+    V, Cn = x.shape
+    out = torch.empty_like(x)
+    w = torch.empty((V, 9), dtype=torch.float32, device="cuda")
+    idx = torch.empty((V, 9), dtype=torch.int32, device="cuda")
+    _lib.check(_lib.lib().tln_aflow(_ptr(x), _ptr(h), V, h.shape[0], Cn, table_ptr, float(alpha), float(beta),
+                                    float(pad_value), 1 if use_center else 0, _ptr(_f32c(bias)), _ptr(out), _ptr(w),
+                                    _ptr(idx), stream_ptr()), "tln_aflow")
+    return out, w, idx
+
+
+def slice_gather(lv, indices, weights):
+    lv = _f32c(lv)
+    n = indices.shape[0] // 4
+    cb = lv.shape[1]
+    out = torch.empty((n, 4 * (cb + 1)), dtype=torch.float32, device="cuda")
+    _lib.check(_lib.lib().tln_slice_gather(_ptr(lv), lv.shape[0], cb, _ptr(indices.contiguous()),
+                                           _ptr(_f32c(weights)), n, _ptr(out), stream_ptr()), "tln_slice_gather")
+    return out
+
+
+def slice_blend(lv, indices, weights, delta=None):
+    lv = _f32c(lv)
+    n = indices.shape[0] // 4
+    out = torch.empty((n, lv.shape[1]), dtype=torch.float32, device="cuda")
+    _lib.check(_lib.lib().tln_slice(_ptr(lv), lv.shape[0], lv.shape[1], _ptr(indices.contiguous()),
+                                    _ptr(_f32c(weights)), _ptr(_f32c(delta)), n, _ptr(out), stream_ptr()), "tln_slice")
+    return out
+
+
+def splat(lattice: Lattice, values, indices, weights):
+    lattice.ensure_csr(indices)
+    values = _f32c(values)
+    val_dim = values.shape[1] if values is not None else 0
+    V = lattice.nr_lattice_vertices()
+    out = torch.empty((V, val_dim + 1), dtype=torch.float32, device="cuda")
+    _lib.check(_lib.lib().tln_splat(lattice._h, _ptr(values), val_dim, _ptr(_f32c(weights)), indices.shape[0],
+                                    _ptr(out), stream_ptr()), "tln_splat")
+    return out
+
+
+def im2row(src, table_ptr, M):
+    src = _f32c(src)
+    out = torch.empty((M, 9 * src.shape[1]), dtype=torch.float32, device="cuda")
+    _lib.check(_lib.lib().tln_im2row(_ptr(src), src.shape[0], src.shape[1], table_ptr, M, _ptr(out), stream_ptr()),
+               "tln_im2row")
+    return out
+
+
+def scatter_max(src, index, out_rows):
+    src = _f32c(src)
+    index = index.contiguous().long()
+    rows, Cn = src.shape
+    out = torch.empty((out_rows, Cn), dtype=torch.float32, device="cuda")
+    arg = torch.empty((out_rows, Cn), dtype=torch.int64, device="cuda")
+    ws = torch.empty((max(out_rows * Cn, 1),), dtype=torch.int64, device="cuda")
+    _lib.check(_lib.lib().tln_scatter_max(_ptr(src), _ptr(index), rows, Cn, out_rows, _ptr(out), _ptr(arg), _ptr(ws),
+                                          ws.numel() * 8, stream_ptr()), "tln_scatter_max")
+    return out, arg
+
+
+def scatter_add(src, index, out_rows, out=None):
+    src = _f32c(src)
+    index = index.contiguous().long()
+    rows, Cn = src.shape
+    if out is None:
+        out = torch.zeros((out_rows, Cn), dtype=torch.float32, device="cuda")
+    _lib.check(_lib.lib().tln_scatter_add(_ptr(src), _ptr(index), rows, Cn, out_rows, _ptr(out), stream_ptr()),
+               "tln_scatter_add")
+    return out

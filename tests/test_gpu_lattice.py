@@ -1,0 +1,112 @@
+"""GPU parity: lattice structure (K1 distribute, hash numbering, neighbour / cross-level tables) vs oracle.
+Integer outputs are compared bit-exactly."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ops as O
+from oracle import permuto as P
+from temporal_latticenet_amd.synthetic import make_sequence
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_sequence(gpu, seq, sigma, capacity, subtract_mean=True):
+    from temporal_latticenet_amd.lattice import Lattice
+    lat = Lattice.from_params([sigma] * 3, capacity)
+    tab = P.VertexTable(3, capacity)
+    outs = []
+    for t, (pos, val) in enumerate(seq):
+        d, i, w = lat.distribute(torch.from_numpy(pos).to(gpu), torch.from_numpy(val).to(gpu),
+                                 reset_hashmap=(t == 0), subtract_mean=subtract_mean)
+        od, oi, ow = O.distribute(tab, pos, val, [sigma] * 3, subtract_mean)
+        outs.append((d.cpu().numpy(), i.cpu().numpy(), w.cpu().numpy(), od, oi, ow))
+        assert lat.nr_lattice_vertices() == tab.nr_vertices
+    return lat, tab, outs
+
+
+@pytest.mark.parametrize("n,sigma", [(20000, 1.0), (120000, 0.6), (5000, 0.2)])
+def test_distribute_matches_oracle(gpu, n, sigma):
+    seq = make_sequence(n, 3, seed=7)
+    lat, tab, outs = _run_sequence(gpu, seq, sigma, 1 << 18)
+    for d, i, w, od, oi, ow in outs:
+        assert np.array_equal(i, oi), "vertex indices must be bit-exact"
+        assert np.array_equal(w, ow), "barycentric weights must be bit-exact (same fp32 sequence)"
+        np.testing.assert_allclose(d, od, rtol=0, atol=2e-5)
+    assert np.array_equal(lat.keys().cpu().numpy(), tab.keys)
+    assert lat.overflow_rows() == 0
+
+
+def test_prefix_stability_and_reset(gpu):
+    seq = make_sequence(8000, 2, seed=3)
+    lat, tab, outs = _run_sequence(gpu, seq, 0.6, 1 << 16)
+    keys_after = lat.keys().cpu().numpy()
+    # a fresh run over frame 0 alone gives a prefix of the two-frame numbering
+    lat1, tab1, _ = _run_sequence(gpu, seq[:1], 0.6, 1 << 16)
+    k1 = lat1.keys().cpu().numpy()
+    assert np.array_equal(keys_after[: k1.shape[0]], k1)
+    # reset_hashmap really resets
+    pos, val = seq[1]
+    d, i, w = lat.distribute(torch.from_numpy(pos).to(gpu), torch.from_numpy(val).to(gpu), reset_hashmap=True)
+    t2 = P.VertexTable(3, 1 << 16)
+    _, oi, _ = O.distribute(t2, pos, val, [0.6] * 3)
+    assert np.array_equal(i.cpu().numpy(), oi)
+
+
+def test_capacity_overflow_is_reported(gpu):
+    pos, val = make_sequence(6000, 1, seed=5)[0]
+    from temporal_latticenet_amd.lattice import Lattice
+    cap = 64
+    lat = Lattice.from_params([0.3] * 3, cap)
+    d, i, w = lat.distribute(torch.from_numpy(pos).to(gpu), torch.from_numpy(val).to(gpu))
+    tab = P.VertexTable(3, cap)
+    _, oi, _ = O.distribute(tab, pos, val, [0.3] * 3)
+    i = i.cpu().numpy()
+    assert lat.nr_lattice_vertices() == cap
+    assert np.array_equal(i, oi)          # first-touch numbering decides which keys fit
+    assert lat.overflow_rows() == int((oi < 0).sum()) > 0
+
+
+def test_neighbour_and_cross_level_tables(gpu):
+    seq = make_sequence(30000, 2, seed=11)
+    lat, tab, _ = _run_sequence(gpu, seq[:1], 0.6, 1 << 16)
+    # level 0 neighbours
+    assert np.array_equal(lat.neighbour_table().cpu().numpy(), P.neighbour_table(tab))
+    # coarse levels, built incrementally over two frames
+    c1 = P.VertexTable(3, 1 << 16)
+    c2 = P.VertexTable(3, 1 << 16)
+    P.coarsen_insert(c1, tab.keys)
+    P.coarsen_insert(c2, c1.keys)
+    g1 = lat.coarsen()
+    g2 = g1.coarsen()
+    assert np.array_equal(g1.keys().cpu().numpy(), c1.keys)
+    assert np.array_equal(g2.keys().cpu().numpy(), c2.keys)
+    v0, v1 = tab.nr_vertices, c1.nr_vertices
+    pos, val = seq[1]
+    lat.distribute(torch.from_numpy(pos).to(gpu), torch.from_numpy(val).to(gpu), reset_hashmap=False)
+    O.distribute(tab, pos, val, [0.6] * 3)
+    P.coarsen_insert(c1, tab.keys[v0:])
+    P.coarsen_insert(c2, c1.keys[v1:])
+    g1 = lat.coarsen()
+    g2 = g1.coarsen()
+    assert np.array_equal(g1.keys().cpu().numpy(), c1.keys)
+    assert np.array_equal(g2.keys().cpu().numpy(), c2.keys)
+    assert np.array_equal(g1.neighbour_table().cpu().numpy(), P.neighbour_table(c1))
+    # coarse -> fine taps: fine keys 2*c +- off
+    want = tab.lookup(P.neighbour_keys(c1.keys * 2))
+    assert np.array_equal(g1.coarse_to_fine_table().cpu().numpy(), want)
+    # fine -> coarse taps around the nearest coarse vertex
+    want = c1.lookup(P.neighbour_keys(P.finefy_centres(tab.keys)))
+    assert np.array_equal(g1.fine_to_coarse_table(tab.nr_vertices).cpu().numpy(), want)
+
+
+def test_insert_keys_matches_distribute_numbering(gpu):
+    pos, val = make_sequence(10000, 1, seed=13)[0]
+    from temporal_latticenet_amd.lattice import Lattice
+    lat = Lattice.from_params([0.6] * 3, 1 << 16)
+    lat.distribute(torch.from_numpy(pos).to(gpu), torch.from_numpy(val).to(gpu))
+    keys = lat.keys()
+    lat2 = Lattice.from_params([0.6] * 3, 1 << 16)
+    idx = lat2.insert_keys(keys)
+    assert np.array_equal(idx.cpu().numpy(), np.arange(keys.shape[0], dtype=np.int32))
+    assert np.array_equal(lat2.keys().cpu().numpy(), keys.cpu().numpy())

@@ -1,0 +1,194 @@
+"""GPU parity of the per-op kernels against the CPU oracle (fp32 tolerances stated per test)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ops as O
+from oracle import permuto as P
+from temporal_latticenet_amd.synthetic import make_sequence
+
+pytestmark = pytest.mark.gpu
+
+
+def _lattice(gpu, n=20000, sigma=0.6, seed=21, frames=1):
+    from temporal_latticenet_amd.lattice import Lattice
+    seq = make_sequence(n, frames, seed=seed)
+    lat = Lattice.from_params([sigma] * 3, 1 << 17)
+    tab = P.VertexTable(3, 1 << 17)
+    res = None
+    for t, (pos, val) in enumerate(seq):
+        res = lat.distribute(torch.from_numpy(pos).to(gpu), torch.from_numpy(val).to(gpu), reset_hashmap=(t == 0))
+        ores = O.distribute(tab, pos, val, [sigma] * 3)
+    return lat, tab, res, ores
+
+
+@pytest.mark.parametrize("layers", [[16, 32, 64], [16, 32], []])
+def test_pointnet_pool(gpu, layers):
+    from temporal_latticenet_amd import ops
+    lat, tab, (d, i, w), (od, oi, ow) = _lattice(gpu, 30000, 0.6, frames=2)
+    g = torch.Generator().manual_seed(0)
+    dims = [4] + layers
+    Ws = [torch.randn(dims[k + 1], dims[k], generator=g) * 0.5 for k in range(len(layers))]
+    Bs = [torch.randn(dims[k + 1], generator=g) * 0.1 for k in range(len(layers))]
+    out = ops.pointnet_pool(lat, d, i, [x.to(gpu) for x in Ws], [x.to(gpu) for x in Bs], 4)
+    want = O.pointnet_pool(od, oi, tab.nr_vertices, Ws, Bs, 4)
+    assert out.shape == want.shape
+    np.testing.assert_allclose(out.cpu().numpy(), want.numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_pool_folds_invalid_rows_into_vertex0(gpu):
+    from temporal_latticenet_amd import ops
+    from temporal_latticenet_amd.lattice import Lattice
+    pos, val = make_sequence(6000, 1, seed=5)[0]
+    lat = Lattice.from_params([0.3] * 3, 200)
+    d, i, w = lat.distribute(torch.from_numpy(pos).to(gpu), torch.from_numpy(val).to(gpu))
+    tab = P.VertexTable(3, 200)
+    od, oi, ow = O.distribute(tab, pos, val, [0.3] * 3)
+    assert (oi < 0).sum() > 0
+    g = torch.Generator().manual_seed(1)
+    Ws = [torch.randn(16, 4, generator=g), torch.randn(32, 16, generator=g), torch.randn(64, 32, generator=g)]
+    Bs = [torch.randn(16, generator=g), torch.randn(32, generator=g), torch.randn(64, generator=g)]
+    out = ops.pointnet_pool(lat, d, i, [x.to(gpu) for x in Ws], [x.to(gpu) for x in Bs], 4)
+    want = O.pointnet_pool(od, oi, tab.nr_vertices, Ws, Bs, 4)
+    np.testing.assert_allclose(out.cpu().numpy(), want.numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("cin,cout", [(64, 64), (128, 64), (192, 192), (16, 16), (256, 128), (36, 36), (6, 10)])
+def test_lattice_conv(gpu, cin, cout):
+    from temporal_latticenet_amd import ops
+    lat, tab, _, _ = _lattice(gpu, 20000, 0.5)
+    V = lat.nr_lattice_vertices()
+    g = torch.Generator().manual_seed(cin * 1000 + cout)
+    lv = torch.randn(V, cin, generator=g)
+    W = torch.randn(9 * cin, cout, generator=g) / np.sqrt(9 * cin)
+    b = torch.randn(cout, generator=g)
+    tblp = lat.neighbour_table_ptr()
+    s0 = ops.gemm_src(lv.to(gpu), tblp, 9)
+    out = ops.gather_gemm(V, W.to(gpu), s0, bias=b.to(gpu))
+    want = O.conv(lv, P.neighbour_table(tab), W, b)
+    np.testing.assert_allclose(out.cpu().numpy(), want.numpy(), rtol=1e-4, atol=2e-5)
+    # materialised im2row agrees too
+    rows = ops.im2row(lv.to(gpu), tblp, V)
+    assert torch.equal(rows.cpu(), O.im2row(lv, P.neighbour_table(tab)))
+
+
+@pytest.mark.parametrize("tm,tn", [(1, 1), (2, 1), (1, 2), (2, 2)])
+def test_gemm_all_tiles_with_prologue_epilogue(gpu, tm, tn):
+    from temporal_latticenet_amd import _lib, ops
+    lat, tab, _, _ = _lattice(gpu, 20000, 0.5)
+    V = lat.nr_lattice_vertices()
+    g = torch.Generator().manual_seed(5)
+    cin, cout = 64, 192
+    lv = torch.randn(V, cin, generator=g)
+    gamma, beta = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g)
+    W = torch.randn(9 * cin, cout, generator=g) / np.sqrt(9 * cin)
+    res = torch.randn(V, cout, generator=g)
+    scale, shift = ops.groupnorm_stats(lv.to(gpu), 32, gamma.to(gpu), beta.to(gpu))
+    _lib.lib().tln_gemm_force_tiles(tm, tn)
+    try:
+        s0 = ops.gemm_src(lv.to(gpu), lat.neighbour_table_ptr(), 9, scale=scale, shift=shift, relu=True)
+        out = ops.gather_gemm(V, W.to(gpu), s0, residual=res.to(gpu), relu=False)
+    finally:
+        _lib.lib().tln_gemm_force_tiles(0, 0)
+    act = torch.relu(O.group_norm(lv, gamma, beta))
+    want = O.conv(act, P.neighbour_table(tab), W) + res
+    np.testing.assert_allclose(out.cpu().numpy(), want.numpy(), rtol=1e-4, atol=5e-5)
+
+
+@pytest.mark.parametrize("V,cin,cout", [(1000, 64, 64), (37, 256, 64), (5000, 192, 26), (3, 8, 4), (777, 36, 4)])
+def test_linear_nk_layout_and_two_sources(gpu, V, cin, cout):
+    from temporal_latticenet_amd import ops
+    g = torch.Generator().manual_seed(V + cin)
+    a, b2 = torch.randn(V, cin, generator=g), torch.randn(V, cin, generator=g)
+    W = torch.randn(cout, 2 * cin, generator=g) / np.sqrt(2 * cin)
+    bias = torch.randn(cout, generator=g)
+    out = ops.gather_gemm(V, W.to(gpu), ops.gemm_src(a.to(gpu)), ops.gemm_src(b2.to(gpu)), w_is_nk=True,
+                          bias=bias.to(gpu), relu=True)
+    want = torch.relu(F.linear(torch.cat([a, b2], 1), W, bias))
+    np.testing.assert_allclose(out.cpu().numpy(), want.numpy(), rtol=1e-4, atol=2e-5)
+    # padded second source (rows beyond src_rows read as pad_value)
+    vh = max(1, V // 2)
+    out = ops.gather_gemm(V, W.to(gpu), ops.gemm_src(a.to(gpu)), ops.gemm_src(b2[:vh].to(gpu), src_rows=vh, pad_value=0.5),
+                          w_is_nk=True)
+    b_pad = torch.cat([b2[:vh], torch.full((V - vh, cin), 0.5)], 0)
+    want = F.linear(torch.cat([a, b_pad], 1), W)
+    np.testing.assert_allclose(out.cpu().numpy(), want.numpy(), rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("V,C", [(5000, 64), (1234, 192), (70, 256), (3000, 6)])
+def test_groupnorm_stats(gpu, V, C):
+    from temporal_latticenet_amd import ops
+    g = torch.Generator().manual_seed(C)
+    x = torch.randn(V, C, generator=g) * 3 + 1.5
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    groups = O.gn_groups(C)
+    scale, shift = ops.groupnorm_stats(x.to(gpu), groups, gamma.to(gpu), beta.to(gpu))
+    got = ops.affine_act(x.to(gpu), scale, shift, relu=True)
+    want = torch.relu(O.group_norm(x, gamma, beta))
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("C", [64, 128, 192])
+def test_gru_cell(gpu, C):
+    from temporal_latticenet_amd import ops
+    g = torch.Generator().manual_seed(C)
+    V, Vh = 3000, 2500
+    cell = torch.nn.GRUCell(C, C)
+    x, h = torch.randn(V, C, generator=g), torch.randn(Vh, C, generator=g)
+    out = ops.gru_cell(x.to(gpu), h.to(gpu), cell.weight_ih.detach().to(gpu), cell.weight_hh.detach().to(gpu),
+                       cell.bias_ih.detach().to(gpu), cell.bias_hh.detach().to(gpu))
+    with torch.no_grad():
+        want = cell(x, torch.cat([h, torch.zeros(V - Vh, C)], 0))
+    np.testing.assert_allclose(out.cpu().numpy(), want.numpy(), rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("C", [64, 256])
+def test_aflow_correlation(gpu, C):
+    from temporal_latticenet_amd import ops
+    lat, tab, _, _ = _lattice(gpu, 20000, 0.8, frames=2)
+    V = lat.nr_lattice_vertices()
+    Vh = V - 57
+    g = torch.Generator().manual_seed(C)
+    x, h = torch.randn(V, C, generator=g), torch.randn(Vh, C, generator=g)
+    bias = torch.randn(C, generator=g) * 0.1
+    out, w, idx = ops.aflow(x.to(gpu), h.to(gpu), lat.neighbour_table_ptr(), 0.1, 0.1, bias.to(gpu))
+    table = P.neighbour_table(tab)
+    hp = F.pad(h, (0, 0, 0, V - Vh), value=-999999)
+    want, ww, _ = O.aflow_correlation(x, hp, table, torch.tensor(0.1), torch.tensor(0.1), bias)
+    assert np.array_equal(idx.cpu().numpy(), table)
+    np.testing.assert_allclose(w.cpu().numpy(), ww.numpy(), rtol=1e-4, atol=1e-6)
+    # rows that touch a padded (-999999) neighbour carry huge magnitudes: compare relatively
+    np.testing.assert_allclose(out.cpu().numpy(), want.numpy(), rtol=2e-4, atol=1e-4)
+
+
+def test_slice_kernels(gpu):
+    from temporal_latticenet_amd import ops
+    lat, tab, (d, i, w), (od, oi, ow) = _lattice(gpu, 20000, 0.6)
+    V = lat.nr_lattice_vertices()
+    g = torch.Generator().manual_seed(9)
+    lvb, lv = torch.randn(V, 8, generator=g), torch.randn(V, 26, generator=g)
+    delta = torch.randn(oi.shape[0], generator=g) * 0.1
+    got = ops.slice_gather(lvb.to(gpu), i, w)
+    np.testing.assert_allclose(got.cpu().numpy(), O.slice_gather(lvb, oi, ow).numpy(), rtol=1e-6, atol=1e-6)
+    got = ops.slice_blend(lv.to(gpu), i, w, delta.to(gpu))
+    np.testing.assert_allclose(got.cpu().numpy(), O.slice_blend(lv, oi, ow, delta).numpy(), rtol=1e-5, atol=1e-5)
+    # splat of [values,1] followed by a normalised slice reproduces a constant field
+    ones = torch.full((oi.shape[0] // 4, 1), 3.25)
+    sp = ops.splat(lat, ones.to(gpu), i, w)
+    np.testing.assert_allclose(sp.cpu().numpy(), O.splat(ones, oi, ow, V).numpy(), rtol=1e-5, atol=1e-4)
+    sl = ops.slice_blend(sp, i, w)
+    val = (sl[:, 0] / sl[:, 1]).cpu().numpy()
+    np.testing.assert_allclose(val, 3.25, rtol=1e-5)
+
+
+def test_torch_scatter_equivalents(gpu):
+    from temporal_latticenet_amd import ops
+    g = torch.Generator().manual_seed(3)
+    src = torch.randn(5000, 7, generator=g).round(decimals=1)   # ties on purpose
+    index = torch.randint(0, 300, (5000,), generator=g)
+    out, arg = ops.scatter_max(src.to(gpu), index.to(gpu), 320)
+    wo, wa = O.scatter_max(src, index, 320)
+    assert torch.equal(out.cpu(), wo) and torch.equal(arg.cpu(), wa)
+    add = ops.scatter_add(src.to(gpu), index.to(gpu), 320)
+    np.testing.assert_allclose(add.cpu().numpy(), O.scatter_add(src, index, 320).numpy(), rtol=1e-5, atol=1e-5)
