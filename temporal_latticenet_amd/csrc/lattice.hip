@@ -28,7 +28,7 @@ extern "C" int tln_version(void) { return 1; }
 // ---------------------------------------------------------------------------------------
 // handle
 // ---------------------------------------------------------------------------------------
-enum { CTR_NV = 0, CTR_NEW = 1, CTR_OVERFLOW = 2, CTR_PROBE_FAIL = 3, CTR_VOLD = 4, CTR_COUNT = 8 };
+enum { CTR_NV = 0, CTR_NEW = 1, CTR_OVERFLOW = 2, CTR_PROBE_FAIL = 3, CTR_VOLD = 4, CTR_OCCUPIED = 5, CTR_COUNT = 8 };
 #define TLN_MAX_PROBES 8192
 #define TLN_SCAN_BLOCK 1024
 
@@ -44,6 +44,7 @@ struct tln_lattice {
   int32_t* d_ctr = nullptr;
   int32_t* h_ctr = nullptr;
   int64_t nr_vertices = 0, overflow_rows = 0;
+  int64_t occupied = 0;  // claimed slots (numbered vertices + keys rejected by the capacity)
   // tables (owned)
   int32_t* nbr = nullptr;
   int64_t nbr_built_for = -1;
@@ -123,8 +124,9 @@ static int lattice_alloc(tln_lattice** out, int pos_dim, const double* sigmas, i
   l->pos_dim = pos_dim;
   l->level = level;
   l->capacity = capacity;
-  int64_t ns = 1;
-  while (ns < 2 * capacity) ns <<= 1;
+  // level 0 starts with room for one 120k-point frame (4 rows per point) at load factor 1/2; every level
+  // grows on demand (ensure_slots), so the slot count never limits which keys are accepted
+  const int64_t ns = level == 0 ? (1 << 20) : (1 << 16);
   l->nslots = ns;
   for (int i = 0; i < 3; ++i) {
     l->sigmas[i] = sigmas[i];
@@ -150,6 +152,7 @@ extern "C" int tln_lattice_clear(tln_lattice_t* l, void* stream_) {
     TLN_HIP(hipMemsetAsync(p->d_ctr, 0, CTR_COUNT * sizeof(int32_t), s));
     p->nr_vertices = 0;
     p->overflow_rows = 0;
+    p->occupied = 0;
     p->nbr_built_for = -1;
     p->c2f_vc = p->c2f_vf = p->f2c_vc = p->f2c_vf = -1;
     p->embedded_fine = 0;
@@ -193,10 +196,11 @@ struct TableRef {
   uint64_t* slot_key;
   int32_t* slot_val;
   uint32_t* slot_touch;
+  int32_t* ctr;
   uint64_t mask;
 };
 static TableRef table_ref(const tln_lattice* l) {
-  return TableRef{l->slot_key, l->slot_val, l->slot_touch, (uint64_t)(l->nslots - 1)};
+  return TableRef{l->slot_key, l->slot_val, l->slot_touch, l->d_ctr, (uint64_t)(l->nslots - 1)};
 }
 
 // find-or-claim the slot of key K; records the smallest row id touching a not-yet-numbered slot
@@ -206,7 +210,10 @@ __device__ __forceinline__ int probe_insert(const TableRef& t, uint64_t K, uint3
     uint64_t cur = t.slot_key[slot];
     if (cur == TLN_KEY_EMPTY) {
       cur = atomicCAS((unsigned long long*)&t.slot_key[slot], (unsigned long long)TLN_KEY_EMPTY, (unsigned long long)K);
-      if (cur == TLN_KEY_EMPTY) cur = K;
+      if (cur == TLN_KEY_EMPTY) {
+        cur = K;
+        atomicAdd(&t.ctr[CTR_OCCUPIED], 1);
+      }
     }
     if (cur == K) {
       if (t.slot_val[slot] < 0) {
@@ -216,6 +223,7 @@ __device__ __forceinline__ int probe_insert(const TableRef& t, uint64_t K, uint3
     }
     slot = (slot + 1) & t.mask;
   }
+  atomicAdd(&t.ctr[CTR_PROBE_FAIL], 1);
   return -1;
 }
 
@@ -345,6 +353,62 @@ __device__ __forceinline__ void coarse_simplex(int f0, int f1, int f2, int rem0[
     rem0[i] = r[i] / 2;
     bn[i] = b[i];
   }
+}
+
+// ---------------------------------------------------------------------------------------
+// slot table growth: probing must never fail, so that ONLY the first-touch numbering decides which
+// keys fit into `capacity` (deterministic overflow, identical to the sequential oracle)
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_rehash(const int32_t* __restrict__ vkeys, int64_t nv, TableRef t) {
+  const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= nv) return;
+  const uint64_t K = tln_pack_key(vkeys[4 * v], vkeys[4 * v + 1], vkeys[4 * v + 2]);
+  uint64_t slot = tln_mix64(K) & t.mask;
+  for (int probe = 0; probe < TLN_MAX_PROBES; ++probe) {
+    const uint64_t old = atomicCAS((unsigned long long*)&t.slot_key[slot], (unsigned long long)TLN_KEY_EMPTY,
+                                   (unsigned long long)K);
+    if (old == TLN_KEY_EMPTY) {
+      t.slot_val[slot] = (int32_t)v;
+      return;
+    }
+    slot = (slot + 1) & t.mask;
+  }
+  atomicAdd(&t.ctr[CTR_PROBE_FAIL], 1);
+}
+
+static int ensure_slots(tln_lattice* l, int64_t rows, hipStream_t s) {
+  if (2 * (l->occupied + rows) <= l->nslots) return TLN_OK;
+  int64_t ns = l->nslots;
+  while (ns < 2 * (l->nr_vertices + rows)) ns <<= 1;
+  TLN_HIP(hipStreamSynchronize(s));
+  uint64_t* nk = nullptr;
+  int32_t* nv = nullptr;
+  uint32_t* nt = nullptr;
+  TLN_HIP(hipMalloc(&nk, ns * sizeof(uint64_t)));
+  TLN_HIP(hipMalloc(&nv, ns * sizeof(int32_t)));
+  TLN_HIP(hipMalloc(&nt, ns * sizeof(uint32_t)));
+  TLN_HIP(hipMemsetAsync(nk, 0xFF, ns * sizeof(uint64_t), s));
+  TLN_HIP(hipMemsetAsync(nv, 0xFF, ns * sizeof(int32_t), s));
+  TLN_HIP(hipMemsetAsync(nt, 0xFF, ns * sizeof(uint32_t), s));
+  (void)hipFree(l->slot_key);
+  (void)hipFree(l->slot_val);
+  (void)hipFree(l->slot_touch);
+  l->slot_key = nk;
+  l->slot_val = nv;
+  l->slot_touch = nt;
+  l->nslots = ns;
+  if (l->nr_vertices > 0) {
+    hipLaunchKernelGGL(k_rehash, dim3((unsigned)tln_cdiv(l->nr_vertices, 256)), dim3(256), 0, s, l->vkeys,
+                       l->nr_vertices, table_ref(l));
+    TLN_LAUNCH_CHECK();
+  }
+  // keys that were rejected by the capacity are dropped here; they are retried by later insertions
+  const int32_t occ = (int32_t)l->nr_vertices;
+  TLN_HIP(hipMemcpyAsync(l->d_ctr + CTR_OCCUPIED, &occ, sizeof(int32_t), hipMemcpyHostToDevice, s));
+  TLN_HIP(hipStreamSynchronize(s));
+  l->occupied = l->nr_vertices;
+  l->nbr_built_for = -1;
+  return TLN_OK;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -535,6 +599,11 @@ static int fetch_counters(tln_lattice* l, hipStream_t s) {
   TLN_HIP(hipMemcpyAsync(l->h_ctr, l->d_ctr, CTR_COUNT * sizeof(int32_t), hipMemcpyDeviceToHost, s));
   TLN_HIP(hipStreamSynchronize(s));
   l->nr_vertices = l->h_ctr[CTR_NV];
+  l->occupied = l->h_ctr[CTR_OCCUPIED];
+  if (l->h_ctr[CTR_PROBE_FAIL] != 0) {
+    tln_set_error("hash probing failed for %d rows (table too full)", l->h_ctr[CTR_PROBE_FAIL]);
+    return TLN_E_CAPACITY;
+  }
   return TLN_OK;
 }
 
@@ -635,6 +704,8 @@ extern "C" int tln_distribute(tln_lattice_t* l, const float* d_positions, const 
   const int64_t rows = 4 * n;
   int rc = ensure_rows(l, rows);
   if (rc) return rc;
+  rc = ensure_slots(l, rows, s);
+  if (rc) return rc;
   TableRef t = table_ref(l);
   TLN_HIP(hipMemsetAsync(l->d_ctr + CTR_OVERFLOW, 0, sizeof(int32_t), s));
   hipLaunchKernelGGL(k_distribute_insert, dim3((unsigned)tln_cdiv(n, 256)), dim3(256), 0, s, d_positions, d_values, n,
@@ -664,6 +735,8 @@ extern "C" int tln_lattice_insert_keys(tln_lattice_t* l, const int32_t* d_keys, 
   TLN_REQUIRE(l && d_keys && n > 0 && n < (1ll << 31), "bad insert_keys arguments");
   hipStream_t s = (hipStream_t)stream_;
   int rc = ensure_rows(l, n);
+  if (rc) return rc;
+  rc = ensure_slots(l, n, s);
   if (rc) return rc;
   TableRef t = table_ref(l);
   TLN_HIP(hipMemsetAsync(l->d_ctr + CTR_OVERFLOW, 0, sizeof(int32_t), s));
@@ -780,6 +853,8 @@ extern "C" int tln_coarsen(tln_lattice_t* fine, tln_lattice_t** coarse_out, void
   if (count > 0) {
     const int64_t rows = 4 * count;
     int rc = ensure_rows(c, rows);
+    if (rc) return rc;
+    rc = ensure_slots(c, rows, s);
     if (rc) return rc;
     hipLaunchKernelGGL(k_coarsen_insert, dim3((unsigned)tln_cdiv(count, 256)), dim3(256), 0, s, fine->vkeys, first,
                        count, table_ref(c), c->row_slot);
