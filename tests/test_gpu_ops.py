@@ -162,6 +162,21 @@ def test_aflow_correlation(gpu, C):
     np.testing.assert_allclose(out.cpu().numpy(), want.numpy(), rtol=2e-4, atol=1e-4)
 
 
+def test_aflow_zero_rowsum_gives_nan_like_the_reference(gpu):
+    """lm:321 divides by the row sum without a guard: identical rows => 0/0 => NaN, which must be reproduced"""
+    from temporal_latticenet_amd import ops
+    lat, tab, _, _ = _lattice(gpu, 5000, 1.0)
+    V = lat.nr_lattice_vertices()
+    x = torch.zeros(V, 64)
+    x[V // 2:] = torch.randn(V - V // 2, 64, generator=torch.Generator().manual_seed(0))
+    out, w, idx = ops.aflow(x.to(gpu), x.to(gpu), lat.neighbour_table_ptr(), 0.1, 0.1, None)
+    want, ww, _ = O.aflow_correlation(x, x, P.neighbour_table(tab), torch.tensor(0.1), torch.tensor(0.1), None)
+    assert torch.isnan(ww).any()
+    assert torch.equal(torch.isnan(w.cpu()), torch.isnan(ww))
+    np.testing.assert_allclose(w.cpu().numpy(), ww.numpy(), rtol=1e-4, atol=1e-6, equal_nan=True)
+    np.testing.assert_allclose(out.cpu().numpy(), want.numpy(), rtol=2e-4, atol=1e-4, equal_nan=True)
+
+
 def test_slice_kernels(gpu):
     from temporal_latticenet_amd import ops
     lat, tab, (d, i, w), (od, oi, ow) = _lattice(gpu, 20000, 0.6)
