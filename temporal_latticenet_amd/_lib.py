@@ -71,6 +71,9 @@ def lib():
             raise TlnError(
                 "libtln_hip.so is missing (%s). Build it with `python -m temporal_latticenet_amd.build`; "
                 "there is no CPU fallback." % LIB_PATH)
+        # torch ships its own libamdhip64; it must be in the process BEFORE our library is mapped so that both
+        # share one HIP runtime (loading ours first binds it to /opt/rocm's copy, which then sees no device)
+        import torch  # noqa: F401
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in _PROTOS.items():
             fn = getattr(l, name)          # AttributeError if the symbol is not exported

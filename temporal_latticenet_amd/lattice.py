@@ -197,9 +197,12 @@ class Lattice:
         distributed = torch.empty((4 * n, cols), dtype=torch.float32, device="cuda")
         indices = torch.empty((4 * n,), dtype=torch.int32, device="cuda")
         weights = torch.empty((4 * n,), dtype=torch.float32, device="cuda")
-        _lib.check(_lib.lib().tln_distribute(self._h, _ptr(positions), _ptr(values), n, val_dim,
-                                             1 if subtract_mean else 0, _ptr(distributed), _ptr(indices),
-                                             _ptr(weights), stream_ptr()), "tln_distribute")
+        from . import ops as _ops
+        with _ops._timed("distribute", n=n):
+            rc = _lib.lib().tln_distribute(self._h, _ptr(positions), _ptr(values), n, val_dim,
+                                           1 if subtract_mean else 0, _ptr(distributed), _ptr(indices),
+                                           _ptr(weights), stream_ptr())
+        _lib.check(rc, "tln_distribute")
         self._csr_key = (indices, indices._version)
         return distributed, indices, weights
 

@@ -10,7 +10,39 @@ from .lattice import Lattice, stream_ptr, _ptr
 __all__ = ["gemm_src", "gather_gemm", "groupnorm_stats", "affine_act", "pointnet_pool", "gru_cell", "aflow",
            "slice_gather", "slice_blend", "splat", "im2row", "scatter_max", "scatter_add"]
 
-_keep = []  # not needed: ctypes structs only live for the duration of the call
+# ---- optional per-call timing (bench.py roofline pass): HIP events on the launch stream ----------------
+_prof = None
+
+
+def profile_begin():
+    global _prof
+    _prof = []
+
+
+def profile_end():
+    """returns [(name, ms, meta)] for every recorded call; synchronises the device"""
+    global _prof
+    rec, _prof = _prof, None
+    torch.cuda.synchronize()
+    return [(n, e0.elapsed_time(e1), meta) for n, e0, e1, meta in (rec or [])]
+
+
+class _timed:
+    def __init__(self, name, **meta):
+        self.name, self.meta = name, meta
+
+    def __enter__(self):
+        if _prof is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *a):
+        if _prof is not None:
+            self.e1.record()
+            _prof.append((self.name, self.e0, self.e1, self.meta))
+        return False
 
 
 def _f32c(t):
@@ -56,10 +88,11 @@ def gather_gemm(M, weight, s0, s1=None, w_is_nk=False, bias=None, residual=None,
         raise _lib.TlnError("gather_gemm: residual shape %s != (%d,%d)" % (tuple(residual.shape), M, N))
     if bias is not None and bias.numel() != N:
         raise _lib.TlnError("gather_gemm: bias has %d entries, N=%d" % (bias.numel(), N))
-    rc = _lib.lib().tln_gather_gemm(M, N, C.byref(s0[0]), C.byref(s1[0]) if s1 is not None else None, _ptr(weight),
-                                    1 if w_is_nk else 0, _ptr(bias), _ptr(residual),
-                                    residual.stride(0) if residual is not None else 0, 1 if relu else 0, _ptr(out),
-                                    out.stride(0), stream_ptr())
+    with _timed("gather_gemm", M=M, N=N, K=K, taps=s0[0].taps, cin=s0[0].cin, res=residual is not None):
+        rc = _lib.lib().tln_gather_gemm(M, N, C.byref(s0[0]), C.byref(s1[0]) if s1 is not None else None,
+                                        _ptr(weight), 1 if w_is_nk else 0, _ptr(bias), _ptr(residual),
+                                        residual.stride(0) if residual is not None else 0, 1 if relu else 0,
+                                        _ptr(out), out.stride(0), stream_ptr())
     _lib.check(rc, "tln_gather_gemm")
     return out
 
@@ -101,8 +134,10 @@ def pointnet_pool(lattice: Lattice, distributed, indices, weights, biases, min_p
     warr = (C.c_void_p * max(nl, 1))(*[w.data_ptr() for w in ws])
     barr = (C.c_void_p * max(nl, 1))(*[b.data_ptr() for b in bs])
     darr = (C.c_int * (nl + 1))(*dims)
-    _lib.check(_lib.lib().tln_pointnet_pool(lattice._h, _ptr(distributed), rows, cols, nl, warr, barr, darr,
-                                            int(min_points), _ptr(out), stream_ptr()), "tln_pointnet_pool")
+    with _timed("pointnet_pool", rows=rows, V=V, cout=dims[-1]):
+        rc = _lib.lib().tln_pointnet_pool(lattice._h, _ptr(distributed), rows, cols, nl, warr, barr, darr,
+                                          int(min_points), _ptr(out), stream_ptr())
+    _lib.check(rc, "tln_pointnet_pool")
     return out
 
 
