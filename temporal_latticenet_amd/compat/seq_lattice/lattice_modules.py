@@ -1,0 +1,2 @@
+from temporal_latticenet_amd.lattice_modules import *  # noqa: F401,F403
+from temporal_latticenet_amd.seq_modules import *  # noqa: F401,F403

@@ -1,0 +1,142 @@
+"""CPU: host-side logic (cfg reader, ModelParams, model wiring) and the C-ABI library surface."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CFG_TEXT = '''
+core: {
+    loguru_verbosity: 3
+    hidpi: false  // a comment
+}
+train: { dataset_name: "semantickitti", lr:0.001
+    weight_decay: 1e-3 }
+model: {
+    positions_mode: "xyz"
+    pointnet_layers: [16,32,64]
+    nr_blocks_up_stage: [1,2,2]
+    compression_factor: 1.0
+    //pointnet_layers: [16,32]
+    sequence_learning: true
+    rnn_modules: ["gru", "gru", "aflow", "gru"] // possibilities are lstm,aflow,...
+    experiment: "none"
+}
+lattice_gpu: {
+    hash_table_capacity: 100000 //good for semantic kitti
+    nr_sigmas: 1
+    sigma_0: "0.6 3" //sigma of X affecting Y dimensions
+}
+loader_semantic_kitti: { frames_per_seq: 4, accumulate_clouds: false
+    label_mngr: { unlabeled_idx: 0 }
+    transformer: { hsv_jitter: [0,0,0] } }
+'''
+
+
+def test_cfg_reader_handles_the_reference_dialect():
+    from temporal_latticenet_amd.cfg import cfgParser, loads
+    c = loads(CFG_TEXT)
+    assert c["core"] == {"loguru_verbosity": 3, "hidpi": False}
+    assert c["train"]["lr"] == 0.001 and c["train"]["weight_decay"] == 1e-3
+    assert c["model"]["pointnet_layers"] == [16, 32, 64]
+    assert c["model"]["rnn_modules"] == ["gru", "gru", "aflow", "gru"]
+    assert c["lattice_gpu"]["sigma_0"] == "0.6 3" and c["lattice_gpu"]["hash_table_capacity"] == 100000
+    p = cfgParser(contents=c)
+    assert p.get_loader_vars()["frames_per_seq"] == 4
+    assert p.get_label_mngr_vars()["unlabeled_idx"] == 0
+    assert p.get_transformer_vars()["hsv_jitter"] == [0, 0, 0]
+    assert p.get_model_vars()["sequence_learning"] is True
+
+
+def test_model_params_getters():
+    from temporal_latticenet_amd.cfg import loads
+    from temporal_latticenet_amd.lattice import ModelParams
+    mp = ModelParams(loads(CFG_TEXT)["model"])
+    assert mp.pointnet_layers() == [16, 32, 64] and mp.nr_blocks_up_stage() == [1, 2, 2]
+    assert mp.compression_factor() == 1.0 and mp.experiment() == "none" and mp.nr_downsamples() == 2
+    assert mp.positions_mode() == "xyz"
+
+
+def test_model_wiring_matches_the_reference_channel_trace(capsys):
+    """models.py:129-153 fusion widths and the module lists, without touching a GPU (parameters are lazy)"""
+    from temporal_latticenet_amd.configs import make_config
+    from temporal_latticenet_amd.cfg import cfgParser
+    from temporal_latticenet_amd.lattice import ModelParams
+    from temporal_latticenet_amd.models import LNN_SEQ
+    from temporal_latticenet_amd import seq_modules as S
+    c = make_config()
+    m = LNN_SEQ(26, ModelParams(c["model"]), cfgParser(contents=c))
+    assert isinstance(m.point_net_seq.fusion_module, S.GRUModule)
+    assert m.point_net_seq.fusion_module.GRU.weight_ih.shape == (3 * 128, 128)
+    assert isinstance(m.recurrent_fusion_modules[0], S.GRUModule) and m.recurrent_fusion_modules[0].GRU.hidden_size == 64
+    assert isinstance(m.recurrent_fusion_modules[1], S.CrossframeLocalInterpolationModule)
+    assert m.recurrent_fusion_modules[1].linear.weight.shape == (256, 512)
+    assert m.recurrent_fusion_modules[2].GRU.hidden_size == 192
+    assert len(m.resnet_blocks_per_down_lvl_list) == 2 and len(m.resnet_blocks_bottleneck) == 3
+    assert [len(x) for x in m.resnet_blocks_per_up_lvl_list] == [1, 2]
+    assert m.first_sequence is True
+    m.first_sequence = False
+    m.reset_sequence()
+    assert m.first_sequence is True
+    # invalid fusion names fall back to "none"; all-none is rejected (models.py:51-56)
+    c2 = make_config(rnn_modules=("foo", "gru", "NONE", "Aflow"))
+    m2 = LNN_SEQ(20, ModelParams(c2["model"]), cfgParser(contents=c2))
+    assert m2.rnn_modules == ["none", "gru", "none", "aflow"]
+    with pytest.raises(AssertionError):
+        c3 = make_config(rnn_modules=("x", "y", "z", "w"))
+        LNN_SEQ(20, ModelParams(c3["model"]), cfgParser(contents=c3))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "tln.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(tln_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_c_abi_library_exports_every_declared_symbol():
+    from temporal_latticenet_amd import _lib
+    from temporal_latticenet_amd import build
+    if not os.path.exists(_lib.LIB_PATH):
+        build.build(verbose=False)
+    declared = _declared_symbols()
+    assert len(declared) >= 25
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [s for s in declared if not hasattr(lib, s)]
+    assert not missing, "declared in include/tln.h but not exported: %s" % missing
+    # the ctypes prototypes cover exactly the declared surface
+    assert sorted(_lib.exported_symbols()) == declared
+    assert _lib.lib().tln_version() >= 1            # no device needed
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from temporal_latticenet_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.TlnError, match="no CPU fallback"):
+        _lib.lib()
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "temporal_latticenet_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+
+
+def test_synthetic_scan_contract():
+    """the loader contract the generator mimics (kitti:100-201): [N,3] f32, [N,1] f32, frames in frame-0 coords"""
+    import numpy as np
+    from temporal_latticenet_amd.synthetic import make_sequence
+    seq = make_sequence(3000, 3, seed=9)
+    assert len(seq) == 3
+    for pos, val in seq:
+        assert pos.shape == (3000, 3) and pos.dtype == np.float32 and val.shape == (3000, 1)
+        r = np.linalg.norm(pos, axis=1)
+        assert val.min() >= 0 and val.max() < 1
+        assert pos[:, 1].min() > -3.0 and pos[:, 1].max() < 6.0      # +y is up, ground ~ -1.73
+    again = make_sequence(3000, 3, seed=9)
+    assert all(np.array_equal(a[0], b[0]) for a, b in zip(seq, again)), "seeded"
