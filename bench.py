@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--rnn", type=str, default="gru,gru,aflow,gru")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-points", type=int, default=120000, help="points per frame of the CPU sample")
-    ap.add_argument("--cpu-frames", type=int, default=2)
+    ap.add_argument("--cpu-frames", type=int, default=1)
     ap.add_argument("--breakdown", action="store_true", help="print a per-op time table to stderr")
     return ap.parse_args()
 
@@ -189,7 +189,7 @@ def cpu_baseline(model, contents, args):
     from temporal_latticenet_amd.synthetic import make_sequence
     from oracle.model import OracleLNN
     m = contents["model"]
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 32)     # eager ops on a few-thousand-row lattice do not scale past this
     torch.set_num_threads(cores)
     oracle = OracleLNN(model.state_dict(), 26, m["rnn_modules"], m["sequence_learning"], m["pointnet_layers"],
                        m["nr_downsamples"], m["nr_blocks_down_stage"], m["nr_blocks_bottleneck"],

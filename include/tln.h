@@ -97,8 +97,19 @@ int tln_gather_gemm(int64_t M, int N, const tln_gemm_src* s0, const tln_gemm_src
                     const float* d_w, int w_is_nk, const float* d_bias, const float* d_residual,
                     int64_t ld_res, int relu, float* d_out, int64_t ld_out, void* stream);
 
+/* same, plus the GroupNorm statistics of the output for the NEXT layer: d_stats (optional) receives
+ * [ceil(M/32)][N] pairs of doubles (sum, sum of squares) over each 32-row block of the final values, i.e. the
+ * input format of tln_groupnorm_from_partials */
+int tln_gather_gemm_ex(int64_t M, int N, const tln_gemm_src* s0, const tln_gemm_src* s1,
+                       const float* d_w, int w_is_nk, const float* d_bias, const float* d_residual,
+                       int64_t ld_res, int relu, float* d_out, int64_t ld_out, void* d_stats, void* stream);
+
 /* tuning hook: force the block tile (TM,TN in {1,2}; 0 = heuristic) */
 void tln_gemm_force_tiles(int tm, int tn);
+/* tuning hook: force the number of K-groups per block (1, 2, 4; 0 = heuristic) for 64x64 tiles */
+void tln_gemm_force_groups(int groups);
+/* tuning hook: force the split-K slices over the grid and the tile height (wm: 1 = 32 rows, 2 = 64 rows) */
+void tln_gemm_force_splits(int splits, int wm);
 
 /* materialised im2row (API parity with Im2RowLattice / Im2RowIndicesLattice, lm:301-304) */
 int tln_im2row(const float* d_src, int64_t src_rows, int cin, const int32_t* d_table, int64_t M,
@@ -110,6 +121,10 @@ int64_t tln_groupnorm_ws_bytes(int64_t V, int C);
 int tln_groupnorm_stats(const float* d_x, int64_t V, int C, int groups, const float* d_gamma,
                         const float* d_beta, float eps, float* d_scale, float* d_shift, void* d_ws,
                         int64_t ws_bytes, void* stream);
+/* second half of tln_groupnorm_stats on partial sums that already exist (written by tln_gather_gemm_ex):
+ * d_partials = [ceil(V/32)][C] (sum, sumsq) doubles */
+int tln_groupnorm_from_partials(const void* d_partials, int64_t V, int C, int groups, const float* d_gamma,
+                                const float* d_beta, float eps, float* d_scale, float* d_shift, void* stream);
 int tln_affine_act(const float* d_x, int64_t V, int C, const float* d_scale, const float* d_shift,
                    int relu, float* d_out, void* stream);
 

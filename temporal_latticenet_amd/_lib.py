@@ -43,6 +43,10 @@ _PROTOS = {
     "tln_fine_to_coarse_table": (_i, [_vp, C.POINTER(_vp), _vp]),
     "tln_gather_gemm": (_i, [_i64, _i, C.POINTER(GemmSrc), C.POINTER(GemmSrc), _vp, _i, _vp, _vp, _i64, _i, _vp, _i64, _vp]),
     "tln_gemm_force_tiles": (None, [_i, _i]),
+    "tln_gemm_force_groups": (None, [_i]),
+    "tln_gemm_force_splits": (None, [_i, _i]),
+    "tln_gather_gemm_ex": (_i, [_i64, _i, C.POINTER(GemmSrc), C.POINTER(GemmSrc), _vp, _i, _vp, _vp, _i64, _i, _vp, _i64, _vp, _vp]),
+    "tln_groupnorm_from_partials": (_i, [_vp, _i64, _i, _i, _vp, _vp, _f, _vp, _vp, _vp]),
     "tln_im2row": (_i, [_vp, _i64, _i, _vp, _i64, _vp, _vp]),
     "tln_groupnorm_ws_bytes": (_i64, [_i64, _i]),
     "tln_groupnorm_stats": (_i, [_vp, _i64, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _i64, _vp]),

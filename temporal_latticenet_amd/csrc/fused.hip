@@ -8,40 +8,38 @@
 // Two deterministic passes: per-row-block (sum, sumsq) in double, then a fixed-order combine.
 // The result is per-CHANNEL scale/shift consumed by the gather-GEMM prologue.
 // =======================================================================================
-#define GN_ROWS_PER_BLOCK 128
-#define GN_MAX_CT 8  // C <= 512
+#define GN_ROWS_PER_BLOCK 32
+#define GN_MAX_C 512
 
+// grid (row blocks of 32, channel tiles of 64); block = 4 waves, wave w takes rows r0+w, r0+w+4, ... (8 rows):
+// every load is independent, so a lattice level of a few thousand vertices still spreads over hundreds of blocks
 __global__ void __launch_bounds__(256) k_gn_partial(const float* __restrict__ x, int64_t V, int C,
                                                     double2* __restrict__ partial) {
-  __shared__ double2 red[4][64 * GN_MAX_CT];
+  __shared__ double2 red[4][64];
   const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+  const int c = blockIdx.y * 64 + lx;
   const int64_t r0 = (int64_t)blockIdx.x * GN_ROWS_PER_BLOCK;
-  const int64_t r1 = (r0 + GN_ROWS_PER_BLOCK < V) ? r0 + GN_ROWS_PER_BLOCK : V;
-  const int nct = (C + 63) >> 6;
-  double s[GN_MAX_CT], q[GN_MAX_CT];
+  float v[GN_ROWS_PER_BLOCK / 4];
 #pragma unroll
-  for (int t = 0; t < GN_MAX_CT; ++t) s[t] = q[t] = 0.0;
-  for (int64_t r = r0 + ly; r < r1; r += 4) {
-    const float* row = x + r * C;
-#pragma unroll
-    for (int t = 0; t < GN_MAX_CT; ++t) {
-      const int c = t * 64 + lx;
-      if (t < nct && c < C) {
-        const double v = (double)row[c];
-        s[t] += v;
-        q[t] += v * v;
-      }
-    }
+  for (int i = 0; i < GN_ROWS_PER_BLOCK / 4; ++i) {
+    const int64_t r = r0 + ly + 4 * i;
+    v[i] = (r < V && c < C) ? x[r * C + c] : 0.0f;
   }
+  double s = 0.0, q = 0.0;
 #pragma unroll
-  for (int t = 0; t < GN_MAX_CT; ++t)
-    if (t < nct) red[ly][t * 64 + lx] = make_double2(s[t], q[t]);
+  for (int i = 0; i < GN_ROWS_PER_BLOCK / 4; ++i) {
+    const double d = (double)v[i];
+    s += d;
+    q += d * d;
+  }
+  red[ly][lx] = make_double2(s, q);
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256) {
-    double2 a = red[0][c];
+  if (ly == 0 && c < C) {
+    double2 a = red[0][lx];
+#pragma unroll
     for (int w = 1; w < 4; ++w) {
-      a.x += red[w][c].x;
-      a.y += red[w][c].y;
+      a.x += red[w][lx].x;
+      a.y += red[w][lx].y;
     }
     partial[(int64_t)blockIdx.x * C + c] = a;
   }
@@ -87,14 +85,27 @@ extern "C" int tln_groupnorm_stats(const float* d_x, int64_t V, int C, int group
                                    const float* d_beta, float eps, float* d_scale, float* d_shift, void* d_ws,
                                    int64_t ws_bytes, void* stream_) {
   TLN_REQUIRE(d_x && d_scale && d_shift && d_ws, "null argument");
-  TLN_REQUIRE(V > 0 && C > 0 && C <= 64 * GN_MAX_CT && groups > 0 && C % groups == 0, "bad groupnorm shape V=%lld C=%d G=%d",
+  TLN_REQUIRE(V > 0 && C > 0 && C <= GN_MAX_C && groups > 0 && C % groups == 0, "bad groupnorm shape V=%lld C=%d G=%d",
               (long long)V, C, groups);
   TLN_REQUIRE(ws_bytes >= tln_groupnorm_ws_bytes(V, C), "groupnorm workspace too small");
   hipStream_t s = (hipStream_t)stream_;
   const int nblk = (int)tln_cdiv(V, GN_ROWS_PER_BLOCK);
-  hipLaunchKernelGGL(k_gn_partial, dim3(nblk), dim3(256), 0, s, d_x, V, C, (double2*)d_ws);
+  hipLaunchKernelGGL(k_gn_partial, dim3(nblk, (unsigned)tln_cdiv(C, 64)), dim3(256), 0, s, d_x, V, C, (double2*)d_ws);
   hipLaunchKernelGGL(k_gn_finalize, dim3((unsigned)tln_cdiv(groups, 4)), dim3(256), 0, s, (const double2*)d_ws, nblk, V,
                      C, groups, d_gamma, d_beta, eps, d_scale, d_shift);
+  TLN_LAUNCH_CHECK();
+  return TLN_OK;
+}
+
+extern "C" int tln_groupnorm_from_partials(const void* d_partials, int64_t V, int C, int groups, const float* d_gamma,
+                                           const float* d_beta, float eps, float* d_scale, float* d_shift,
+                                           void* stream_) {
+  TLN_REQUIRE(d_partials && d_scale && d_shift, "null argument");
+  TLN_REQUIRE(V > 0 && C > 0 && groups > 0 && C % groups == 0, "bad groupnorm shape V=%lld C=%d G=%d", (long long)V, C,
+              groups);
+  const int nblk = (int)tln_cdiv(V, GN_ROWS_PER_BLOCK);
+  hipLaunchKernelGGL(k_gn_finalize, dim3((unsigned)tln_cdiv(groups, 4)), dim3(256), 0, (hipStream_t)stream_,
+                     (const double2*)d_partials, nblk, V, C, groups, d_gamma, d_beta, eps, d_scale, d_shift);
   TLN_LAUNCH_CHECK();
   return TLN_OK;
 }

@@ -8,10 +8,21 @@
 // GroupNorm-apply + ReLU folded into the staging (y = relu(x*scale[c] + shift[c]); a missing neighbour
 // stays an exact zero row, as in the reference where im2row pads AFTER the activation).
 //
-// Tiling: 256 threads = 2x2 waves, each wave owns TMxTN tiles of 32x32 (block = 64TM x 64TN), K stepped
-// in BK chunks that never straddle a tap.  LDS tiles are k-major (As[k][m], Bs[k][n]) so that the MFMA
-// operand reads (lane -> m|n = lane&31, k = lane>>5) are conflict-free ds_read_b32; the next chunk's global
-// loads are issued before the MFMAs of the current one (register prefetch, one barrier pair per chunk).
+// Decomposition.  A lattice level has only a few thousand vertices, so M is small and K (9 taps x C_in) is where
+// the parallelism is:
+//   * tile: (32*WM*TM) x (64*TN) outputs; a K-group is WM x 2 waves, each wave TM x TN MFMA tiles of 32x32
+//   * split-K over the grid (blockIdx.z = S slices of the chunk list): every slice block writes its partial tile to
+//     a slab; an arrival counter per tile elects the last arriver, which sums the S slabs in FIXED order s = 0..S-1
+//     (bitwise reproducible whatever the arrival order) and runs the epilogue.  Visibility follows the agent-scope
+//     release / acquire recipe for in-launch hand-offs (stores -> vmcnt(0) -> barrier -> release fence -> vmcnt(0)
+//     -> relaxed agent atomic; reader: acquire fence -> vmcnt(0) -> barrier -> plain loads).
+//   * G K-groups inside a block interleave over the slice's chunks (more waves per SIMD to hide the gather
+//     latency) and are summed through LDS in fixed order.
+// LDS tiles are k-major (As[k][m], Bs[k][n]) so the MFMA operand reads (lane -> m|n = lane&31, k = lane>>5) are
+// conflict-free ds_read_b32; the tap-index tile of the block sits in LDS (no dependent index load); the global
+// loads of the next two chunks are in flight while the current one feeds the MFMAs.
+// Epilogue: + bias, + residual, ReLU, and optionally the per-32-row (sum, sum^2) of every output column in fp64 —
+// the GroupNorm statistics of the NEXT layer, so that no separate pass over the tensor is needed.
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -39,27 +50,41 @@ struct GemmArgs {
   int relu;
   float* out;
   int64_t ld_out;
+  double2* stats;   // optional [cdiv(M,32)][N] (sum, sumsq) of the final values
+  float* slab;      // split-K partial tiles [S][tiles][TM*TN*16][GT]
+  int* counters;    // split-K arrival counters [tiles], zero between launches
+  int splits;
 };
 
-template <int TM, int TN, int BK, bool W_NK, bool VEC>
-__global__ void __launch_bounds__(256) k_gather_gemm(const GemmArgs g) {
-  constexpr int BM = 64 * TM, BN = 64 * TN;
+template <int WM, int TM, int TN, int BK, int G, bool W_NK, bool VEC>
+__global__ void __launch_bounds__(128 * WM * G) k_gather_gemm(const GemmArgs g) {
+  constexpr int GT = 128 * WM;                // threads per K-group (WM x 2 waves)
+  constexpr int BM = 32 * WM * TM, BN = 64 * TN;
   constexpr int LDA = BM + 1;
   constexpr int LDB = W_NK ? BN + 1 : BN;
-  constexpr int KQ = BK / 4;                 // float4 per row chunk
-  constexpr int A_ROWS_PASS = 256 / KQ;      // rows staged per pass
+  constexpr int KQ = BK / 4;                  // float4 per row chunk
+  constexpr int A_ROWS_PASS = GT / KQ;        // rows staged per pass
   constexpr int A_PASSES = BM / A_ROWS_PASS;
   constexpr int B_F4_ROW = BN / 4;
-  constexpr int B_ROWS_PASS = 256 / B_F4_ROW;  // [K,N] layout: k rows per pass
+  constexpr int B_ROWS_PASS = GT / B_F4_ROW;  // [K,N] layout: k rows per pass
   constexpr int B_PASSES_KN = BK / B_ROWS_PASS;
   constexpr int B_PASSES_NK = BN / A_ROWS_PASS;  // [N,K] layout: n rows per pass (same shape as A)
   constexpr int B_PASSES = W_NK ? B_PASSES_NK : B_PASSES_KN;
-  static_assert(A_PASSES >= 1 && B_PASSES >= 1, "tile too small for 256 threads");
+  constexpr int A_TILE = ((BK * LDA + 3) / 4) * 4;
+  constexpr int B_TILE = ((BK * LDB + 3) / 4) * 4;
+  constexpr int GROUP_FLOATS = A_TILE + B_TILE;
+  constexpr int ACC = TM * TN * 16;
+  constexpr int RED_FLOATS = (G - 1) * ACC * GT;  // partial accumulators of groups 1..G-1
+  constexpr int REGION = (G * GROUP_FLOATS > RED_FLOATS) ? G * GROUP_FLOATS : RED_FLOATS;
+  static_assert(A_PASSES >= 1 && B_PASSES >= 1 && BM % A_ROWS_PASS == 0, "bad staging geometry");
 
-  __shared__ __attribute__((aligned(16))) float As[BK * LDA];
-  __shared__ __attribute__((aligned(16))) float Bs[BK * LDB + 4];
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x % GT, grp = threadIdx.x / GT;
+  float* As = smem + grp * GROUP_FLOATS;
+  float* Bs = As + A_TILE;
+  int* Is = reinterpret_cast<int*>(smem + REGION);  // [BM][TLN_TAPS] tap indices of source 0, then 1 flag word
 
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
   const int l31 = lane & 31, half = lane >> 5;
   const int64_t m0 = (int64_t)blockIdx.x * BM;
@@ -78,14 +103,26 @@ __global__ void __launch_bounds__(256) k_gather_gemm(const GemmArgs g) {
   const int cpt1 = g.nsrc > 1 ? (g.s[1].cin + BK - 1) / BK : 1;
   const int nch1 = g.nsrc > 1 ? g.s[1].taps * cpt1 : 0;
   const int nchunks = nch0 + nch1;
+  // this block's slice of the chunk list
+  const int per_slice = (nchunks + g.splits - 1) / g.splits;
+  const int c_begin = blockIdx.z * per_slice;
+  const int c_end = (c_begin + per_slice < nchunks) ? c_begin + per_slice : nchunks;
+  const int my_chunks = c_end > c_begin ? c_end - c_begin : 0;
+  const int iters = (my_chunks + G - 1) / G;
+
+  if (g.s[0].table != nullptr) {
+    const int taps = g.s[0].taps;
+    for (int i = threadIdx.x; i < BM * taps; i += GT * G) {
+      const int64_t m = m0 + i / taps;
+      Is[i] = (m < g.M) ? g.s[0].table[m * taps + (i % taps)] : -1;
+    }
+  }
+  __syncthreads();
 
   const int a_kq = tid % KQ;
   const int a_row0 = tid / KQ;
 
-  float4 a_reg[A_PASSES];
-  float4 b_reg[B_PASSES];
-
-  auto prefetch = [&](int t) {
+  auto prefetch = [&](int t, float4 (&a_reg)[A_PASSES], float4 (&b_reg)[B_PASSES]) {
     const int si = (t < nch0) ? 0 : 1;
     const SrcDev& s = g.s[si];
     const int tt = si ? t - nch0 : t;
@@ -97,11 +134,13 @@ __global__ void __launch_bounds__(256) k_gather_gemm(const GemmArgs g) {
     // ---- A: gathered rows
 #pragma unroll
     for (int p = 0; p < A_PASSES; ++p) {
-      const int64_t m = m0 + p * A_ROWS_PASS + a_row0;
+      const int rloc = p * A_ROWS_PASS + a_row0;
+      const int64_t m = m0 + rloc;
       const int c = c0 + 4 * a_kq;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (m < g.M && 4 * a_kq < kvalid) {
-        const int64_t srow = s.table ? (int64_t)s.table[m * s.taps + tap] : m;
+        int64_t srow = m;
+        if (s.table) srow = (si == 0) ? (int64_t)Is[rloc * s.taps + tap] : (int64_t)s.table[m * s.taps + tap];
         if (srow >= 0) {
           if (srow >= s.src_rows) {
             v = make_float4(s.pad, s.pad, s.pad, s.pad);
@@ -187,7 +226,7 @@ __global__ void __launch_bounds__(256) k_gather_gemm(const GemmArgs g) {
     }
   };
 
-  auto stage = [&]() {
+  auto stage = [&](const float4 (&a_reg)[A_PASSES], const float4 (&b_reg)[B_PASSES]) {
 #pragma unroll
     for (int p = 0; p < A_PASSES; ++p) {
       const int row = p * A_ROWS_PASS + a_row0;
@@ -217,11 +256,7 @@ __global__ void __launch_bounds__(256) k_gather_gemm(const GemmArgs g) {
     }
   };
 
-  prefetch(0);
-  for (int t = 0; t < nchunks; ++t) {
-    stage();
-    __syncthreads();
-    if (t + 1 < nchunks) prefetch(t + 1);
+  auto compute = [&]() {
     const float* ap = As + half * LDA + wm * 32 * TM + l31;
     const float* bp = Bs + half * LDB + wn * 32 * TN + l31;
 #pragma unroll
@@ -236,7 +271,98 @@ __global__ void __launch_bounds__(256) k_gather_gemm(const GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
+  };
+
+  // iteration `it` of group `grp` handles chunk c_begin + it*G + grp; all groups run `iters` iterations
+  float4 a0[A_PASSES], b0[B_PASSES], a1[A_PASSES], b1[B_PASSES];
+  auto chunk_of = [&](int it) { return c_begin + it * G + grp; };
+  if (iters > 0 && chunk_of(0) < c_end) prefetch(chunk_of(0), a0, b0);
+  if (iters > 1 && chunk_of(1) < c_end) prefetch(chunk_of(1), a1, b1);
+  for (int it = 0; it < iters; it += 2) {
+    {
+      const bool valid = chunk_of(it) < c_end;
+      if (valid) stage(a0, b0);
+      __syncthreads();
+      if (it + 2 < iters && chunk_of(it + 2) < c_end) prefetch(chunk_of(it + 2), a0, b0);
+      if (valid) compute();
+      __syncthreads();
+    }
+    if (it + 1 < iters) {
+      const bool valid = chunk_of(it + 1) < c_end;
+      if (valid) stage(a1, b1);
+      __syncthreads();
+      if (it + 3 < iters && chunk_of(it + 3) < c_end) prefetch(chunk_of(it + 3), a1, b1);
+      if (valid) compute();
+      __syncthreads();
+    }
+  }
+
+  // ---- sum the K-groups through LDS in fixed order (the staging tiles are idle now)
+  if (G > 1) {
+    float* red = smem;
+    if (grp > 0) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) red[((grp - 1) * ACC + (i * TN + j) * 16 + r) * GT + tid] = acc[i][j][r];
+    }
     __syncthreads();
+    if (grp > 0) return;
+#pragma unroll
+    for (int gg = 1; gg < G; ++gg)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] += red[((gg - 1) * ACC + (i * TN + j) * 16 + r) * GT + tid];
+  }
+
+  // ---- split-K over the grid: slab + arrival counter, the last arriver sums the slices in order 0..S-1
+  if (g.splits > 1) {
+    const int64_t tile = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+    const int64_t ntiles = (int64_t)gridDim.x * gridDim.y;
+    float* mine = g.slab + ((int64_t)blockIdx.z * ntiles + tile) * (ACC * GT);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mine[((i * TN + j) * 16 + r) * GT + tid] = acc[i][j][r];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* flag = Is + BM * TLN_TAPS;
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const int old = __hip_atomic_fetch_add(&g.counters[tile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = (old == g.splits - 1) ? 1 : 0;
+      if (last) {
+        __hip_atomic_store(&g.counters[tile], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      *flag = last;
+    }
+    __syncthreads();
+    if (*flag == 0) return;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    for (int sl = 0; sl < g.splits; ++sl) {
+      const float* p = g.slab + ((int64_t)sl * ntiles + tile) * (ACC * GT);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] += p[((i * TN + j) * 16 + r) * GT + tid];
+    }
   }
 
   // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -245,28 +371,39 @@ __global__ void __launch_bounds__(256) k_gather_gemm(const GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int n = n0 + wn * 32 * TN + j * 32 + l31;
-      if (n >= g.N) continue;
-      const float bias = g.bias ? g.bias[n] : 0.f;
+      const bool ncol = n < g.N;
+      const float bias = (ncol && g.bias) ? g.bias[n] : 0.f;
+      const int64_t mrow0 = m0 + wm * 32 * TM + i * 32;
+      double s1 = 0.0, s2 = 0.0;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int64_t m = m0 + wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (m >= g.M) continue;
+        const int64_t m = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (!ncol || m >= g.M) continue;
         float v = acc[i][j][r] + bias;
         if (g.res) v += g.res[m * g.ld_res + n];
         if (g.relu) v = fmaxf(v, 0.f);
         g.out[m * g.ld_out + n] = v;
+        s1 += (double)v;
+        s2 += (double)v * (double)v;
+      }
+      if (g.stats) {  // wave-uniform
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        if (half == 0 && ncol && mrow0 < g.M) g.stats[(mrow0 >> 5) * g.N + n] = make_double2(s1, s2);
       }
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-static int fill_src(SrcDev& d, const tln_gemm_src* s, int64_t M) {
+static int fill_src(SrcDev& d, const tln_gemm_src* s) {
   TLN_REQUIRE(s->d_src && s->cin > 0 && s->ld >= s->cin, "bad gemm source");
   TLN_REQUIRE(s->taps == 1 || s->taps == TLN_TAPS, "taps must be 1 or %d", TLN_TAPS);
   TLN_REQUIRE(s->d_table || s->taps == 1, "taps > 1 needs a table");
   TLN_REQUIRE((s->d_scale == nullptr) == (s->d_shift == nullptr), "scale/shift must come together");
-  (void)M;
   d.src = s->d_src;
   d.table = s->d_table;
   d.scale = s->d_scale;
@@ -280,44 +417,148 @@ static int fill_src(SrcDev& d, const tln_gemm_src* s, int64_t M) {
   return TLN_OK;
 }
 
-template <int TM, int TN, int BK, bool W_NK, bool VEC>
-static void launch_gemm(const GemmArgs& g, hipStream_t s) {
-  dim3 grid((unsigned)tln_cdiv(g.M, 64 * TM), (unsigned)tln_cdiv(g.N, 64 * TN));
-  hipLaunchKernelGGL((k_gather_gemm<TM, TN, BK, W_NK, VEC>), grid, dim3(256), 0, s, g);
+// split-K workspace (slabs + arrival counters), one per process; the library serialises on the caller's stream
+// (a handle / op set is used from one stream at a time, INTEGRATION.md "Threading")
+static float* g_slab = nullptr;
+static size_t g_slab_floats = 0;
+static int* g_counters = nullptr;
+static size_t g_counter_ints = 0;
+
+static int ensure_splitk_ws(size_t slab_floats, size_t counters, hipStream_t s) {
+  if (slab_floats > g_slab_floats) {
+    TLN_HIP(hipStreamSynchronize(s));
+    if (g_slab) (void)hipFree(g_slab);
+    g_slab = nullptr;
+    size_t want = slab_floats < (size_t)(16u << 20) ? (size_t)(16u << 20) : slab_floats;  // >= 64 MB
+    TLN_HIP(hipMalloc(&g_slab, want * sizeof(float)));
+    g_slab_floats = want;
+  }
+  if (counters > g_counter_ints) {
+    TLN_HIP(hipStreamSynchronize(s));
+    if (g_counters) (void)hipFree(g_counters);
+    g_counters = nullptr;
+    size_t want = counters < 65536 ? 65536 : counters;
+    TLN_HIP(hipMalloc(&g_counters, want * sizeof(int)));
+    TLN_HIP(hipMemsetAsync(g_counters, 0, want * sizeof(int), s));
+    g_counter_ints = want;
+  }
+  return TLN_OK;
+}
+
+struct Plan {
+  int wm, tm, tn, groups, splits;
+};
+
+template <int WM, int TM, int TN, int BK, int G, bool W_NK, bool VEC>
+static int launch_gemm(GemmArgs& g, int splits, hipStream_t s) {
+  constexpr int GT = 128 * WM;
+  constexpr int BM = 32 * WM * TM, BN = 64 * TN;
+  constexpr int LDA = BM + 1, LDB = W_NK ? BN + 1 : BN;
+  constexpr int GROUP_FLOATS = ((BK * LDA + 3) / 4) * 4 + ((BK * LDB + 3) / 4) * 4;
+  constexpr int ACC = TM * TN * 16;
+  constexpr int RED_FLOATS = (G - 1) * ACC * GT;
+  constexpr int REGION = (G * GROUP_FLOATS > RED_FLOATS) ? G * GROUP_FLOATS : RED_FLOATS;
+  const size_t lds = (size_t)(REGION + BM * TLN_TAPS + 4) * sizeof(float);
+  auto kern = k_gather_gemm<WM, TM, TN, BK, G, W_NK, VEC>;
+  if (lds > 48 * 1024) {
+    static bool attr_set = false;  // per instantiation
+    if (!attr_set) {
+      TLN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr_set = true;
+    }
+  }
+  dim3 grid((unsigned)tln_cdiv(g.M, BM), (unsigned)tln_cdiv(g.N, BN), (unsigned)splits);
+  g.splits = splits;
+  if (splits > 1) {
+    const size_t ntiles = (size_t)grid.x * grid.y;
+    int rc = ensure_splitk_ws((size_t)splits * ntiles * ACC * GT, ntiles, s);
+    if (rc) return rc;
+    g.slab = g_slab;
+    g.counters = g_counters;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(GT * G), lds, s, g);
+  return TLN_OK;
 }
 
 template <int BK, bool W_NK>
-static void dispatch_tiles(const GemmArgs& g, int tm, int tn, hipStream_t s) {
-  if (tm == 2 && tn == 2) launch_gemm<2, 2, BK, W_NK, true>(g, s);
-  else if (tm == 2) launch_gemm<2, 1, BK, W_NK, true>(g, s);
-  else if (tn == 2) launch_gemm<1, 2, BK, W_NK, true>(g, s);
-  else launch_gemm<1, 1, BK, W_NK, true>(g, s);
+static int dispatch(GemmArgs& g, const Plan& p, hipStream_t s) {
+  if (p.wm == 1) {  // 32 x 64 tile, two waves per K-group
+    if (p.groups >= 4) return launch_gemm<1, 1, 1, BK, 4, W_NK, true>(g, p.splits, s);
+    if (p.groups == 2) return launch_gemm<1, 1, 1, BK, 2, W_NK, true>(g, p.splits, s);
+    return launch_gemm<1, 1, 1, BK, 1, W_NK, true>(g, p.splits, s);
+  }
+  if (p.tm == 2 && p.tn == 2) return launch_gemm<2, 2, 2, BK, 1, W_NK, true>(g, p.splits, s);
+  if (p.tm == 2) return launch_gemm<2, 2, 1, BK, 1, W_NK, true>(g, p.splits, s);
+  if (p.tn == 2) return launch_gemm<2, 1, 2, BK, 1, W_NK, true>(g, p.splits, s);
+  if (p.groups >= 4) return launch_gemm<2, 1, 1, BK, 4, W_NK, true>(g, p.splits, s);
+  if (p.groups == 2) return launch_gemm<2, 1, 1, BK, 2, W_NK, true>(g, p.splits, s);
+  return launch_gemm<2, 1, 1, BK, 1, W_NK, true>(g, p.splits, s);
 }
 
-// optional tile override for tuning (0 = heuristic)
-static int g_force_tm = 0, g_force_tn = 0;
+// optional overrides for tuning / tests (0 = heuristic)
+static int g_force_tm = 0, g_force_tn = 0, g_force_groups = 0, g_force_splits = 0, g_force_wm = 0;
 extern "C" void tln_gemm_force_tiles(int tm, int tn) {
   g_force_tm = tm;
   g_force_tn = tn;
 }
+extern "C" void tln_gemm_force_groups(int groups) { g_force_groups = groups; }
+extern "C" void tln_gemm_force_splits(int splits, int wm) {
+  g_force_splits = splits;
+  g_force_wm = wm;
+}
 
-extern "C" int tln_gather_gemm(int64_t M, int N, const tln_gemm_src* s0, const tln_gemm_src* s1, const float* d_w,
-                               int w_is_nk, const float* d_bias, const float* d_residual, int64_t ld_res, int relu,
-                               float* d_out, int64_t ld_out, void* stream_) {
+static Plan make_plan(int64_t M, int N, int nchunks) {
+  Plan p{2, 1, 1, 1, 1};
+  auto nblk = [&](int bm, int bn) { return tln_cdiv(M, bm) * tln_cdiv(N, bn); };
+  // big problems: 128 x 128 / 128 x 64 / 64 x 128 tiles, no split
+  if (nblk(128, N > 64 ? 128 : 64) >= 512) {
+    p.tm = 2;
+    p.tn = (N > 64) ? 2 : 1;
+  } else if (nblk(64, N > 64 ? 128 : 64) >= 512) {
+    p.tn = (N > 64) ? 2 : 1;
+  } else if (nblk(64, 64) < 512) {
+    // small M (a lattice level of a few thousand vertices): 32-row tiles, K-groups for latency hiding, and when
+    // even the 32-row tiles cannot cover the CUs, slices of K over the grid.  Thresholds from tools/gemm_bench.py
+    // on MI355X (profiles/r01_gemm_sweep.txt).
+    p.wm = 1;
+    const int64_t tiles = nblk(32, 64);
+    int splits = 1;
+    if (tiles < 160)
+      while (splits < 4 && tiles * splits * 2 <= 512 && nchunks >= 4 * (splits * 2)) splits *= 2;
+    p.splits = splits;
+    const int per = (nchunks + splits - 1) / splits;
+    p.groups = splits == 1 ? (per >= 8 ? 4 : (per >= 4 ? 2 : 1)) : (per >= 4 ? 2 : 1);
+  }
+  if (g_force_tm) p.tm = g_force_tm;
+  if (g_force_tn) p.tn = g_force_tn;
+  if (g_force_wm) p.wm = g_force_wm;
+  if (g_force_groups) p.groups = g_force_groups;
+  if (g_force_splits) p.splits = g_force_splits;
+  if (p.tm == 2 || p.tn == 2) {
+    p.wm = 2;
+    p.groups = 1;
+  }
+  if (p.splits > nchunks) p.splits = nchunks > 0 ? nchunks : 1;
+  return p;
+}
+
+extern "C" int tln_gather_gemm_ex(int64_t M, int N, const tln_gemm_src* s0, const tln_gemm_src* s1, const float* d_w,
+                                  int w_is_nk, const float* d_bias, const float* d_residual, int64_t ld_res, int relu,
+                                  float* d_out, int64_t ld_out, void* d_stats, void* stream_) {
   TLN_REQUIRE(s0 && d_w && d_out, "null argument");
   TLN_REQUIRE(M >= 0 && N > 0 && ld_out >= N, "bad gemm shape M=%lld N=%d", (long long)M, N);
   if (M == 0) return TLN_OK;
-  TLN_REQUIRE(tln_cdiv(M, 64) < (1ll << 31), "M too large");
+  TLN_REQUIRE(tln_cdiv(M, 32) < (1ll << 31), "M too large");
   GemmArgs g{};
   g.M = M;
   g.N = N;
-  int rc = fill_src(g.s[0], s0, M);
+  int rc = fill_src(g.s[0], s0);
   if (rc) return rc;
   g.K0 = s0->taps * s0->cin;
   g.nsrc = 1;
   int K = g.K0;
   if (s1) {
-    rc = fill_src(g.s[1], s1, M);
+    rc = fill_src(g.s[1], s1);
     if (rc) return rc;
     g.nsrc = 2;
     K += s1->taps * s1->cin;
@@ -330,40 +571,40 @@ extern "C" int tln_gather_gemm(int64_t M, int N, const tln_gemm_src* s0, const t
   g.relu = relu;
   g.out = d_out;
   g.ld_out = ld_out;
+  g.stats = reinterpret_cast<double2*>(d_stats);
+  g.splits = 1;
   hipStream_t s = (hipStream_t)stream_;
 
   bool vec = aligned16(d_w);
   for (int i = 0; i < g.nsrc; ++i) {
     const SrcDev& d = g.s[i];
     vec = vec && aligned16(d.src) && (d.ld % 4 == 0) && (d.cin % 4 == 0);
-    if (d.scale) vec = vec && true;
   }
   vec = vec && (w_is_nk ? (K % 4 == 0) : (N % 4 == 0));
-  int min_cin = g.s[0].cin;
-  if (g.nsrc > 1 && g.s[1].cin < min_cin) min_cin = g.s[1].cin;
   const bool bk32 = (g.s[0].cin % 32 == 0) && (g.nsrc == 1 || g.s[1].cin % 32 == 0);
 
   if (!vec) {
-    if (w_is_nk) launch_gemm<1, 1, 16, true, false>(g, s);
-    else launch_gemm<1, 1, 16, false, false>(g, s);
+    rc = w_is_nk ? launch_gemm<2, 1, 1, 16, 1, true, false>(g, 1, s) : launch_gemm<2, 1, 1, 16, 1, false, false>(g, 1, s);
+    if (rc) return rc;
     TLN_LAUNCH_CHECK();
     return TLN_OK;
   }
-  int tn = (N > 64) ? 2 : 1, tm = 2;
-  auto blocks = [&](int a, int b) { return tln_cdiv(M, 64 * a) * tln_cdiv(N, 64 * b); };
-  if (blocks(tm, tn) < 512) tm = 1;
-  if (blocks(tm, tn) < 512 && tn == 2) tn = 1;
-  if (g_force_tm) tm = g_force_tm;
-  if (g_force_tn) tn = g_force_tn;
-  if (bk32) {
-    if (w_is_nk) dispatch_tiles<32, true>(g, tm, tn, s);
-    else dispatch_tiles<32, false>(g, tm, tn, s);
-  } else {
-    if (w_is_nk) dispatch_tiles<16, true>(g, tm, tn, s);
-    else dispatch_tiles<16, false>(g, tm, tn, s);
-  }
+  const int bk = bk32 ? 32 : 16;
+  int nchunks = 0;
+  for (int i = 0; i < g.nsrc; ++i) nchunks += g.s[i].taps * ((g.s[i].cin + bk - 1) / bk);
+  const Plan p = make_plan(M, N, nchunks);
+  if (bk32) rc = w_is_nk ? dispatch<32, true>(g, p, s) : dispatch<32, false>(g, p, s);
+  else rc = w_is_nk ? dispatch<16, true>(g, p, s) : dispatch<16, false>(g, p, s);
+  if (rc) return rc;
   TLN_LAUNCH_CHECK();
   return TLN_OK;
+}
+
+extern "C" int tln_gather_gemm(int64_t M, int N, const tln_gemm_src* s0, const tln_gemm_src* s1, const float* d_w,
+                               int w_is_nk, const float* d_bias, const float* d_residual, int64_t ld_res, int relu,
+                               float* d_out, int64_t ld_out, void* stream_) {
+  return tln_gather_gemm_ex(M, N, s0, s1, d_w, w_is_nk, d_bias, d_residual, ld_res, relu, d_out, ld_out, nullptr,
+                            stream_);
 }
 
 // ---------------------------------------------------------------------------------------

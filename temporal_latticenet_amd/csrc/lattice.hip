@@ -63,6 +63,8 @@ struct tln_lattice {
   void* sort_temp = nullptr;
   size_t sort_temp_bytes = 0;
   int32_t* seg_start = nullptr;  // [capacity+2]
+  float* mean = nullptr;         // [capacity][3] local mean of the last distribute
+  double* pieces = nullptr;      // [rows_cap/256+1][2][3] partial sums of segments that span blocks
   int64_t csr_rows = -1;
   // pool workspace
   unsigned long long* pool_packed = nullptr;
@@ -96,11 +98,12 @@ static int ensure_rows(tln_lattice* l, int64_t rows) {
   if (rows <= l->rows_cap) return TLN_OK;
   int64_t cap = 1;
   while (cap < rows) cap <<= 1;
-  void* ptrs[] = {l->row_slot, l->block_cnt, l->sk_in, l->sk_out, l->sv_in, l->sv_out, l->sort_temp};
+  void* ptrs[] = {l->row_slot, l->block_cnt, l->sk_in, l->sk_out, l->sv_in, l->sv_out, l->sort_temp, l->pieces};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   l->row_slot = l->block_cnt = l->sk_in = l->sk_out = l->sv_in = l->sv_out = nullptr;
   l->sort_temp = nullptr;
+  l->pieces = nullptr;
   l->rows_cap = 0;
   TLN_HIP(hipMalloc(&l->row_slot, cap * sizeof(int32_t)));
   TLN_HIP(hipMalloc(&l->block_cnt, (cap / TLN_SCAN_BLOCK + 2) * sizeof(int32_t)));
@@ -108,6 +111,7 @@ static int ensure_rows(tln_lattice* l, int64_t rows) {
   TLN_HIP(hipMalloc(&l->sk_out, cap * sizeof(int32_t)));
   TLN_HIP(hipMalloc(&l->sv_in, cap * sizeof(int32_t)));
   TLN_HIP(hipMalloc(&l->sv_out, cap * sizeof(int32_t)));
+  TLN_HIP(hipMalloc(&l->pieces, (cap / 256 + 2) * 6 * sizeof(double)));
   size_t bytes = 0;
   TLN_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, l->sk_in, l->sk_out, l->sv_in, l->sv_out, (int)cap, 0, 32,
                                              (hipStream_t)0));
@@ -139,6 +143,7 @@ static int lattice_alloc(tln_lattice** out, int pos_dim, const double* sigmas, i
   TLN_HIP(hipMalloc(&l->d_ctr, CTR_COUNT * sizeof(int32_t)));
   TLN_HIP(hipHostMalloc(&l->h_ctr, CTR_COUNT * sizeof(int32_t)));
   TLN_HIP(hipMalloc(&l->seg_start, (capacity + 2) * sizeof(int32_t)));
+  TLN_HIP(hipMalloc(&l->mean, capacity * 3 * sizeof(float)));
   *out = l;
   return TLN_OK;
 }
@@ -176,7 +181,7 @@ extern "C" int tln_lattice_destroy(tln_lattice_t* l) {
   if (l->coarse) tln_lattice_destroy(l->coarse);
   void* ptrs[] = {l->slot_key, l->slot_val, l->slot_touch, l->vkeys, l->d_ctr, l->nbr, l->c2f, l->f2c,
                   l->row_slot, l->block_cnt, l->sk_in, l->sk_out, l->sv_in, l->sv_out, l->sort_temp,
-                  l->seg_start, l->pool_packed};
+                  l->seg_start, l->pool_packed, l->mean, l->pieces};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (l->h_ctr) (void)hipHostFree(l->h_ctr);
@@ -661,37 +666,111 @@ extern "C" int tln_build_csr(tln_lattice_t* l, const int32_t* d_indices, int64_t
 }
 
 // ---------------------------------------------------------------------------------------
-// K1 phase D: local mean per vertex (double accumulation, fixed tree) and subtraction
-// one wave per vertex; rows of the vertex come from the CSR
+// K1 phase D: local mean per vertex and subtraction, independent of how skewed the rows-per-vertex
+// distribution is (one vertex next to the sensor collects thousands of rows):
+//   k_mean_pieces : 256 consecutive SORTED rows per block, segmented inclusive scan (fp64, fixed tree) by vertex;
+//                   a segment that lies inside one block is finished there, otherwise the block stores the sum of
+//                   its first piece (slot 0, touches the block start) and last piece (slot 1)
+//   k_mean_combine: segments spanning several blocks add their pieces in block order
+//   k_subtract_rows: dist[row][0:3] = pos - mean[vertex]
 // ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_subtract_mean(const float* __restrict__ pos, const int32_t* __restrict__ order,
-                                                       const int32_t* __restrict__ seg_start, int64_t nv, int cols,
-                                                       float* __restrict__ dist) {
-  const int64_t v = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+#define MEAN_BLOCK 256
+__global__ void __launch_bounds__(MEAN_BLOCK) k_mean_pieces(const float* __restrict__ pos,
+                                                            const int32_t* __restrict__ order,
+                                                            const int32_t* __restrict__ sorted_vertex,
+                                                            const int32_t* __restrict__ seg_start, int nv,
+                                                            float* __restrict__ mean, double* __restrict__ pieces) {
+  __shared__ double sx[MEAN_BLOCK], sy[MEAN_BLOCK], sz[MEAN_BLOCK];
+  __shared__ int key[MEAN_BLOCK];
+  const int valid_rows = seg_start[nv];  // rows that have a vertex (the tail bucket is excluded)
+  const int j = threadIdx.x;
+  const int base = blockIdx.x * MEAN_BLOCK;
+  const int gi = base + j;
+  const bool ok = gi < valid_rows;
+  int v = -1 - j;  // unique dummy keys for the padding lanes
+  double x = 0, y = 0, z = 0;
+  if (ok) {
+    v = sorted_vertex[gi];
+    const int64_t p = order[gi] >> 2;
+    x = (double)pos[3 * p];
+    y = (double)pos[3 * p + 1];
+    z = (double)pos[3 * p + 2];
+  }
+  key[j] = v;
+  sx[j] = x;
+  sy[j] = y;
+  sz[j] = z;
+  __syncthreads();
+#pragma unroll
+  for (int o = 1; o < MEAN_BLOCK; o <<= 1) {
+    double ax = 0, ay = 0, az = 0;
+    const bool take = (j >= o) && (key[j - o] == v);
+    if (take) {
+      ax = sx[j - o];
+      ay = sy[j - o];
+      az = sz[j - o];
+    }
+    __syncthreads();
+    if (take) {
+      sx[j] += ax;
+      sy[j] += ay;
+      sz[j] += az;
+    }
+    __syncthreads();
+  }
+  if (!ok) return;
+  const int last = ((valid_rows - base) < MEAN_BLOCK ? (valid_rows - base) : MEAN_BLOCK) - 1;
+  const bool seg_end = (j == last) || (key[j + 1] != v);
+  if (!seg_end) return;
+  const int b = seg_start[v], e = seg_start[v + 1];
+  if (b >= base && e <= base + last + 1) {
+    const double cnt = (double)(e - b);
+    mean[3 * v] = (float)(sx[j] / cnt);
+    mean[3 * v + 1] = (float)(sy[j] / cnt);
+    mean[3 * v + 2] = (float)(sz[j] / cnt);
+  } else {
+    const int slot = (key[0] == v) ? 0 : 1;
+    double* d = pieces + ((int64_t)blockIdx.x * 2 + slot) * 3;
+    d[0] = sx[j];
+    d[1] = sy[j];
+    d[2] = sz[j];
+  }
+}
+
+__global__ void __launch_bounds__(256) k_mean_combine(const int32_t* __restrict__ seg_start, int nv,
+                                                      const double* __restrict__ pieces, float* __restrict__ mean) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= nv) return;
-  const int lane = threadIdx.x & 63;
   const int b = seg_start[v], e = seg_start[v + 1];
   if (b == e) return;
-  double sx = 0, sy = 0, sz = 0;
-  for (int j = b + lane; j < e; j += 64) {
-    const int64_t p = order[j] >> 2;
-    sx += (double)pos[3 * p];
-    sy += (double)pos[3 * p + 1];
-    sz += (double)pos[3 * p + 2];
+  const int kb = b / MEAN_BLOCK, ke = (e - 1) / MEAN_BLOCK;
+  if (kb == ke) return;  // finished by k_mean_pieces
+  const double* d = pieces + ((int64_t)kb * 2 + ((b % MEAN_BLOCK == 0) ? 0 : 1)) * 3;
+  double x = d[0], y = d[1], z = d[2];
+  for (int k = kb + 1; k <= ke; ++k) {
+    d = pieces + (int64_t)k * 2 * 3;
+    x += d[0];
+    y += d[1];
+    z += d[2];
   }
-  sx = tln_wave_sum(sx);
-  sy = tln_wave_sum(sy);
-  sz = tln_wave_sum(sz);
   const double cnt = (double)(e - b);
-  const float mx = (float)(sx / cnt), my = (float)(sy / cnt), mz = (float)(sz / cnt);
-  for (int j = b + lane; j < e; j += 64) {
-    const int64_t row = order[j];
-    const int64_t p = row >> 2;
-    float* d = dist + row * cols;
-    d[0] = pos[3 * p] - mx;
-    d[1] = pos[3 * p + 1] - my;
-    d[2] = pos[3 * p + 2] - mz;
-  }
+  mean[3 * v] = (float)(x / cnt);
+  mean[3 * v + 1] = (float)(y / cnt);
+  mean[3 * v + 2] = (float)(z / cnt);
+}
+
+__global__ void __launch_bounds__(256) k_subtract_rows(const float* __restrict__ pos, const int32_t* __restrict__ indices,
+                                                       const float* __restrict__ mean, int64_t rows, int cols,
+                                                       float* __restrict__ dist) {
+  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= rows) return;
+  const int v = indices[row];
+  if (v < 0) return;  // rows without a vertex keep the raw position
+  const int64_t p = row >> 2;
+  float* d = dist + row * cols;
+  d[0] = pos[3 * p] - mean[3 * v];
+  d[1] = pos[3 * p + 1] - mean[3 * v + 1];
+  d[2] = pos[3 * p + 2] - mean[3 * v + 2];
 }
 
 extern "C" int tln_distribute(tln_lattice_t* l, const float* d_positions, const float* d_values, int64_t n,
@@ -723,8 +802,12 @@ extern "C" int tln_distribute(tln_lattice_t* l, const float* d_positions, const 
   if (rc) return rc;
   if (subtract_mean && l->nr_vertices > 0) {
     const int64_t nv = l->nr_vertices;
-    hipLaunchKernelGGL(k_subtract_mean, dim3((unsigned)tln_cdiv(nv * 64, 256)), dim3(256), 0, s, d_positions,
-                       l->sv_out, l->seg_start, nv, 3 + val_dim + 1, d_distributed);
+    hipLaunchKernelGGL(k_mean_pieces, dim3((unsigned)tln_cdiv(rows, MEAN_BLOCK)), dim3(MEAN_BLOCK), 0, s, d_positions,
+                       l->sv_out, l->sk_out, l->seg_start, (int)nv, l->mean, l->pieces);
+    hipLaunchKernelGGL(k_mean_combine, dim3((unsigned)tln_cdiv(nv, 256)), dim3(256), 0, s, l->seg_start, (int)nv,
+                       l->pieces, l->mean);
+    hipLaunchKernelGGL(k_subtract_rows, dim3((unsigned)tln_cdiv(rows, 256)), dim3(256), 0, s, d_positions, d_indices,
+                       l->mean, rows, 3 + val_dim + 1, d_distributed);
     TLN_LAUNCH_CHECK();
   }
   return TLN_OK;

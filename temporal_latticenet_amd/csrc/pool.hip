@@ -39,32 +39,18 @@ template <int CIN, int H1, int H2, int COUT>
 __global__ void __launch_bounds__(256) k_pool_chunks(const float* __restrict__ dist, int cols,
                                                      const int32_t* __restrict__ order,
                                                      const int32_t* __restrict__ sorted_vertex, int64_t rows, int nv,
-                                                     MlpParams mp, unsigned long long* __restrict__ packed) {
-  constexpr int NW1 = H1 * CIN, NW2 = (H2 ? H2 : COUT) * H1, NW3 = H2 ? COUT * H2 : 0;
-  constexpr int NB1 = H1, NB2 = (H2 ? H2 : COUT), NB3 = H2 ? COUT : 0;
+                                                     const float* __restrict__ w1, const float* __restrict__ b1,
+                                                     const float* __restrict__ w2, const float* __restrict__ b2,
+                                                     const float* __restrict__ w3, const float* __restrict__ b3,
+                                                     unsigned long long* __restrict__ packed) {
+  // the MLP weights are wave-uniform, read-only kernel arguments indexed by compile-time constants: the
+  // compiler keeps them in SGPRs (s_load_dwordx8/x16), so the dense layers cost no LDS or vector-memory traffic
   constexpr int TS = COUT + 1;  // padded tile stride
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* w1 = smem;
-  float* w2 = w1 + NW1;
-  float* w3 = w2 + NW2;
-  float* b1 = w3 + NW3;
-  float* b2 = b1 + NB1;
-  float* b3 = b2 + NB2;
-  float* tiles = b3 + NB3;
   const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  float* tile = tiles + wid * (64 * TS + 128);
+  float* tile = smem + wid * (64 * TS + 128);
   int* tv = reinterpret_cast<int*>(tile + 64 * TS);
   int* tr = tv + 64;
-
-  if (H1) {
-    for (int i = threadIdx.x; i < NW1; i += 256) w1[i] = mp.w[0][i];
-    for (int i = threadIdx.x; i < NW2; i += 256) w2[i] = mp.w[1][i];
-    for (int i = threadIdx.x; i < NW3; i += 256) w3[i] = mp.w[2][i];
-    for (int i = threadIdx.x; i < NB1; i += 256) b1[i] = mp.b[0][i];
-    for (int i = threadIdx.x; i < NB2; i += 256) b2[i] = mp.b[1][i];
-    for (int i = threadIdx.x; i < NB3; i += 256) b3[i] = mp.b[2][i];
-  }
-  __syncthreads();
 
   const int64_t chunk = (int64_t)blockIdx.x * 4 + wid;
   const int64_t j0 = chunk * 64;
@@ -156,9 +142,7 @@ __global__ void __launch_bounds__(256) k_pool_finalize(const unsigned long long*
 template <int CIN, int H1, int H2, int COUT>
 static int launch_pool(tln_lattice* l, const float* d_dist, int64_t rows, int cols, const float* const* w,
                        const float* const* b, int nv, unsigned long long* packed, hipStream_t s) {
-  constexpr int NW = H1 * CIN + (H2 ? H2 : COUT) * H1 + (H2 ? COUT * H2 : 0);
-  constexpr int NB = H1 + (H2 ? H2 : COUT) + (H2 ? COUT : 0);
-  const size_t lds = (size_t)((H1 ? NW + NB : 0) + 4 * (64 * (COUT + 1) + 128)) * sizeof(float);
+  const size_t lds = (size_t)(4 * (64 * (COUT + 1) + 128)) * sizeof(float);
   MlpParams mp{};
   for (int i = 0; i < 3; ++i) {
     mp.w[i] = (H1 && w) ? w[i < (H2 ? 3 : 2) ? i : 0] : nullptr;
@@ -168,7 +152,7 @@ static int launch_pool(tln_lattice* l, const float* d_dist, int64_t rows, int co
   auto kern = k_pool_chunks<CIN, H1, H2, COUT>;
   TLN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)tln_cdiv(chunks, 4)), dim3(256), lds, s, d_dist, cols, tln_lat_order(l),
-                     tln_lat_sorted_vertex(l), rows, nv, mp, packed);
+                     tln_lat_sorted_vertex(l), rows, nv, mp.w[0], mp.b[0], mp.w[1], mp.b[1], mp.w[2], mp.b[2], packed);
   TLN_LAUNCH_CHECK();
   return TLN_OK;
 }

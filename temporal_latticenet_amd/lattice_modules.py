@@ -130,7 +130,7 @@ class Conv1x1(torch.nn.Module):
         scale, shift, relu = prologue if prologue is not None else (None, None, False)
         src = ops.gemm_src(lv, scale=scale, shift=shift, relu=relu)
         out = ops.gather_gemm(lv.shape[0], self.linear.weight, src, w_is_nk=True, bias=self.linear.bias,
-                              residual=residual)
+                              residual=residual, stats=True)
         ls.set_values(out)
         return out, ls
 
@@ -157,7 +157,8 @@ class _TapConv(torch.nn.Module):
             self._make(lv.shape[1])
         scale, shift, relu = prologue if prologue is not None else (None, None, False)
         src = ops.gemm_src(lv, table_ptr, 9, scale=scale, shift=shift, relu=relu)
-        return ops.gather_gemm(rows, self.weight, src, bias=self.bias, residual=residual)
+        # stats=True: the product also emits the GroupNorm partial sums of its output for whatever Gn comes next
+        return ops.gather_gemm(rows, self.weight, src, bias=self.bias, residual=residual, stats=True)
 
 
 class ConvLatticeModule(_TapConv):

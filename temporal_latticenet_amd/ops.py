@@ -73,8 +73,10 @@ def gemm_src(src, table_ptr=None, taps=1, src_rows=None, pad_value=0.0, scale=No
     return s, (src, scale, shift)
 
 
-def gather_gemm(M, weight, s0, s1=None, w_is_nk=False, bias=None, residual=None, relu=False, out=None):
-    """out[M,N] = epi( [gather(s0) | gather(s1)] @ W ).  weight: [K,N] (w_is_nk False) or [N,K]."""
+def gather_gemm(M, weight, s0, s1=None, w_is_nk=False, bias=None, residual=None, relu=False, out=None, stats=False):
+    """out[M,N] = epi( [gather(s0) | gather(s1)] @ W ).  weight: [K,N] (w_is_nk False) or [N,K].
+    stats=True additionally produces the per-32-row (sum, sumsq) of every output column (GroupNorm statistics of the
+    next layer) and attaches them to the result as `out._tln_stats`."""
     weight = _f32c(weight)
     N = weight.shape[0] if w_is_nk else weight.shape[1]
     K = weight.shape[1] if w_is_nk else weight.shape[0]
@@ -88,21 +90,32 @@ def gather_gemm(M, weight, s0, s1=None, w_is_nk=False, bias=None, residual=None,
         raise _lib.TlnError("gather_gemm: residual shape %s != (%d,%d)" % (tuple(residual.shape), M, N))
     if bias is not None and bias.numel() != N:
         raise _lib.TlnError("gather_gemm: bias has %d entries, N=%d" % (bias.numel(), N))
+    st = torch.empty(((M + 31) // 32, N, 2), dtype=torch.float64, device="cuda") if (stats and M > 0) else None
     with _timed("gather_gemm", M=M, N=N, K=K, taps=s0[0].taps, cin=s0[0].cin, res=residual is not None):
-        rc = _lib.lib().tln_gather_gemm(M, N, C.byref(s0[0]), C.byref(s1[0]) if s1 is not None else None,
-                                        _ptr(weight), 1 if w_is_nk else 0, _ptr(bias), _ptr(residual),
-                                        residual.stride(0) if residual is not None else 0, 1 if relu else 0,
-                                        _ptr(out), out.stride(0), stream_ptr())
+        rc = _lib.lib().tln_gather_gemm_ex(M, N, C.byref(s0[0]), C.byref(s1[0]) if s1 is not None else None,
+                                           _ptr(weight), 1 if w_is_nk else 0, _ptr(bias), _ptr(residual),
+                                           residual.stride(0) if residual is not None else 0, 1 if relu else 0,
+                                           _ptr(out), out.stride(0), _ptr(st), stream_ptr())
     _lib.check(rc, "tln_gather_gemm")
+    if st is not None:
+        out._tln_stats = st
     return out
 
 
 def groupnorm_stats(x, groups, gamma, beta, eps=1e-5):
-    """per-channel (scale, shift) such that x*scale+shift == GroupNorm_over_all_vertices(x)*gamma+beta"""
+    """per-channel (scale, shift) such that x*scale+shift == GroupNorm_over_all_vertices(x)*gamma+beta.
+    If x was produced by gather_gemm(..., stats=True) its partial sums are reused (one tiny launch)."""
     x = _f32c(x)
     V, Cn = x.shape
     scale = torch.empty((Cn,), dtype=torch.float32, device="cuda")
     shift = torch.empty((Cn,), dtype=torch.float32, device="cuda")
+    st = getattr(x, "_tln_stats", None)
+    if st is not None and tuple(st.shape) == ((V + 31) // 32, Cn, 2):
+        gamma, beta = _f32c(gamma), _f32c(beta)
+        _lib.check(_lib.lib().tln_groupnorm_from_partials(_ptr(st), V, Cn, groups, _ptr(gamma), _ptr(beta),
+                                                          float(eps), _ptr(scale), _ptr(shift), stream_ptr()),
+                   "tln_groupnorm_from_partials")
+        return scale, shift
     ws_bytes = int(_lib.lib().tln_groupnorm_ws_bytes(V, Cn))
     ws = torch.empty((max(ws_bytes, 16) // 8,), dtype=torch.float64, device="cuda")
     gamma, beta = _f32c(gamma), _f32c(beta)

@@ -96,6 +96,50 @@ def test_gemm_all_tiles_with_prologue_epilogue(gpu, tm, tn):
     np.testing.assert_allclose(out.cpu().numpy(), want.numpy(), rtol=1e-4, atol=5e-5)
 
 
+@pytest.mark.parametrize("splits,wm,groups", [(1, 1, 1), (2, 1, 2), (4, 1, 1), (8, 2, 1), (3, 2, 4), (2, 1, 4)])
+def test_gemm_split_k_is_exact_and_reproducible(gpu, splits, wm, groups):
+    """split-K over the grid (slab + last-arriver reduction in fixed slice order), 32- and 64-row tiles, K-groups,
+    and the fused GroupNorm partial sums of the epilogue"""
+    from temporal_latticenet_amd import _lib, ops
+    lat, tab, _, _ = _lattice(gpu, 20000, 0.5)
+    V = lat.nr_lattice_vertices()
+    g = torch.Generator().manual_seed(11)
+    cin, cout = 96, 160
+    lv = torch.randn(V, cin, generator=g)
+    W = torch.randn(9 * cin, cout, generator=g) / np.sqrt(9 * cin)
+    b = torch.randn(cout, generator=g)
+    res = torch.randn(V, cout, generator=g)
+    lib = _lib.lib()
+    lib.tln_gemm_force_splits(splits, wm)
+    lib.tln_gemm_force_groups(groups)
+    try:
+        outs = []
+        for _ in range(3):
+            s0 = ops.gemm_src(lv.to(gpu), lat.neighbour_table_ptr(), 9)
+            outs.append(ops.gather_gemm(V, W.to(gpu), s0, bias=b.to(gpu), residual=res.to(gpu), relu=True, stats=True))
+    finally:
+        lib.tln_gemm_force_splits(0, 0)
+        lib.tln_gemm_force_groups(0)
+    want = torch.relu(O.conv(lv, P.neighbour_table(tab), W, b) + res)
+    np.testing.assert_allclose(outs[0].cpu().numpy(), want.numpy(), rtol=1e-4, atol=3e-5)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2]), "bitwise reproducible"
+    # fused statistics == statistics of the tensor that was written
+    st = outs[0]._tln_stats.cpu()
+    got = outs[0].cpu().double()
+    nb = (V + 31) // 32
+    pad = torch.zeros(nb * 32 - V, cout, dtype=torch.float64)
+    blk = torch.cat([got, pad]).reshape(nb, 32, cout)
+    np.testing.assert_allclose(st[:, :, 0].numpy(), blk.sum(1).numpy(), rtol=1e-12, atol=1e-9)
+    np.testing.assert_allclose(st[:, :, 1].numpy(), (blk * blk).sum(1).numpy(), rtol=1e-12, atol=1e-9)
+    # and the GroupNorm built from them equals the two-pass one
+    gamma, beta = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+    sc1, sh1 = ops.groupnorm_stats(outs[0], 32, gamma.to(gpu), beta.to(gpu))
+    plain = outs[0].clone()
+    sc2, sh2 = ops.groupnorm_stats(plain, 32, gamma.to(gpu), beta.to(gpu))
+    np.testing.assert_allclose(sc1.cpu().numpy(), sc2.cpu().numpy(), rtol=1e-6)
+    np.testing.assert_allclose(sh1.cpu().numpy(), sh2.cpu().numpy(), rtol=1e-5, atol=1e-6)
+
+
 @pytest.mark.parametrize("V,cin,cout", [(1000, 64, 64), (37, 256, 64), (5000, 192, 26), (3, 8, 4), (777, 36, 4)])
 def test_linear_nk_layout_and_two_sources(gpu, V, cin, cout):
     from temporal_latticenet_amd import ops
