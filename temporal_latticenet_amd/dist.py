@@ -113,3 +113,112 @@ class FrameShardPlan:
 
     def owns_last_frame(self):
         return self.frames[-1] == self.nr_frames - 1
+
+
+class FrameShardRunner:
+    """Runs a stream of T-frame sequences with the frames of each sequence sharded over the ranks of a group
+    (FrameShardPlan) while keeping the single-GPU sequential semantics of LNN_SEQ (models.py:284-476):
+
+      1. every rank hashes its own frames on a scratch lattice and the group all-gathers the first-touch-ordered
+         keys of every frame (`all_gather_rows`); done for the whole batch of sequences up front so that the
+         collective never sits between two pipeline stages;
+      2. per sequence, a rank inserts the keys of the frames before its block (`Lattice.insert_keys`), which
+         reproduces the sequential vertex numbering on every level, then runs its frames through the model;
+      3. each fusion module receives its hidden state from the previous rank right before it is needed and
+         sends it to the next rank right after it is produced (forward hooks, point-to-point), so rank g works on
+         stage s of its frame while rank g-1 is already past it — over a stream of sequences this is a systolic
+         pipeline in which every rank is busy with a different sequence.
+
+    `via_host=True` stages tensors through host memory (gloo); otherwise tensors go GPU-to-GPU (RCCL over xGMI).
+    """
+
+    def __init__(self, model, make_lattice, plan, group=None, via_host=False):
+        self.model, self.make_lattice, self.plan = model, make_lattice, plan
+        self.group, self.via_host = group, via_host
+        self.scratch = make_lattice()
+        self.lattice = make_lattice()
+        self._recv_now = False
+        self._send_now = False
+        self._slots = []
+        self._install_hooks()
+
+    # ---- hidden-state hand-off ----------------------------------------------------------------
+    def _fusion_modules(self):
+        m = self.model
+        mods = []
+        if m.sequence_learning:
+            if m.point_net_seq.fusion_module is not None:
+                mods.append(m.point_net_seq.fusion_module)
+            mods += [x for x in m.recurrent_fusion_modules if x is not None]
+        return mods
+
+    def _install_hooks(self):
+        for slot, mod in enumerate(self._fusion_modules()):
+            self._slots.append(mod)
+            mod.register_forward_pre_hook(self._make_pre(slot))
+            mod.register_forward_hook(self._make_post(slot))
+
+    def _make_pre(self, slot):
+        def pre(mod, args):
+            if self._recv_now and self.plan.prev_rank is not None:
+                dev = "cpu" if self.via_host else args[0].device
+                h = recv_tensor(self.plan.prev_rank, dev, tag=slot, group=self.group)
+                mod.h_lv = h.to(args[0].device) if h.numel() else None
+            return None
+        return pre
+
+    def _make_post(self, slot):
+        def post(mod, args, out):
+            if self._send_now and self.plan.next_rank is not None:
+                h = mod.h_lv
+                if h is None:
+                    h = torch.zeros(0, device=args[0].device)
+                send_tensor(h.cpu() if self.via_host else h, self.plan.next_rank, tag=slot, group=self.group)
+            return None
+        return post
+
+    # ---- key exchange ---------------------------------------------------------------------------
+    def exchange_keys(self, sequences):
+        """sequences: list over sequences of {frame index: (positions, values)} for the frames this rank owns.
+        Returns, per sequence, the list of key tensors of ALL frames (frame order)."""
+        per_seq = []
+        for frames in sequences:
+            mine = []
+            for f in self.plan.frames:
+                pos, val = frames[f]
+                self.scratch.distribute(pos, val, reset_hashmap=True, subtract_mean=False)
+                mine.append(self.scratch.keys())
+            gathered = []     # frame-major
+            for j in range(len(self.plan.frames)):
+                k = mine[j].cpu() if self.via_host else mine[j]
+                gathered.append(all_gather_rows(k, group=self.group))
+            allk = [None] * self.plan.nr_frames
+            per = len(self.plan.frames)
+            for slot in range(self.plan.group_size):
+                for j in range(per):
+                    allk[slot * per + j] = gathered[j][slot]
+            per_seq.append(allk)
+        return per_seq
+
+    # ---- one sequence ---------------------------------------------------------------------------
+    def run_sequence(self, frames, all_keys):
+        """frames: {frame index: (positions, values)} of the frames this rank owns.  Returns the model output
+        of the last owned frame (logits on the rank that owns the final frame)."""
+        model, lat = self.model, self.lattice
+        model.reset_sequence()
+        lat.clear()
+        first = self.plan.frames[0]
+        for f in range(first):
+            k = all_keys[f]
+            if k.shape[0]:
+                lat.insert_keys(k.to("cuda") if k.device.type != "cuda" else k)
+        out = None
+        for j, f in enumerate(self.plan.frames):
+            pos, val = frames[f]
+            if f > 0:
+                model.first_sequence = False          # the lattice already holds the earlier frames (models.py:287-289)
+            self._recv_now = (j == 0 and f > 0)
+            self._send_now = (j == len(self.plan.frames) - 1 and f < self.plan.nr_frames - 1)
+            out = model(lat, pos, val, f != self.plan.nr_frames - 1, False)
+            self._recv_now = self._send_now = False
+        return out
