@@ -65,6 +65,12 @@ int tln_pointnet_pool(tln_lattice_t* l, const float* d_distributed, int64_t rows
                       int nr_layers, const float* const* d_w, const float* const* d_b,
                       const int* dims /* [nr_layers+1] */, int min_points, float* d_out, void* stream);
 
+/* same, and d_argrow [V, cout_last] int32 = the row whose MLP output is the pooled value (-1: empty / masked
+ * vertex) — what the backward pass of the pool needs */
+int tln_pointnet_pool_ex(tln_lattice_t* l, const float* d_distributed, int64_t rows, int dist_cols,
+                         int nr_layers, const float* const* d_w, const float* const* d_b,
+                         const int* dims, int min_points, float* d_out, int32_t* d_argrow, void* stream);
+
 /* ---- structure: neighbour tables, coarse level ---------------------------------------- */
 /* [V,9] table of the level itself (centre last = own index); cached until the level grows.
  * Replaces the hashing inside Im2RowLattice / Im2RowIndicesLattice (lm:301, 304). */

@@ -37,6 +37,7 @@ _PROTOS = {
     "tln_distribute": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp]),
     "tln_build_csr": (_i, [_vp, _vp, _i64, _vp]),
     "tln_pointnet_pool": (_i, [_vp, _vp, _i64, _i, _i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i), _i, _vp, _vp]),
+    "tln_pointnet_pool_ex": (_i, [_vp, _vp, _i64, _i, _i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i), _i, _vp, _vp, _vp]),
     "tln_neighbour_table": (_i, [_vp, C.POINTER(_vp), _vp]),
     "tln_coarsen": (_i, [_vp, C.POINTER(_vp), _vp]),
     "tln_coarse_to_fine_table": (_i, [_vp, C.POINTER(_vp), _vp]),

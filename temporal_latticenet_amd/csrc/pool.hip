@@ -114,7 +114,8 @@ __global__ void __launch_bounds__(256) k_pool_chunks(const float* __restrict__ d
 __global__ void __launch_bounds__(256) k_pool_finalize(const unsigned long long* __restrict__ packed,
                                                        const int32_t* __restrict__ seg_start, int nv, int cout,
                                                        const float* __restrict__ dist, int cols, int64_t rows,
-                                                       int min_points, float* __restrict__ out) {
+                                                       int min_points, float* __restrict__ out,
+                                                       int32_t* __restrict__ argrow) {
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t v = gid / cout;
   const int c = (int)(gid - v * cout);
@@ -128,6 +129,8 @@ __global__ void __launch_bounds__(256) k_pool_finalize(const unsigned long long*
     val = tln_ord2f((uint32_t)(p >> 32));
     arg = (int64_t)(0xFFFFFFFFu - (uint32_t)(p & 0xFFFFFFFFull));
   }
+  // row whose MLP output IS the pooled value (for the backward pass): -1 when the segment is empty or masked
+  if (argrow) argrow[gid] = (p != 0ull && count >= min_points) ? (int32_t)arg : -1;
   if (arg > (int64_t)nv) arg = 0;  // lm:514 compares row ids against the number of vertices
   if (arg >= rows) arg = 0;        // (the reference would raise an index error here: rows <= V)
   float bary = dist[arg * cols + (cols - 1)];
@@ -157,9 +160,9 @@ static int launch_pool(tln_lattice* l, const float* d_dist, int64_t rows, int co
   return TLN_OK;
 }
 
-extern "C" int tln_pointnet_pool(tln_lattice_t* l, const float* d_distributed, int64_t rows, int dist_cols,
-                                 int nr_layers, const float* const* d_w, const float* const* d_b, const int* dims,
-                                 int min_points, float* d_out, void* stream_) {
+extern "C" int tln_pointnet_pool_ex(tln_lattice_t* l, const float* d_distributed, int64_t rows, int dist_cols,
+                                    int nr_layers, const float* const* d_w, const float* const* d_b, const int* dims,
+                                    int min_points, float* d_out, int32_t* d_argrow, void* stream_) {
   TLN_REQUIRE(l && d_distributed && d_out && dims, "null argument");
   TLN_REQUIRE(tln_lat_csr_rows(l) == rows, "pool needs the CSR of a distribute/build_csr call over the same %lld rows",
               (long long)rows);
@@ -187,9 +190,16 @@ extern "C" int tln_pointnet_pool(tln_lattice_t* l, const float* d_distributed, i
   if (rc) return rc;
   const int64_t total = (int64_t)nv * cout;
   hipLaunchKernelGGL(k_pool_finalize, dim3((unsigned)tln_cdiv(total, 256)), dim3(256), 0, s, packed,
-                     tln_lat_seg_start(l), nv, cout, d_distributed, dist_cols, rows, min_points, d_out);
+                     tln_lat_seg_start(l), nv, cout, d_distributed, dist_cols, rows, min_points, d_out, d_argrow);
   TLN_LAUNCH_CHECK();
   return TLN_OK;
+}
+
+extern "C" int tln_pointnet_pool(tln_lattice_t* l, const float* d_distributed, int64_t rows, int dist_cols,
+                                 int nr_layers, const float* const* d_w, const float* const* d_b, const int* dims,
+                                 int min_points, float* d_out, void* stream_) {
+  return tln_pointnet_pool_ex(l, d_distributed, rows, dist_cols, nr_layers, d_w, d_b, dims, min_points, d_out, nullptr,
+                              stream_);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -117,10 +117,12 @@ class Lattice:
     def clear(self):
         _lib.check(_lib.lib().tln_lattice_clear(self._h, stream_ptr()), "tln_lattice_clear")
         self._csr_key = None
+        self.__dict__.pop("_tables", None)
         c = self._coarse
         while c is not None:
             c._csr_key = None
             c._values = None
+            c.__dict__.pop("_tables", None)
             c = c._coarse
 
     # ---- structure ------------------------------------------------------------------------
@@ -160,14 +162,31 @@ class Lattice:
             return torch.empty((0, 9), dtype=torch.int32, device="cuda")
         return torch.as_tensor(_DevView(ptr.value, (rows, 9), "<i4"), device="cuda").clone()
 
+    def _cached_table(self, name, key, make):
+        """torch copies of the native tables, kept while the levels do not grow (used by the backward passes)"""
+        cache = self.__dict__.setdefault("_tables", {})
+        hit = cache.get(name)
+        if hit is None or hit[0] != key:
+            hit = (key, make())
+            cache[name] = hit
+        return hit[1]
+
     def neighbour_table(self):
-        return self._table_tensor(self.neighbour_table_ptr(), self.nr_lattice_vertices())
+        v = self.nr_lattice_vertices()
+        return self._cached_table("nbr", v, lambda: self._table_tensor(self.neighbour_table_ptr(), v))
 
     def coarse_to_fine_table(self):
-        return self._table_tensor(self.coarse_to_fine_table_ptr(), self.nr_lattice_vertices())
+        v = self.nr_lattice_vertices()
+        vf = self._parent_vertices()
+        return self._cached_table("c2f", (v, vf), lambda: self._table_tensor(self.coarse_to_fine_table_ptr(), v))
 
     def fine_to_coarse_table(self, nr_fine):
-        return self._table_tensor(self.fine_to_coarse_table_ptr(), nr_fine)
+        v = self.nr_lattice_vertices()
+        return self._cached_table("f2c", (v, nr_fine),
+                                  lambda: self._table_tensor(self.fine_to_coarse_table_ptr(), nr_fine))
+
+    def _parent_vertices(self):
+        return self._parent.nr_lattice_vertices() if getattr(self, "_parent", None) is not None else -1
 
     def coarsen(self):
         """The persistent coarse level, extended by the vertices added since the last call."""
@@ -176,6 +195,7 @@ class Lattice:
         if self._coarse is None:
             self._coarse = Lattice(p, [2 * s for s in self._sigmas], self._capacity,
                                    self._root if self._root is not None else self, self.name + "_c")
+            self._coarse._parent = self
         return self._coarse
 
     # ---- K1 -----------------------------------------------------------------------------

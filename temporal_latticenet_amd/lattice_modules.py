@@ -11,6 +11,7 @@ import math
 
 import torch
 
+from . import autograd as AG
 from . import ops
 from .lattice import Lattice
 
@@ -86,12 +87,20 @@ class GroupNormLatticeModule(torch.nn.Module):
     def _make(self, c):
         self.norm = torch.nn.GroupNorm(gn_groups(c), c, affine=self.affine).to("cuda")
 
-    def stats(self, lv):
+    def ensure(self, lv):
         if self.norm is None:
             self._make(lv.shape[1])
+        return self.norm
+
+    def stats(self, lv):
+        self.ensure(lv)
         return ops.groupnorm_stats(lv, self.norm.num_groups, self.norm.weight, self.norm.bias, self.norm.eps)
 
     def forward(self, lv, ls, relu=False):
+        if AG.grad_mode():                       # training path: torch's differentiable GroupNorm
+            out = AG.group_norm_relu(lv, self.ensure(lv), relu)
+            ls.set_values(out)
+            return out, ls
         scale, shift = self.stats(lv)
         out = ops.affine_act(lv, scale, shift, relu)
         ls.set_values(out)
@@ -127,6 +136,11 @@ class Conv1x1(torch.nn.Module):
     def forward(self, lv, ls, prologue=None, residual=None):
         if self.linear is None:
             self._make(lv.shape[1])
+        if AG.grad_mode():                       # training path (the caller has applied GN/ReLU already)
+            assert prologue is None
+            out = AG.gather_gemm(lv.shape[0], lv, None, self.linear.weight, self.linear.bias, residual, w_is_nk=True)
+            ls.set_values(out)
+            return out, ls
         scale, shift, relu = prologue if prologue is not None else (None, None, False)
         src = ops.gemm_src(lv, scale=scale, shift=shift, relu=relu)
         out = ops.gather_gemm(lv.shape[0], self.linear.weight, src, w_is_nk=True, bias=self.linear.bias,
@@ -152,9 +166,12 @@ class _TapConv(torch.nn.Module):
             bound = 1.0 / math.sqrt(self.nr_filters)
             self.bias = torch.nn.Parameter(torch.empty(self.nr_filters, device="cuda").uniform_(-bound, bound))
 
-    def _product(self, rows, lv, table_ptr, prologue, residual):
+    def _product(self, rows, lv, table_ptr, prologue, residual, table_tensor=None):
         if self.weight is None:
             self._make(lv.shape[1])
+        if AG.grad_mode():                       # training path: autograd wrapper around the same kernel
+            assert prologue is None
+            return AG.gather_gemm(rows, lv, table_tensor(), self.weight, self.bias, residual)
         scale, shift, relu = prologue if prologue is not None else (None, None, False)
         src = ops.gemm_src(lv, table_ptr, 9, scale=scale, shift=shift, relu=relu)
         # stats=True: the product also emits the GroupNorm partial sums of its output for whatever Gn comes next
@@ -169,7 +186,8 @@ class ConvLatticeModule(_TapConv):
         assert neighbourhood_size == 1 and dilation == 1, "only the one-hop, dilation-1 filter is supported"
 
     def forward(self, lv, ls, prologue=None, residual=None):
-        out = self._product(ls.nr_lattice_vertices(), lv, ls.neighbour_table_ptr(), prologue, residual)
+        out = self._product(ls.nr_lattice_vertices(), lv, ls.neighbour_table_ptr(), prologue, residual,
+                            ls.neighbour_table)
         ls.set_values(out)
         return out, ls
 
@@ -180,7 +198,8 @@ class CoarsenLatticeModule(_TapConv):
 
     def forward(self, lv, ls, prologue=None):
         coarse = ls.coarsen()
-        out = self._product(coarse.nr_lattice_vertices(), lv, coarse.coarse_to_fine_table_ptr(), prologue, None)
+        out = self._product(coarse.nr_lattice_vertices(), lv, coarse.coarse_to_fine_table_ptr(), prologue, None,
+                            coarse.coarse_to_fine_table)
         coarse.set_values(out)
         return out, coarse
 
@@ -190,8 +209,9 @@ class FinefyLatticeModule(_TapConv):
         super().__init__(nr_filters, bias)
 
     def forward(self, lv_coarse, ls_coarse, ls_fine, prologue=None):
-        out = self._product(ls_fine.nr_lattice_vertices(), lv_coarse, ls_coarse.fine_to_coarse_table_ptr(), prologue,
-                            None)
+        nf = ls_fine.nr_lattice_vertices()
+        out = self._product(nf, lv_coarse, ls_coarse.fine_to_coarse_table_ptr(), prologue, None,
+                            lambda: ls_coarse.fine_to_coarse_table(nf))
         ls_fine.set_values(out)
         return out, ls_fine
 
@@ -220,6 +240,8 @@ class GnRelu1x1(torch.nn.Module):
         self.linear = Conv1x1(out_channels, bias)
 
     def forward(self, lv, ls, residual=None):
+        if AG.grad_mode():
+            return self.linear(AG.group_norm_relu(lv, self.norm.ensure(lv)), ls, None, residual)
         scale, shift = self.norm.stats(lv)
         return self.linear(lv, ls, (scale, shift, True), residual)
 
@@ -236,6 +258,8 @@ class GnReluConv(torch.nn.Module):
             lv, ls = self.norm(lv, ls, relu=True)
             lv, ls = self.drop(lv, ls)
             return self.conv(lv, ls, None, residual)
+        if AG.grad_mode():
+            return self.conv(AG.group_norm_relu(lv, self.norm.ensure(lv)), ls, None, residual)
         scale, shift = self.norm.stats(lv)
         return self.conv(lv, ls, (scale, shift, True), residual)
 
@@ -249,6 +273,8 @@ class GnReluCoarsen(torch.nn.Module):
         self.coarse = CoarsenLatticeModule(nr_filters, bias=False)
 
     def forward(self, lv, ls):
+        if AG.grad_mode():
+            return self.coarse(AG.group_norm_relu(lv, self.norm.ensure(lv)), ls, None)
         scale, shift = self.norm.stats(lv)
         return self.coarse(lv, ls, (scale, shift, True))
 
@@ -262,6 +288,8 @@ class GnReluFinefy(torch.nn.Module):
         self.fine = FinefyLatticeModule(nr_filters, bias=False)
 
     def forward(self, lv_coarse, ls_coarse, ls_fine):
+        if AG.grad_mode():
+            return self.fine(AG.group_norm_relu(lv_coarse, self.norm.ensure(lv_coarse)), ls_coarse, ls_fine, None)
         scale, shift = self.norm.stats(lv_coarse)
         return self.fine(lv_coarse, ls_coarse, ls_fine, (scale, shift, True))
 
@@ -364,6 +392,19 @@ class SliceFastCUDALatticeModule(torch.nn.Module):
         ls.set_values(lv)
         if self.dropout is not None:
             lv, ls = self.dropout(lv, ls)
+        if AG.grad_mode():                       # training path: same arithmetic in differentiable torch form
+            delta = None
+            if self.experiment != "slice_no_deform":
+                b = lv
+                for m in self.stepdown:
+                    b, _ = m(b, ls)
+                b, _ = self.bottleneck(b, ls)
+                g = AG.slice_gather(b, indices, weights)
+                hdn = torch.relu(torch.nn.functional.linear(g, self.linear_pre_deltaW.weight))
+                delta = torch.nn.functional.linear(hdn, self.linear_deltaW.weight, self.linear_deltaW.bias)
+            feat = AG.slice_blend(lv, indices, weights, delta)
+            ls.set_values(lv)
+            return torch.nn.functional.linear(feat, self.linear_clasify.weight, self.linear_clasify.bias)
         delta = None
         if self.experiment != "slice_no_deform":
             b = lv

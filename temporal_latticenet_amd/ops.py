@@ -133,8 +133,9 @@ def affine_act(x, scale, shift, relu=False):
     return out
 
 
-def pointnet_pool(lattice: Lattice, distributed, indices, weights, biases, min_points=4):
-    """Fused per-row MLP + segment max (+argmax barycentric) of PointNetSeqModule (lm:448-530)."""
+def pointnet_pool(lattice: Lattice, distributed, indices, weights, biases, min_points=4, want_argrow=False):
+    """Fused per-row MLP + segment max (+argmax barycentric) of PointNetSeqModule (lm:448-530).
+    want_argrow=True also returns [V, cout] int32: the row that produced each pooled value (-1 = empty/masked)."""
     distributed = _f32c(distributed)
     lattice.ensure_csr(indices)
     rows, cols = distributed.shape
@@ -147,11 +148,12 @@ def pointnet_pool(lattice: Lattice, distributed, indices, weights, biases, min_p
     warr = (C.c_void_p * max(nl, 1))(*[w.data_ptr() for w in ws])
     barr = (C.c_void_p * max(nl, 1))(*[b.data_ptr() for b in bs])
     darr = (C.c_int * (nl + 1))(*dims)
+    argrow = torch.empty((V, dims[-1]), dtype=torch.int32, device="cuda") if want_argrow else None
     with _timed("pointnet_pool", rows=rows, V=V, cout=dims[-1]):
-        rc = _lib.lib().tln_pointnet_pool(lattice._h, _ptr(distributed), rows, cols, nl, warr, barr, darr,
-                                          int(min_points), _ptr(out), stream_ptr())
+        rc = _lib.lib().tln_pointnet_pool_ex(lattice._h, _ptr(distributed), rows, cols, nl, warr, barr, darr,
+                                             int(min_points), _ptr(out), _ptr(argrow), stream_ptr())
     _lib.check(rc, "tln_pointnet_pool")
-    return out
+    return (out, argrow) if want_argrow else out
 
 
 def gru_cell(x, h, w_ih, w_hh, b_ih, b_hh):

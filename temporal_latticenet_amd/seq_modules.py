@@ -9,6 +9,7 @@ import math
 
 import torch
 
+from . import autograd as AG
 from . import ops
 from .lattice_modules import (Conv1x1, ConvLatticeModule, Gn, GnRelu1x1, Im2RowIndicesLattice, Im2RowLattice)
 
@@ -20,6 +21,9 @@ __all__ = ["LSTMModule", "GRUModule", "CrossframeGlobalAttentionModule", "Tempor
 def _linear(mod, x, src_rows=None, pad_value=0.0, relu=False, rows=None):
     """torch.nn.Linear `mod` applied per vertex on the matrix cores; rows beyond src_rows read as pad_value"""
     rows = x.shape[0] if rows is None else rows
+    if AG.grad_mode():                           # training path
+        y = torch.nn.functional.linear(AG.pad_rows(x, rows, pad_value), mod.weight, mod.bias)
+        return torch.relu(y) if relu else y
     return ops.gather_gemm(rows, mod.weight, ops.gemm_src(x, src_rows=src_rows, pad_value=pad_value), w_is_nk=True,
                            bias=mod.bias, relu=relu)
 
@@ -43,6 +47,15 @@ class LSTMModule(torch.nn.Module):
             self.h_lv = _linear(self.hidden_linear, self.h_lv)                       # lm:32
             V, C = lv.shape
             Vh = self.h_lv.shape[0]
+            if AG.grad_mode():
+                Fn = torch.nn.functional
+                gates = Fn.linear(lv, self.lstm.weight_ih, self.lstm.bias_ih) + \
+                    Fn.linear(AG.pad_rows(self.h_lv, V), self.lstm.weight_hh, self.lstm.bias_hh)
+                i, f, g, o = gates.chunk(4, 1)
+                lv = torch.sigmoid(o) * torch.tanh(torch.sigmoid(i) * torch.tanh(g))
+                self.h_lv = lv.clone()
+                ls.set_values(lv)
+                return lv, ls
             # gates = lv W_ih^T + b_ih + pad(h) W_hh^T + b_hh  (cell state is zero, lm:36)
             gi = ops.gather_gemm(V, self.lstm.weight_ih, ops.gemm_src(lv), w_is_nk=True, bias=self.lstm.bias_ih)
             gates = ops.gather_gemm(V, self.lstm.weight_hh, ops.gemm_src(self.h_lv, src_rows=Vh, pad_value=0.0),
@@ -74,8 +87,11 @@ class GRUModule(torch.nn.Module):
         else:
             self.h_lv = _linear(self.hidden_linear, self.h_lv)                       # lm:58
             # zero padding of h to lv.shape[0] rows (lm:59-60) happens inside the kernel
-            new_lv = ops.gru_cell(lv, self.h_lv, self.GRU.weight_ih, self.GRU.weight_hh, self.GRU.bias_ih,
-                                  self.GRU.bias_hh)                                  # lm:62
+            if AG.grad_mode():
+                new_lv = AG.gru_cell(lv, AG.pad_rows(self.h_lv, lv.shape[0]), self.GRU)
+            else:
+                new_lv = ops.gru_cell(lv, self.h_lv, self.GRU.weight_ih, self.GRU.weight_hh, self.GRU.bias_ih,
+                                      self.GRU.bias_hh)                              # lm:62
             self.h_lv = new_lv.clone()
             ls.set_values(new_lv)
         return new_lv, ls
@@ -110,8 +126,11 @@ class CrossframeGlobalAttentionModule(torch.nn.Module):
             h_lv, _ = self.conv(h_lv, ls)                                            # lm:102
             h_lv = h_lv * (1.0 / (h_lv.shape[0] + h_lv.shape[1]))                    # lm:104
             h_lv = self.sigmoid(h_lv)                                                # lm:106
-            if V > Vh:
-                h_lv[Vh:] = 1.0                                                      # lm:109-110
+            if V > Vh:                                                               # lm:109-110
+                if AG.grad_mode():
+                    h_lv = torch.cat([h_lv[:Vh], torch.ones_like(h_lv[Vh:])], 0)
+                else:
+                    h_lv[Vh:] = 1.0
             lv = h_lv * lv                                                           # lm:112
             self.h_lv = lv.clone()
             ls.set_values(lv)
@@ -166,7 +185,11 @@ class TemporalLinearModule(torch.nn.Module):
             self.h_lv = _linear(self.hidden_linear, self.h_lv)                       # lm:172
             V, Vh = lv.shape[0], self.h_lv.shape[0]
             # cat([pad(h), lv]) @ W^T + b, ReLU (lm:174-179); alpha = 0 removes the h term of lm:181
-            lv = ops.gather_gemm(V, self.linear.weight, ops.gemm_src(self.h_lv, src_rows=Vh, pad_value=0.0),
+            if AG.grad_mode():
+                lv = torch.relu(torch.nn.functional.linear(torch.cat([AG.pad_rows(self.h_lv, V), lv], 1),
+                                                           self.linear.weight, self.linear.bias))
+            else:
+              lv = ops.gather_gemm(V, self.linear.weight, ops.gemm_src(self.h_lv, src_rows=Vh, pad_value=0.0),
                                  ops.gemm_src(lv), w_is_nk=True, bias=self.linear.bias, relu=True)
             self.h_lv = lv.clone()
         ls.set_values(lv)
@@ -222,6 +245,25 @@ class CustomKernelConvLatticeIm2RowModule(torch.nn.Module):
                 self.bias = torch.nn.Parameter(torch.empty(self.nr_filters).to("cuda"))
             with torch.no_grad():
                 self.reset_parameters(filter_extent)
+        if AG.grad_mode():                       # training path: lm:298-334 in differentiable torch form
+            V, Cn = lattice_values.shape
+            table = lattice_structure.neighbour_table()
+            hp = AG.pad_rows(hidden_state, V, -999999.0)
+            nbrs = AG.im2row(hp, table).reshape(V, 9, Cn)
+            valid = (table != -1).float()
+            d = torch.cdist(nbrs, lattice_values.unsqueeze(1), p=2.0).squeeze(2) * valid
+            if not self.use_center:
+                d = torch.cat([d[:, :-1], d[:, -1:] * 0.0], 1)
+            d = d * 1 / (torch.sum(d, dim=1, keepdim=True).detach())
+            alpha_t = torch.ones_like(d) * self.alpha
+            weights = (alpha_t - torch.min(d, alpha_t)) * self.beta * valid
+            if not self.use_center:
+                weights = torch.cat([weights[:, :-1], weights[:, -1:] * 0.0], 1)
+            out = (nbrs * weights.unsqueeze(2)).sum(1)
+            if self.use_bias:
+                out = out + self.bias
+            lattice_structure.set_values(lattice_values)
+            return out, weights, table
         # `hidden_state` is the -999999-padded h^(t-1) (lm:215); the kernel applies the same padding to rows
         # beyond hidden_state's own length, so an unpadded tensor is accepted as well.
         out, weights, nbr_idx = ops.aflow(lattice_values, hidden_state, lattice_structure.neighbour_table_ptr(),
@@ -261,7 +303,11 @@ class CrossframeLocalInterpolationModule(torch.nn.Module):
             self.h_lv_vis, self.weights_vis, self.lattice_neighbors_previous = self.h_lv, weights, nbr_prev
             V = lv.shape[0]
             # relu(cat([aflow, lv]) @ W^T + b) (lm:223-227); alpha = 0 (lm:212, 229)
-            lv = ops.gather_gemm(V, self.linear.weight, ops.gemm_src(aflow_vec), ops.gemm_src(lv), w_is_nk=True,
+            if AG.grad_mode():
+                lv = torch.relu(torch.nn.functional.linear(torch.cat([aflow_vec, lv], 1), self.linear.weight,
+                                                           self.linear.bias))
+            else:
+              lv = ops.gather_gemm(V, self.linear.weight, ops.gemm_src(aflow_vec), ops.gemm_src(lv), w_is_nk=True,
                                  bias=self.linear.bias, relu=True)
             self.h_lv = lv.clone()
         ls.set_values(lv)
@@ -366,9 +412,10 @@ class PointNetSeqModule(torch.nn.Module):
             # scatter_max + argmax, argmax clamp, points-per-vertex, barycentric-of-argmax, <4 mask
             no_elevation = self.experiment in ("pointnet_no_elevate", "pointnet_no_elevate_no_local_mean", "splat")
             layers = [] if no_elevation else list(self.layers)
-            distributed_reduced = ops.pointnet_pool(
+            pool = AG.pointnet_pool if AG.grad_mode() else ops.pointnet_pool
+            distributed_reduced = pool(
                 lattice_py, distributed, indices, [l.weight for l in layers], [l.bias for l in layers],
-                min_points=0 if self.is_early_maxpool_fusion else 4)
+                0 if self.is_early_maxpool_fusion else 4)
         lattice_py.set_values(distributed_reduced)                                   # lm:532
 
         if self.sequence_learning and self.rnn_modules[0] == "maxpool":              # lm:555-563
@@ -379,8 +426,13 @@ class PointNetSeqModule(torch.nn.Module):
         elif self.sequence_learning and self.fusion_module is not None:              # lm:564-565
             distributed_reduced, lattice_py = self.fusion_module(distributed_reduced, lattice_py)
 
-        if distributed_reduced.shape[0] > 0:
-            distributed_reduced[0, :] = 0                                            # lm:569-570 (fresh tensor: in place)
+        if distributed_reduced.shape[0] > 0:                                         # lm:569-570
+            if AG.grad_mode():
+                keep = torch.ones((distributed_reduced.shape[0], 1), device=distributed_reduced.device)
+                keep[0] = 0
+                distributed_reduced = distributed_reduced * keep
+            else:
+                distributed_reduced[0, :] = 0                                        # fresh tensor: in place
         lattice_py.set_values(distributed_reduced)
         distributed_reduced, lattice_py = self.last_conv(distributed_reduced, lattice_py)   # lm:573
         lattice_py.set_values(distributed_reduced)

@@ -79,3 +79,69 @@ def test_state_dict_roundtrip_and_lazy_parameters(gpu):
     model2.load_state_dict(sd)
     outs2 = _run(model2, contents, seq, gpu)
     assert torch.equal(outs[-1], outs2[-1])        # same weights => bitwise identical (deterministic kernels)
+
+
+CFG = """
+train: { dataset_name: "semantickitti" }
+model: {
+    positions_mode: "xyz"
+    values_mode: "reflectance"
+    pointnet_layers: [16,32,64]
+    pointnet_start_nr_channels: 64
+    nr_downsamples: 2
+    nr_blocks_down_stage: [2,2,2]
+    nr_blocks_bottleneck: 3
+    nr_blocks_up_stage: [1,2,2]
+    nr_levels_down_with_normal_resnet: 3
+    nr_levels_up_with_normal_resnet: 3
+    compression_factor: 1.0
+    dropout_last_layer: 0.0
+    sequence_learning: true
+    rnn_modules: ["gru", "gru", "aflow", "gru"] // the pretrained configuration
+    experiment: "none"
+}
+lattice_gpu: {
+    hash_table_capacity: 100000 //good for semantic kitti
+    nr_sigmas: 1
+    sigma_0: "0.6 3"
+}
+loader_semantic_kitti: { frames_per_seq: 2, accumulate_clouds: false, include_moving_classes: true }
+"""
+
+
+def test_reference_import_names_drive_the_model(gpu, tmp_path):
+    """the reference's own import lines (train_ln.py:15-29, models.py:6-12) resolve to this implementation and the
+    per-frame calling convention of train_ln.py:160-239 works: Lattice.create(cfg), ModelParams.create(cfg),
+    model(lattice, positions, values, early_return, with_gradient), reset_sequence(), a fresh Lattice per sequence"""
+    import temporal_latticenet_amd
+    temporal_latticenet_amd.install_compat()
+    cfg = tmp_path / "lnn.cfg"
+    cfg.write_text(CFG)
+    ns = {}
+    exec("from easypbr import *\nfrom latticenet import ModelParams, Lattice, HashTable\n"
+         "from latticenet_py.lattice.lovasz_loss import LovaszSoftmax\nfrom latticenet_py.lattice.lattice_funcs import *\n"
+         "from latticenet_py.lattice.lattice_modules import *\nimport torch_scatter\nimport hjson\n"
+         "from termcolor import colored\nfrom seq_lattice.models import *\n", ns)
+    from temporal_latticenet_amd.cfg import cfgParser
+    config_parser = cfgParser(str(cfg))
+    assert ns["hjson"].loads(CFG)["lattice_gpu"]["sigma_0"] == "0.6 3"
+    model_params = ns["ModelParams"].create(str(cfg))
+    lattice = ns["Lattice"].create(str(cfg), "lattice")
+    model = ns["LNN_SEQ"](26, model_params, config_parser).to("cuda")
+    loss_fn = ns["LovaszSoftmax"](ignore_index=0)
+    seq = make_sequence(6000, 2, seed=8)
+    target = torch.randint(0, 26, (6000,)).to(gpu)
+    for epoch in range(2):
+        for i, (pos, val) in enumerate(seq):
+            with torch.set_grad_enabled(False):
+                early = i != len(seq) - 1
+                pred, raw, lattice = model(lattice, torch.from_numpy(pos).to("cuda"), torch.from_numpy(val).to("cuda"),
+                                           early, with_gradient=False)
+        loss = 0.5 * loss_fn(pred, target) + 0.5 * torch.nn.NLLLoss(ignore_index=0)(pred, target)
+        assert torch.isfinite(loss)
+        assert lattice.nr_lattice_vertices() > 100
+        model.reset_sequence()
+        lattice = ns["Lattice"].create(str(cfg), "lattice")
+    assert pred.shape == (6000, 26)
+    mx, arg = ns["torch_scatter"].scatter_max(torch.rand(50, 3, device="cuda"), torch.randint(0, 7, (50,), device="cuda"), dim=0)
+    assert mx.shape == (7, 3)

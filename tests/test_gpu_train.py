@@ -1,0 +1,91 @@
+"""GPU: the training path.  loss.backward() through the HIP forward must give the same
+parameter gradients as PyTorch autograd through the CPU oracle, and an optimiser step must work the way
+train_ln.py:212-233 drives it (loss on the last frame only, AdamW)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import build_model, make_config, make_lattice, oracle_from_model, randomize_parameters
+from temporal_latticenet_amd.synthetic import make_sequence
+
+pytestmark = pytest.mark.gpu
+
+
+def _forward(model, contents, seq, gpu, grad):
+    lat = make_lattice(contents)
+    with torch.set_grad_enabled(grad):
+        for t, (pos, val) in enumerate(seq):
+            logsm, raw, lat = model(lat, torch.from_numpy(pos).to(gpu), torch.from_numpy(val).to(gpu),
+                                    t != len(seq) - 1, grad)
+    return logsm, raw
+
+
+@pytest.mark.parametrize("rnn", [("gru", "gru", "aflow", "gru"), ("linear", "none", "lstm", "maxpool")])
+def test_parameter_gradients_match_oracle_autograd(gpu, rnn):
+    contents = make_config(rnn_modules=rnn, frames=2, sigma=0.8)
+    seq = make_sequence(5000, 2, seed=61)
+    model = build_model(contents).train()
+    with torch.no_grad():
+        _forward(model, contents, seq, gpu, False)
+    model.reset_sequence()
+    randomize_parameters(model, seed=4)
+    target = torch.randint(0, 26, (5000,), generator=torch.Generator().manual_seed(0))
+
+    # training-path forward == fused inference forward
+    logsm, raw = _forward(model, contents, seq, gpu, True)
+    model.reset_sequence()
+    with torch.no_grad():
+        _, raw_inf = _forward(model, contents, seq, gpu, False)
+    model.reset_sequence()
+    np.testing.assert_allclose(raw.detach().cpu().numpy(), raw_inf.cpu().numpy(), rtol=1e-4, atol=1e-4)
+
+    loss = torch.nn.functional.nll_loss(logsm, target.to(gpu))
+    loss.backward()
+    got = {k: p.grad.detach().cpu() for k, p in model.named_parameters() if p.grad is not None}
+
+    oracle = oracle_from_model(model, contents)
+    for v in oracle.sd.values():
+        if v.is_floating_point():
+            v.requires_grad_(True)
+    for t, (pos, val) in enumerate(seq):
+        sv = oracle.forward(pos, val, early_return=(t != len(seq) - 1))
+    oloss = torch.nn.functional.nll_loss(torch.log_softmax(sv, 1), target)
+    oloss.backward()
+    assert abs(float(loss.detach()) - float(oloss.detach())) < 1e-4
+    checked = 0
+    for k, g in got.items():
+        og = oracle.sd[k].grad
+        if og is None:
+            assert float(g.abs().max()) == 0.0, k       # e.g. the never-used AFLOW.weight (lm:291)
+            continue
+        scale = max(float(og.abs().max()), 1e-6)
+        err_max = float((g - og).abs().max()) / scale
+        err_l2 = float((g - og).norm()) / max(float(og.norm()), 1e-9)
+        assert err_l2 < 5e-3 and err_max < 3e-2, "%s: gradient error l2 %.3e max %.3e" % (k, err_l2, err_max)
+        checked += 1
+    assert checked > 40
+    # every parameter the oracle gives a gradient to also got one on the GPU
+    for k, v in oracle.sd.items():
+        if v.is_floating_point() and v.grad is not None and float(v.grad.abs().max()) > 0:
+            assert k in got, k
+
+
+def test_training_step_reduces_the_loss(gpu):
+    contents = make_config(frames=2, sigma=0.8)
+    seq = make_sequence(4000, 2, seed=62)
+    model = build_model(contents).train()
+    with torch.no_grad():
+        _forward(model, contents, seq, gpu, False)
+    model.reset_sequence()
+    target = (torch.from_numpy(seq[-1][0][:, 0]) > 0).long().to(gpu) + 1      # a learnable 2-class target
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-3, amsgrad=True)   # train_ln.py:181
+    losses = []
+    for it in range(6):
+        logsm, _ = _forward(model, contents, seq, gpu, True)
+        loss = torch.nn.functional.nll_loss(logsm, target)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        model.reset_sequence()
+        losses.append(float(loss))
+    assert losses[-1] < losses[0], losses
