@@ -131,6 +131,23 @@ int tln_groupnorm_stats(const float* d_x, int64_t V, int C, int groups, const fl
  * d_partials = [ceil(V/32)][C] (sum, sumsq) doubles */
 int tln_groupnorm_from_partials(const void* d_partials, int64_t V, int C, int groups, const float* d_gamma,
                                 const float* d_beta, float eps, float* d_scale, float* d_shift, void* stream);
+/* GroupNorm (+ReLU) folded into a gather-GEMM: statistics -> per-channel scale/shift -> tln_gather_gemm_ex in ONE
+ * host call (GnRelu1x1 / GnReluConv / GnReluCoarsen / GnReluFinefy of the reference's operator package) */
+typedef struct {
+  const void* d_partials;   /* [ceil(V/32)][C] (sum,sumsq) doubles from the producer's epilogue, or NULL      */
+  const float* d_x;         /* [V,C] the normalised tensor (read only when d_partials is NULL)                */
+  int64_t V;
+  int C, groups, relu;
+  const float* d_gamma;
+  const float* d_beta;
+  float eps;
+  float* d_scale_shift;     /* [2,C] out: scale then shift                                                    */
+  void* d_ws;               /* tln_groupnorm_ws_bytes(V,C) bytes, only when d_partials is NULL                */
+  int64_t ws_bytes;
+} tln_gn_desc;
+int tln_gn_gather_gemm(const tln_gn_desc* gn, int64_t M, int N, const tln_gemm_src* s0, const tln_gemm_src* s1,
+                       const float* d_w, int w_is_nk, const float* d_bias, const float* d_residual,
+                       int64_t ld_res, int relu, float* d_out, int64_t ld_out, void* d_stats, void* stream);
 int tln_affine_act(const float* d_x, int64_t V, int C, const float* d_scale, const float* d_shift,
                    int relu, float* d_out, void* stream);
 

@@ -21,6 +21,14 @@ class GemmSrc(C.Structure):
     ]
 
 
+class GnDesc(C.Structure):
+    _fields_ = [
+        ("d_partials", C.c_void_p), ("d_x", C.c_void_p), ("V", C.c_int64), ("C", C.c_int), ("groups", C.c_int),
+        ("relu", C.c_int), ("d_gamma", C.c_void_p), ("d_beta", C.c_void_p), ("eps", C.c_float),
+        ("d_scale_shift", C.c_void_p), ("d_ws", C.c_void_p), ("ws_bytes", C.c_int64),
+    ]
+
+
 _vp, _i64, _i, _f = C.c_void_p, C.c_int64, C.c_int, C.c_float
 _PROTOS = {
     "tln_last_error": (C.c_char_p, []),
@@ -47,6 +55,7 @@ _PROTOS = {
     "tln_gemm_force_groups": (None, [_i]),
     "tln_gemm_force_splits": (None, [_i, _i]),
     "tln_gather_gemm_ex": (_i, [_i64, _i, C.POINTER(GemmSrc), C.POINTER(GemmSrc), _vp, _i, _vp, _vp, _i64, _i, _vp, _i64, _vp, _vp]),
+    "tln_gn_gather_gemm": (_i, [C.POINTER(GnDesc), _i64, _i, C.POINTER(GemmSrc), C.POINTER(GemmSrc), _vp, _i, _vp, _vp, _i64, _i, _vp, _i64, _vp, _vp]),
     "tln_groupnorm_from_partials": (_i, [_vp, _i64, _i, _i, _vp, _vp, _f, _vp, _vp, _vp]),
     "tln_im2row": (_i, [_vp, _i64, _i, _vp, _i64, _vp, _vp]),
     "tln_groupnorm_ws_bytes": (_i64, [_i64, _i]),

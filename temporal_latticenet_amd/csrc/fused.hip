@@ -394,3 +394,32 @@ extern "C" int tln_scatter_add(const float* d_src, const int64_t* d_index, int64
   TLN_LAUNCH_CHECK();
   return TLN_OK;
 }
+
+// =======================================================================================
+// composite: GroupNorm statistics (from the producer's partial sums when they exist, else two passes over x)
+// followed by the gather-GEMM that applies them in its operand staging.  One call from the host instead of two or
+// three: on a lattice of a few thousand vertices the host-side launch path is the bottleneck, not the kernels.
+// =======================================================================================
+extern "C" int tln_gn_gather_gemm(const tln_gn_desc* gn, int64_t M, int N, const tln_gemm_src* s0,
+                                  const tln_gemm_src* s1, const float* d_w, int w_is_nk, const float* d_bias,
+                                  const float* d_residual, int64_t ld_res, int relu, float* d_out, int64_t ld_out,
+                                  void* d_stats, void* stream_) {
+  TLN_REQUIRE(gn && s0 && gn->d_scale_shift, "null argument");
+  float* scale = gn->d_scale_shift;
+  float* shift = gn->d_scale_shift + gn->C;
+  int rc;
+  if (gn->d_partials)
+    rc = tln_groupnorm_from_partials(gn->d_partials, gn->V, gn->C, gn->groups, gn->d_gamma, gn->d_beta, gn->eps, scale,
+                                     shift, stream_);
+  else
+    rc = tln_groupnorm_stats(gn->d_x, gn->V, gn->C, gn->groups, gn->d_gamma, gn->d_beta, gn->eps, scale, shift,
+                             gn->d_ws, gn->ws_bytes, stream_);
+  if (rc) return rc;
+  tln_gemm_src a = *s0;
+  TLN_REQUIRE(a.cin == gn->C, "GroupNorm width %d does not match the GEMM source width %d", gn->C, a.cin);
+  a.d_scale = scale;
+  a.d_shift = shift;
+  a.relu = gn->relu;
+  return tln_gather_gemm_ex(M, N, &a, s1, d_w, w_is_nk, d_bias, d_residual, ld_res, relu, d_out, ld_out, d_stats,
+                            stream_);
+}

@@ -141,10 +141,13 @@ class Conv1x1(torch.nn.Module):
             out = AG.gather_gemm(lv.shape[0], lv, None, self.linear.weight, self.linear.bias, residual, w_is_nk=True)
             ls.set_values(out)
             return out, ls
+        gn = None
+        if prologue is not None and prologue[0] == "gn":      # GroupNorm+ReLU of `lv` inside the same host call
+            gn, prologue = (lv, prologue[1].ensure(lv), True), None
         scale, shift, relu = prologue if prologue is not None else (None, None, False)
         src = ops.gemm_src(lv, scale=scale, shift=shift, relu=relu)
         out = ops.gather_gemm(lv.shape[0], self.linear.weight, src, w_is_nk=True, bias=self.linear.bias,
-                              residual=residual, stats=True)
+                              residual=residual, stats=True, gn=gn)
         ls.set_values(out)
         return out, ls
 
@@ -172,10 +175,13 @@ class _TapConv(torch.nn.Module):
         if AG.grad_mode():                       # training path: autograd wrapper around the same kernel
             assert prologue is None
             return AG.gather_gemm(rows, lv, table_tensor(), self.weight, self.bias, residual)
+        gn = None
+        if prologue is not None and prologue[0] == "gn":      # GroupNorm+ReLU of `lv` inside the same host call
+            gn, prologue = (lv, prologue[1].ensure(lv), True), None
         scale, shift, relu = prologue if prologue is not None else (None, None, False)
         src = ops.gemm_src(lv, table_ptr, 9, scale=scale, shift=shift, relu=relu)
         # stats=True: the product also emits the GroupNorm partial sums of its output for whatever Gn comes next
-        return ops.gather_gemm(rows, self.weight, src, bias=self.bias, residual=residual, stats=True)
+        return ops.gather_gemm(rows, self.weight, src, bias=self.bias, residual=residual, stats=True, gn=gn)
 
 
 class ConvLatticeModule(_TapConv):
@@ -242,8 +248,7 @@ class GnRelu1x1(torch.nn.Module):
     def forward(self, lv, ls, residual=None):
         if AG.grad_mode():
             return self.linear(AG.group_norm_relu(lv, self.norm.ensure(lv)), ls, None, residual)
-        scale, shift = self.norm.stats(lv)
-        return self.linear(lv, ls, (scale, shift, True), residual)
+        return self.linear(lv, ls, ("gn", self.norm), residual)
 
 
 class GnReluConv(torch.nn.Module):
@@ -260,8 +265,7 @@ class GnReluConv(torch.nn.Module):
             return self.conv(lv, ls, None, residual)
         if AG.grad_mode():
             return self.conv(AG.group_norm_relu(lv, self.norm.ensure(lv)), ls, None, residual)
-        scale, shift = self.norm.stats(lv)
-        return self.conv(lv, ls, (scale, shift, True), residual)
+        return self.conv(lv, ls, ("gn", self.norm), residual)
 
 
 class GnReluCoarsen(torch.nn.Module):
@@ -275,8 +279,7 @@ class GnReluCoarsen(torch.nn.Module):
     def forward(self, lv, ls):
         if AG.grad_mode():
             return self.coarse(AG.group_norm_relu(lv, self.norm.ensure(lv)), ls, None)
-        scale, shift = self.norm.stats(lv)
-        return self.coarse(lv, ls, (scale, shift, True))
+        return self.coarse(lv, ls, ("gn", self.norm))
 
 
 class GnReluFinefy(torch.nn.Module):
@@ -290,8 +293,7 @@ class GnReluFinefy(torch.nn.Module):
     def forward(self, lv_coarse, ls_coarse, ls_fine):
         if AG.grad_mode():
             return self.fine(AG.group_norm_relu(lv_coarse, self.norm.ensure(lv_coarse)), ls_coarse, ls_fine, None)
-        scale, shift = self.norm.stats(lv_coarse)
-        return self.fine(lv_coarse, ls_coarse, ls_fine, (scale, shift, True))
+        return self.fine(lv_coarse, ls_coarse, ls_fine, ("gn", self.norm))
 
 
 class ResnetBlock(torch.nn.Module):

@@ -45,9 +45,14 @@ class _timed:
         return False
 
 
+_F32 = torch.float32
+
+
 def _f32c(t):
     if t is None:
         return None
+    if t.dtype is _F32 and t.is_cuda and t.is_contiguous():     # the common case, no further work
+        return t
     if t.dtype != torch.float32 or not t.is_contiguous():
         t = t.float().contiguous()
     if not t.is_cuda:
@@ -73,10 +78,13 @@ def gemm_src(src, table_ptr=None, taps=1, src_rows=None, pad_value=0.0, scale=No
     return s, (src, scale, shift)
 
 
-def gather_gemm(M, weight, s0, s1=None, w_is_nk=False, bias=None, residual=None, relu=False, out=None, stats=False):
+def gather_gemm(M, weight, s0, s1=None, w_is_nk=False, bias=None, residual=None, relu=False, out=None, stats=False,
+                gn=None):
     """out[M,N] = epi( [gather(s0) | gather(s1)] @ W ).  weight: [K,N] (w_is_nk False) or [N,K].
     stats=True additionally produces the per-32-row (sum, sumsq) of every output column (GroupNorm statistics of the
-    next layer) and attaches them to the result as `out._tln_stats`."""
+    next layer) and attaches them to the result as `out._tln_stats`.
+    gn=(x, groupnorm_module, relu): GroupNorm(x) (+ReLU) is applied to source 0 inside the same host call; its
+    statistics come from x._tln_stats when the producer left them, else from two passes over x."""
     weight = _f32c(weight)
     N = weight.shape[0] if w_is_nk else weight.shape[1]
     K = weight.shape[1] if w_is_nk else weight.shape[0]
@@ -85,12 +93,37 @@ def gather_gemm(M, weight, s0, s1=None, w_is_nk=False, bias=None, residual=None,
         raise _lib.TlnError("gather_gemm: weight K=%d but sources give K=%d" % (K, k_expected))
     bias, residual = _f32c(bias), _f32c(residual)
     if out is None:
-        out = torch.empty((M, N), dtype=torch.float32, device="cuda")
+        out = torch.empty((M, N), dtype=torch.float32, device=weight.device)
     if residual is not None and tuple(residual.shape) != (M, N):
         raise _lib.TlnError("gather_gemm: residual shape %s != (%d,%d)" % (tuple(residual.shape), M, N))
     if bias is not None and bias.numel() != N:
         raise _lib.TlnError("gather_gemm: bias has %d entries, N=%d" % (bias.numel(), N))
-    st = torch.empty(((M + 31) // 32, N, 2), dtype=torch.float64, device="cuda") if (stats and M > 0) else None
+    st = torch.empty(((M + 31) // 32, N, 2), dtype=torch.float64, device=weight.device) if (stats and M > 0) else None
+    if gn is not None:
+        x, norm, gn_relu = gn
+        V, Cn = x.shape
+        d = _lib.GnDesc()
+        part = getattr(x, "_tln_stats", None)
+        keep = torch.empty((2, Cn), dtype=torch.float32, device=weight.device)
+        if part is not None and tuple(part.shape) == ((V + 31) // 32, Cn, 2):
+            d.d_partials = part.data_ptr()
+        else:
+            d.ws_bytes = int(_lib.lib().tln_groupnorm_ws_bytes(V, Cn))
+            ws = torch.empty((max(d.ws_bytes, 16) // 8,), dtype=torch.float64, device=weight.device)
+            d.d_ws, d.d_x = ws.data_ptr(), x.data_ptr()
+        d.V, d.C, d.groups, d.relu, d.eps = V, Cn, norm.num_groups, 1 if gn_relu else 0, float(norm.eps)
+        d.d_gamma, d.d_beta = norm.weight.data_ptr(), norm.bias.data_ptr()
+        d.d_scale_shift = keep.data_ptr()
+        with _timed("gather_gemm", M=M, N=N, K=K, taps=s0[0].taps, cin=s0[0].cin, res=residual is not None):
+            rc = _lib.lib().tln_gn_gather_gemm(C.byref(d), M, N, C.byref(s0[0]),
+                                               C.byref(s1[0]) if s1 is not None else None, _ptr(weight),
+                                               1 if w_is_nk else 0, _ptr(bias), _ptr(residual),
+                                               residual.stride(0) if residual is not None else 0, 1 if relu else 0,
+                                               _ptr(out), out.stride(0), _ptr(st), stream_ptr())
+        _lib.check(rc, "tln_gn_gather_gemm")
+        if st is not None:
+            out._tln_stats = st
+        return out
     with _timed("gather_gemm", M=M, N=N, K=K, taps=s0[0].taps, cin=s0[0].cin, res=residual is not None):
         rc = _lib.lib().tln_gather_gemm_ex(M, N, C.byref(s0[0]), C.byref(s1[0]) if s1 is not None else None,
                                            _ptr(weight), 1 if w_is_nk else 0, _ptr(bias), _ptr(residual),
@@ -107,8 +140,8 @@ def groupnorm_stats(x, groups, gamma, beta, eps=1e-5):
     If x was produced by gather_gemm(..., stats=True) its partial sums are reused (one tiny launch)."""
     x = _f32c(x)
     V, Cn = x.shape
-    scale = torch.empty((Cn,), dtype=torch.float32, device="cuda")
-    shift = torch.empty((Cn,), dtype=torch.float32, device="cuda")
+    ss = torch.empty((2, Cn), dtype=torch.float32, device=x.device)
+    scale, shift = ss[0], ss[1]
     st = getattr(x, "_tln_stats", None)
     if st is not None and tuple(st.shape) == ((V + 31) // 32, Cn, 2):
         gamma, beta = _f32c(gamma), _f32c(beta)
