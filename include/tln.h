@@ -94,6 +94,15 @@ typedef struct {
   const float* d_scale;    /* optional per-channel prologue a*scale+shift (GroupNorm apply) */
   const float* d_shift;
   int relu;                /* ReLU after the affine prologue                               */
+  /* GroupNorm of this source finalised INSIDE the GEMM (source 0 only): per-32-row (sum,sumsq) doubles
+   * [ceil(gn_rows/32)][cin] as written by tln_gather_gemm_ex / tln_groupnorm_partials.  When set, d_scale/d_shift
+   * are only scratch [cin] each for the large-V fallback. */
+  const void* d_gn_partials;
+  const float* d_gn_gamma;
+  const float* d_gn_beta;
+  int64_t gn_rows;
+  int gn_groups;
+  float gn_eps;
 } tln_gemm_src;
 
 /* C[M,N] = epilogue( concat_k(src0, src1) @ W ), K = taps0*cin0 (+ taps1*cin1).
@@ -129,6 +138,8 @@ int tln_groupnorm_stats(const float* d_x, int64_t V, int C, int groups, const fl
                         int64_t ws_bytes, void* stream);
 /* second half of tln_groupnorm_stats on partial sums that already exist (written by tln_gather_gemm_ex):
  * d_partials = [ceil(V/32)][C] (sum, sumsq) doubles */
+/* first half only: per-32-row partial sums of x [V,C] -> d_partials [ceil(V/32)][C] pairs of doubles */
+int tln_groupnorm_partials(const float* d_x, int64_t V, int C, void* d_partials, void* stream);
 int tln_groupnorm_from_partials(const void* d_partials, int64_t V, int C, int groups, const float* d_gamma,
                                 const float* d_beta, float eps, float* d_scale, float* d_shift, void* stream);
 /* GroupNorm (+ReLU) folded into a gather-GEMM: statistics -> per-channel scale/shift -> tln_gather_gemm_ex in ONE

@@ -18,6 +18,8 @@ class GemmSrc(C.Structure):
         ("d_src", C.c_void_p), ("src_rows", C.c_int64), ("ld", C.c_int64), ("cin", C.c_int), ("taps", C.c_int),
         ("d_table", C.c_void_p), ("pad_value", C.c_float), ("d_scale", C.c_void_p), ("d_shift", C.c_void_p),
         ("relu", C.c_int),
+        ("d_gn_partials", C.c_void_p), ("d_gn_gamma", C.c_void_p), ("d_gn_beta", C.c_void_p), ("gn_rows", C.c_int64),
+        ("gn_groups", C.c_int), ("gn_eps", C.c_float),
     ]
 
 
@@ -56,6 +58,7 @@ _PROTOS = {
     "tln_gemm_force_splits": (None, [_i, _i]),
     "tln_gather_gemm_ex": (_i, [_i64, _i, C.POINTER(GemmSrc), C.POINTER(GemmSrc), _vp, _i, _vp, _vp, _i64, _i, _vp, _i64, _vp, _vp]),
     "tln_gn_gather_gemm": (_i, [C.POINTER(GnDesc), _i64, _i, C.POINTER(GemmSrc), C.POINTER(GemmSrc), _vp, _i, _vp, _vp, _i64, _i, _vp, _i64, _vp, _vp]),
+    "tln_groupnorm_partials": (_i, [_vp, _i64, _i, _vp, _vp]),
     "tln_groupnorm_from_partials": (_i, [_vp, _i64, _i, _i, _vp, _vp, _f, _vp, _vp, _vp]),
     "tln_im2row": (_i, [_vp, _i64, _i, _vp, _i64, _vp, _vp]),
     "tln_groupnorm_ws_bytes": (_i64, [_i64, _i]),

@@ -97,6 +97,15 @@ extern "C" int tln_groupnorm_stats(const float* d_x, int64_t V, int C, int group
   return TLN_OK;
 }
 
+extern "C" int tln_groupnorm_partials(const float* d_x, int64_t V, int C, void* d_partials, void* stream_) {
+  TLN_REQUIRE(d_x && d_partials && V > 0 && C > 0 && C <= GN_MAX_C, "bad groupnorm partials call");
+  const int nblk = (int)tln_cdiv(V, GN_ROWS_PER_BLOCK);
+  hipLaunchKernelGGL(k_gn_partial, dim3(nblk, (unsigned)tln_cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream_, d_x, V, C,
+                     (double2*)d_partials);
+  TLN_LAUNCH_CHECK();
+  return TLN_OK;
+}
+
 extern "C" int tln_groupnorm_from_partials(const void* d_partials, int64_t V, int C, int groups, const float* d_gamma,
                                            const float* d_beta, float eps, float* d_scale, float* d_shift,
                                            void* stream_) {
@@ -404,22 +413,25 @@ extern "C" int tln_gn_gather_gemm(const tln_gn_desc* gn, int64_t M, int N, const
                                   const tln_gemm_src* s1, const float* d_w, int w_is_nk, const float* d_bias,
                                   const float* d_residual, int64_t ld_res, int relu, float* d_out, int64_t ld_out,
                                   void* d_stats, void* stream_) {
-  TLN_REQUIRE(gn && s0 && gn->d_scale_shift, "null argument");
-  float* scale = gn->d_scale_shift;
-  float* shift = gn->d_scale_shift + gn->C;
-  int rc;
-  if (gn->d_partials)
-    rc = tln_groupnorm_from_partials(gn->d_partials, gn->V, gn->C, gn->groups, gn->d_gamma, gn->d_beta, gn->eps, scale,
-                                     shift, stream_);
-  else
-    rc = tln_groupnorm_stats(gn->d_x, gn->V, gn->C, gn->groups, gn->d_gamma, gn->d_beta, gn->eps, scale, shift,
-                             gn->d_ws, gn->ws_bytes, stream_);
-  if (rc) return rc;
+  TLN_REQUIRE(gn && s0, "null argument");
+  const void* partials = gn->d_partials;
+  if (!partials) {  // the tensor did not come out of a gather-GEMM: one pass for the partial sums
+    TLN_REQUIRE(gn->d_x && gn->d_ws && gn->ws_bytes >= tln_groupnorm_ws_bytes(gn->V, gn->C), "GroupNorm workspace");
+    int rc = tln_groupnorm_partials(gn->d_x, gn->V, gn->C, gn->d_ws, stream_);
+    if (rc) return rc;
+    partials = gn->d_ws;
+  }
   tln_gemm_src a = *s0;
   TLN_REQUIRE(a.cin == gn->C, "GroupNorm width %d does not match the GEMM source width %d", gn->C, a.cin);
-  a.d_scale = scale;
-  a.d_shift = shift;
+  a.d_scale = gn->d_scale_shift;            // scratch for the large-V fallback (may be NULL when not needed)
+  a.d_shift = gn->d_scale_shift ? gn->d_scale_shift + gn->C : nullptr;
   a.relu = gn->relu;
+  a.d_gn_partials = partials;
+  a.d_gn_gamma = gn->d_gamma;
+  a.d_gn_beta = gn->d_beta;
+  a.gn_rows = gn->V;
+  a.gn_groups = gn->groups;
+  a.gn_eps = gn->eps;
   return tln_gather_gemm_ex(M, N, &a, s1, d_w, w_is_nk, d_bias, d_residual, ld_res, relu, d_out, ld_out, d_stats,
                             stream_);
 }

@@ -35,6 +35,13 @@ struct SrcDev {
   int64_t src_rows, ld;
   int cin, taps, relu;
   float pad;
+  // GroupNorm finalised inside the kernel from per-32-row partial sums (source 0 only)
+  const double2* gn_part;
+  const float* gn_gamma;
+  const float* gn_beta;
+  int64_t gn_rows;
+  int gn_nblk, gn_groups;
+  float gn_eps;
 };
 
 struct GemmArgs {
@@ -117,6 +124,56 @@ __global__ void __launch_bounds__(128 * WM * G) k_gather_gemm(const GemmArgs g) 
       Is[i] = (m < g.M) ? g.s[0].table[m * taps + (i % taps)] : -1;
     }
   }
+  // GroupNorm of source 0, finalised here: every block reduces the producer's per-32-row (sum, sumsq) partials in a
+  // fixed order (deterministic) into per-channel scale/shift kept in LDS.  No separate statistics kernel.
+  float* Gsc = reinterpret_cast<float*>(Is + BM * TLN_TAPS + 4);
+  float* Gsh = Gsc + g.s[0].cin;
+  const bool gn_lds = g.s[0].gn_part != nullptr;
+  if (gn_lds) {
+    const SrcDev& s = g.s[0];
+    double2* Gch = reinterpret_cast<double2*>(Gsh + s.cin);
+    const int Cn = s.cin;
+    for (int c = threadIdx.x; c < Cn; c += GT * G) {
+      // four independent accumulation chains keep several partial-sum loads in flight (fixed order => deterministic)
+      double sx[4] = {0.0, 0.0, 0.0, 0.0}, sq[4] = {0.0, 0.0, 0.0, 0.0};
+      int b = 0;
+      for (; b + 4 <= s.gn_nblk; b += 4) {
+        double2 p[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) p[u] = s.gn_part[(int64_t)(b + u) * Cn + c];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          sx[u] += p[u].x;
+          sq[u] += p[u].y;
+        }
+      }
+      for (; b < s.gn_nblk; ++b) {
+        const double2 p = s.gn_part[(int64_t)b * Cn + c];
+        sx[0] += p.x;
+        sq[0] += p.y;
+      }
+      Gch[c] = make_double2((sx[0] + sx[1]) + (sx[2] + sx[3]), (sq[0] + sq[1]) + (sq[2] + sq[3]));
+    }
+    __syncthreads();
+    const int cpg = Cn / s.gn_groups;
+    for (int c = threadIdx.x; c < Cn; c += GT * G) {
+      const int g0 = (c / cpg) * cpg;
+      double sx = 0.0, sq = 0.0;
+      for (int j = 0; j < cpg; ++j) {
+        sx += Gch[g0 + j].x;
+        sq += Gch[g0 + j].y;
+      }
+      const double cnt = (double)s.gn_rows * (double)cpg;
+      const double mean = sx / cnt;
+      double var = sq / cnt - mean * mean;
+      if (var < 0.0) var = 0.0;
+      const double rstd = 1.0 / sqrt(var + (double)s.gn_eps);
+      const double gm = s.gn_gamma ? (double)s.gn_gamma[c] : 1.0;
+      const double bt = s.gn_beta ? (double)s.gn_beta[c] : 0.0;
+      Gsc[c] = (float)(gm * rstd);
+      Gsh[c] = (float)(bt - mean * rstd * gm);
+    }
+  }
   __syncthreads();
 
   const int a_kq = tid % KQ;
@@ -154,7 +211,12 @@ __global__ void __launch_bounds__(128 * WM * G) k_gather_gemm(const GemmArgs g) 
               if (c + 2 < s.cin) v.z = ptr[2];
               if (c + 3 < s.cin) v.w = ptr[3];
             }
-            if (s.scale) {
+            if (si == 0 && gn_lds) {
+              v.x = fmaf(v.x, Gsc[c], Gsh[c]);
+              v.y = fmaf(v.y, Gsc[c + 1], Gsh[c + 1]);
+              v.z = fmaf(v.z, Gsc[c + 2], Gsh[c + 2]);
+              v.w = fmaf(v.w, Gsc[c + 3], Gsh[c + 3]);
+            } else if (s.scale) {
               float sc[4], sh[4];
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
@@ -414,6 +476,14 @@ static int fill_src(SrcDev& d, const tln_gemm_src* s) {
   d.taps = s->taps;
   d.relu = s->relu;
   d.pad = s->pad_value;
+  d.gn_part = reinterpret_cast<const double2*>(s->d_gn_partials);
+  d.gn_gamma = s->d_gn_gamma;
+  d.gn_beta = s->d_gn_beta;
+  d.gn_rows = s->gn_rows;
+  d.gn_nblk = (int)tln_cdiv(s->gn_rows, 32);
+  d.gn_groups = s->gn_groups;
+  d.gn_eps = s->gn_eps;
+  if (d.gn_part) TLN_REQUIRE(s->gn_groups > 0 && s->cin % s->gn_groups == 0 && s->gn_rows > 0, "bad GroupNorm source");
   return TLN_OK;
 }
 
@@ -458,13 +528,15 @@ static int launch_gemm(GemmArgs& g, int splits, hipStream_t s) {
   constexpr int ACC = TM * TN * 16;
   constexpr int RED_FLOATS = (G - 1) * ACC * GT;
   constexpr int REGION = (G * GROUP_FLOATS > RED_FLOATS) ? G * GROUP_FLOATS : RED_FLOATS;
-  const size_t lds = (size_t)(REGION + BM * TLN_TAPS + 4) * sizeof(float);
+  // + scale/shift [2][cin] floats and the per-channel (sum, sumsq) doubles of the in-kernel GroupNorm finalise
+  const size_t gn_floats = g.s[0].gn_part ? (size_t)6 * g.s[0].cin : 0;
+  const size_t lds = (size_t)(REGION + BM * TLN_TAPS + 4 + gn_floats) * sizeof(float);
   auto kern = k_gather_gemm<WM, TM, TN, BK, G, W_NK, VEC>;
   if (lds > 48 * 1024) {
-    static bool attr_set = false;  // per instantiation
-    if (!attr_set) {
+    static size_t attr_bytes = 0;  // per instantiation
+    if (lds > attr_bytes) {
       TLN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      attr_set = true;
+      attr_bytes = lds;
     }
   }
   dim3 grid((unsigned)tln_cdiv(g.M, BM), (unsigned)tln_cdiv(g.N, BN), (unsigned)splits);
@@ -510,12 +582,11 @@ extern "C" void tln_gemm_force_splits(int splits, int wm) {
 static Plan make_plan(int64_t M, int N, int nchunks) {
   Plan p{2, 1, 1, 1, 1};
   auto nblk = [&](int bm, int bn) { return tln_cdiv(M, bm) * tln_cdiv(N, bn); };
-  // big problems: 128 x 128 / 128 x 64 / 64 x 128 tiles, no split
-  if (nblk(128, N > 64 ? 128 : 64) >= 512) {
-    p.tm = 2;
-    p.tn = (N > 64) ? 2 : 1;
-  } else if (nblk(64, N > 64 ? 128 : 64) >= 512) {
-    p.tn = (N > 64) ? 2 : 1;
+  // large M (fine lattices, accumulated clouds): measured on MI355X (tools/gemm_bench_large.py, M = 168k) the
+  // 64 x 128 tile is the fastest when N is a multiple of 128 (82-88 TFLOP/s), the 64 x 64 tile otherwise
+  // (78 TFLOP/s at N = 192); the 128-row tiles are slower (fewer resident blocks to hide the gather latency)
+  if (nblk(64, 64) >= 512) {
+    p.tn = (N % 128 == 0) ? 2 : 1;
   } else if (nblk(64, 64) < 512) {
     // small M (a lattice level of a few thousand vertices): 32-row tiles, K-groups for latency hiding, and when
     // even the 32-row tiles cannot cover the CUs, slices of K over the grid.  Thresholds from tools/gemm_bench.py
@@ -582,6 +653,16 @@ extern "C" int tln_gather_gemm_ex(int64_t M, int N, const tln_gemm_src* s0, cons
   }
   vec = vec && (w_is_nk ? (K % 4 == 0) : (N % 4 == 0));
   const bool bk32 = (g.s[0].cin % 32 == 0) && (g.nsrc == 1 || g.s[1].cin % 32 == 0);
+
+  // in-kernel GroupNorm finalise only while the partial sums are small enough to be re-read by every block
+  if (g.s[0].gn_part && (!vec || (size_t)g.s[0].gn_nblk * g.s[0].cin * sizeof(double2) > (512u << 10))) {
+    TLN_REQUIRE(s0->d_scale && s0->d_shift, "GroupNorm fallback needs the d_scale/d_shift scratch of source 0");
+    rc = tln_groupnorm_from_partials(g.s[0].gn_part, g.s[0].gn_rows, g.s[0].cin, g.s[0].gn_groups, g.s[0].gn_gamma,
+                                     g.s[0].gn_beta, g.s[0].gn_eps, const_cast<float*>(s0->d_scale),
+                                     const_cast<float*>(s0->d_shift), stream_);
+    if (rc) return rc;
+    g.s[0].gn_part = nullptr;
+  }
 
   if (!vec) {
     rc = w_is_nk ? launch_gemm<2, 1, 1, 16, 1, true, false>(g, 1, s) : launch_gemm<2, 1, 1, 16, 1, false, false>(g, 1, s);

@@ -34,7 +34,18 @@ __device__ __forceinline__ void dense(const float* __restrict__ w, const float* 
   }
 }
 
-// CIN -> H1 -> (H2 ->) COUT ; H2 == 0 means a two-layer MLP; H1 == 0 means identity (COUT == CIN)
+// CIN -> H1 -> (H2 ->) COUT ; H2 == 0 means a two-layer MLP; H1 == 0 means identity (COUT == CIN).
+//
+// One wave takes 64 consecutive SORTED rows (rows of one vertex are contiguous).
+//   phase 1: lane = row.  The front layers (all but the last) run per lane with wave-uniform weights that the
+//            compiler keeps in SGPRs (few hundred scalars); the last hidden activation HL goes to a wave-private
+//            LDS tile [64 rows][HL] (rows padded to 16-byte multiples).
+//   phase 2: lane = OUTPUT CHANNEL of the last layer.  Its weight row sits in HL registers (loaded once per wave);
+//            the rows are walked in order, their activations arrive as LDS broadcast reads (ds_read_b128, one address
+//            for the whole wave) and the running (max, argmax-row) of the current vertex lives in registers — no
+//            transposition, no per-row scalar-load stalls in the layer that holds 78 % of the arithmetic.  When the
+//            vertex changes (wave-uniform branch) the lane flushes its channel with one 64-bit atomicMax of
+//            (order-preserving value bits, ~row): 512 contiguous bytes per wave-instruction.
 template <int CIN, int H1, int H2, int COUT>
 __global__ void __launch_bounds__(256) k_pool_chunks(const float* __restrict__ dist, int cols,
                                                      const int32_t* __restrict__ order,
@@ -43,9 +54,8 @@ __global__ void __launch_bounds__(256) k_pool_chunks(const float* __restrict__ d
                                                      const float* __restrict__ w2, const float* __restrict__ b2,
                                                      const float* __restrict__ w3, const float* __restrict__ b3,
                                                      unsigned long long* __restrict__ packed) {
-  // the MLP weights are wave-uniform, read-only kernel arguments indexed by compile-time constants: the
-  // compiler keeps them in SGPRs (s_load_dwordx8/x16), so the dense layers cost no LDS or vector-memory traffic
-  constexpr int TS = COUT + 1;  // padded tile stride
+  constexpr int HL = (H1 == 0) ? CIN : (H2 ? H2 : H1);   // width of the activation that feeds the last layer
+  constexpr int TS = ((HL + 3) / 4) * 4 + 4;             // tile row stride in floats (16-byte aligned rows)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float* tile = smem + wid * (64 * TS + 128);
@@ -54,9 +64,10 @@ __global__ void __launch_bounds__(256) k_pool_chunks(const float* __restrict__ d
 
   const int64_t chunk = (int64_t)blockIdx.x * 4 + wid;
   const int64_t j0 = chunk * 64;
-  if (j0 >= rows) return;  // no barrier below
+  if (j0 >= rows) return;  // no block barrier below: the tile is private to the wave
   const int cnt = (int)((rows - j0) < 64 ? (rows - j0) : 64);
 
+  // ---- phase 1
   if (lane < cnt) {
     const int row = order[j0 + lane];
     int v = sorted_vertex[j0 + lane];
@@ -64,48 +75,75 @@ __global__ void __launch_bounds__(256) k_pool_chunks(const float* __restrict__ d
     float x[CIN];
 #pragma unroll
     for (int c = 0; c < CIN; ++c) x[c] = dist[(int64_t)row * cols + c];
-    float y[COUT];
+    float hl[HL];
     if constexpr (H1 == 0) {
 #pragma unroll
-      for (int c = 0; c < COUT; ++c) y[c] = x[c];
+      for (int c = 0; c < HL; ++c) hl[c] = x[c];
     } else if constexpr (H2 == 0) {
+      dense<CIN, H1, true>(w1, b1, x, hl);
+    } else {
       float h1[H1];
       dense<CIN, H1, true>(w1, b1, x, h1);
-      dense<H1, COUT, false>(w2, b2, h1, y);
-    } else {
-      float h1[H1], h2[H2];
-      dense<CIN, H1, true>(w1, b1, x, h1);
-      dense<H1, H2, true>(w2, b2, h1, h2);
-      dense<H2, COUT, false>(w3, b3, h2, y);
+      dense<H1, H2, true>(w2, b2, h1, hl);
     }
 #pragma unroll
-    for (int c = 0; c < COUT; ++c) tile[lane * TS + c] = y[c];
+    for (int c = 0; c < HL; ++c) tile[lane * TS + c] = hl[c];
     tv[lane] = v;
     tr[lane] = row;
   }
-  // wave-private tile: LDS writes above are visible to the wave's own later reads after the wait below
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the wave's own LDS writes have landed
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-  for (int c = lane; c < COUT; c += 64) {
-    int cur = tv[0];
-    float best = tile[c];
-    int brow = tr[0];
-    for (int j = 1; j < cnt; ++j) {
-      const int v = tv[j];
-      const float val = tile[j * TS + c];
-      if (v != cur) {
+  // ---- phase 2
+  const int c = lane;
+  const bool active = c < COUT;
+  float wl[HL];
+  float bias = 0.0f;
+  if constexpr (H1 != 0) {
+    const float* wlast = H2 ? w3 : w2;
+    const float* blast = H2 ? b3 : b2;
+#pragma unroll
+    for (int i = 0; i < HL; ++i) wl[i] = active ? wlast[c * HL + i] : 0.0f;
+    bias = active ? blast[c] : 0.0f;
+  }
+  auto value_of = [&](int j) {
+    const float* h = tile + j * TS;
+    if constexpr (H1 == 0) {
+      return h[active ? c : 0];
+    } else {
+      float acc0 = bias, acc1 = 0.0f;
+#pragma unroll
+      for (int i = 0; i < HL; i += 4) {
+        const float4 q = *reinterpret_cast<const float4*>(h + i);   // one address for the whole wave: broadcast
+        acc0 = fmaf(wl[i], q.x, acc0);
+        acc1 = fmaf(wl[i + 1], q.y, acc1);
+        acc0 = fmaf(wl[i + 2], q.z, acc0);
+        acc1 = fmaf(wl[i + 3], q.w, acc1);
+      }
+      return acc0 + acc1;
+    }
+  };
+  int cur = tv[0];
+  float best = value_of(0);
+  int brow = tr[0];
+  for (int j = 1; j < cnt; ++j) {
+    const int v = tv[j];
+    const float val = value_of(j);
+    if (v != cur) {  // wave-uniform
+      if (active) {
         const unsigned long long p = ((unsigned long long)tln_f2ord(best) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)brow);
         atomicMax(&packed[(int64_t)cur * COUT + c], p);
-        cur = v;
-        best = val;
-        brow = tr[j];
-      } else if (val > best) {  // rows ascend inside a segment: strict '>' keeps the smallest row on ties
-        best = val;
-        brow = tr[j];
       }
+      cur = v;
+      best = val;
+      brow = tr[j];
+    } else if (val > best) {  // rows ascend inside a segment: strict '>' keeps the smallest row on ties
+      best = val;
+      brow = tr[j];
     }
+  }
+  if (active) {
     const unsigned long long p = ((unsigned long long)tln_f2ord(best) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)brow);
     atomicMax(&packed[(int64_t)cur * COUT + c], p);
   }
@@ -145,7 +183,9 @@ __global__ void __launch_bounds__(256) k_pool_finalize(const unsigned long long*
 template <int CIN, int H1, int H2, int COUT>
 static int launch_pool(tln_lattice* l, const float* d_dist, int64_t rows, int cols, const float* const* w,
                        const float* const* b, int nv, unsigned long long* packed, hipStream_t s) {
-  const size_t lds = (size_t)(4 * (64 * (COUT + 1) + 128)) * sizeof(float);
+  constexpr int HL = (H1 == 0) ? CIN : (H2 ? H2 : H1);
+  constexpr int TS = ((HL + 3) / 4) * 4 + 4;
+  const size_t lds = (size_t)(4 * (64 * TS + 128)) * sizeof(float);
   MlpParams mp{};
   for (int i = 0; i < 3; ++i) {
     mp.w[i] = (H1 && w) ? w[i < (H2 ? 3 : 2) ? i : 0] : nullptr;

@@ -104,7 +104,9 @@ def gather_gemm(M, weight, s0, s1=None, w_is_nk=False, bias=None, residual=None,
         V, Cn = x.shape
         d = _lib.GnDesc()
         part = getattr(x, "_tln_stats", None)
-        keep = torch.empty((2, Cn), dtype=torch.float32, device=weight.device)
+        # scale/shift scratch is only needed when the partial sums are too large for the in-kernel finalise
+        keep = torch.empty((2, Cn), dtype=torch.float32, device=weight.device) \
+            if (((V + 31) // 32) * Cn * 16 > (512 << 10) or Cn % 4) else None
         if part is not None and tuple(part.shape) == ((V + 31) // 32, Cn, 2):
             d.d_partials = part.data_ptr()
         else:
@@ -113,7 +115,7 @@ def gather_gemm(M, weight, s0, s1=None, w_is_nk=False, bias=None, residual=None,
             d.d_ws, d.d_x = ws.data_ptr(), x.data_ptr()
         d.V, d.C, d.groups, d.relu, d.eps = V, Cn, norm.num_groups, 1 if gn_relu else 0, float(norm.eps)
         d.d_gamma, d.d_beta = norm.weight.data_ptr(), norm.bias.data_ptr()
-        d.d_scale_shift = keep.data_ptr()
+        d.d_scale_shift = keep.data_ptr() if keep is not None else None
         with _timed("gather_gemm", M=M, N=N, K=K, taps=s0[0].taps, cin=s0[0].cin, res=residual is not None):
             rc = _lib.lib().tln_gn_gather_gemm(C.byref(d), M, N, C.byref(s0[0]),
                                                C.byref(s1[0]) if s1 is not None else None, _ptr(weight),
