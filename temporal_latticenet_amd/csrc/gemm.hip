@@ -173,7 +173,13 @@ __global__ void __launch_bounds__(128 * WM * G) k_gather_gemm(const GemmArgs g) 
       Gsc[c] = (float)(gm * rstd);
       Gsh[c] = (float)(bt - mean * rstd * gm);
     }
+  } else if (g.s[0].scale) {  // scale/shift given explicitly: stage them once instead of re-reading them per chunk
+    for (int c = threadIdx.x; c < g.s[0].cin; c += GT * G) {
+      Gsc[c] = g.s[0].scale[c];
+      Gsh[c] = g.s[0].shift[c];
+    }
   }
+  const bool pro_lds = gn_lds || g.s[0].scale != nullptr;
   __syncthreads();
 
   const int a_kq = tid % KQ;
@@ -211,7 +217,7 @@ __global__ void __launch_bounds__(128 * WM * G) k_gather_gemm(const GemmArgs g) 
               if (c + 2 < s.cin) v.z = ptr[2];
               if (c + 3 < s.cin) v.w = ptr[3];
             }
-            if (si == 0 && gn_lds) {
+            if (si == 0 && pro_lds && (VEC || c + 3 < s.cin)) {
               v.x = fmaf(v.x, Gsc[c], Gsh[c]);
               v.y = fmaf(v.y, Gsc[c + 1], Gsh[c + 1]);
               v.z = fmaf(v.z, Gsc[c + 2], Gsh[c + 2]);
@@ -529,7 +535,7 @@ static int launch_gemm(GemmArgs& g, int splits, hipStream_t s) {
   constexpr int RED_FLOATS = (G - 1) * ACC * GT;
   constexpr int REGION = (G * GROUP_FLOATS > RED_FLOATS) ? G * GROUP_FLOATS : RED_FLOATS;
   // + scale/shift [2][cin] floats and the per-channel (sum, sumsq) doubles of the in-kernel GroupNorm finalise
-  const size_t gn_floats = g.s[0].gn_part ? (size_t)6 * g.s[0].cin : 0;
+  const size_t gn_floats = g.s[0].gn_part ? (size_t)6 * g.s[0].cin : (g.s[0].scale ? (size_t)2 * g.s[0].cin : 0);
   const size_t lds = (size_t)(REGION + BM * TLN_TAPS + 4 + gn_floats) * sizeof(float);
   auto kern = k_gather_gemm<WM, TM, TN, BK, G, W_NK, VEC>;
   if (lds > 48 * 1024) {

@@ -7,7 +7,6 @@
 // produce bit-identical integer outputs; this file is therefore compiled with FP contraction OFF.
 #pragma clang fp contract(off)
 #include "common.h"
-#include <hipcub/hipcub.hpp>
 #include <stdarg.h>
 #include <string.h>
 #include <math.h>
@@ -112,11 +111,10 @@ static int ensure_rows(tln_lattice* l, int64_t rows) {
   TLN_HIP(hipMalloc(&l->sv_in, cap * sizeof(int32_t)));
   TLN_HIP(hipMalloc(&l->sv_out, cap * sizeof(int32_t)));
   TLN_HIP(hipMalloc(&l->pieces, (cap / 256 + 2) * 6 * sizeof(double)));
-  size_t bytes = 0;
-  TLN_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, l->sk_in, l->sk_out, l->sv_in, l->sv_out, (int)cap, 0, 32,
-                                             (hipStream_t)0));
-  TLN_HIP(hipMalloc(&l->sort_temp, bytes + 256));
-  l->sort_temp_bytes = bytes + 256;
+  // radix-sort scratch: ping-pong keys + values and the [256][blocks] digit histogram
+  const size_t bytes = (size_t)cap * 2 * sizeof(int32_t) + (size_t)256 * (cap / 4096 + 2) * sizeof(int32_t);
+  TLN_HIP(hipMalloc(&l->sort_temp, bytes));
+  l->sort_temp_bytes = bytes;
   l->rows_cap = cap;
   return TLN_OK;
 }
@@ -632,11 +630,135 @@ __global__ void __launch_bounds__(256) k_seg_start(const int32_t* __restrict__ s
   seg_start[v] = (int32_t)lo;
 }
 
+// ---------------------------------------------------------------------------------------
+// stable LSD radix sort of (vertex index, row id) pairs, 8 bits per pass, three launches per pass:
+//   k_radix_hist    per-block digit counts                      -> hist[digit][block]
+//   k_radix_scan    exclusive scan of the digit-major table (one block)
+//   k_radix_scatter ranks inside a wave by ballot multi-split (8 ballots), waves ordered through LDS,
+//                   blocks ordered through the scanned table => stable
+// The keys are vertex indices (< V+1), so a 120k-point frame on a few thousand vertices needs two passes.
+// ---------------------------------------------------------------------------------------
+#define RADIX_KPB 4096   // keys per block
+#define RADIX_TPB 1024   // threads per block (16 waves)
+
+__global__ void __launch_bounds__(RADIX_TPB) k_radix_hist(const int32_t* __restrict__ keys, int64_t n, int shift,
+                                                          int nblk, int32_t* __restrict__ hist) {
+  __shared__ int cnt[256];
+  if (threadIdx.x < 256) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * RADIX_KPB;
+#pragma unroll
+  for (int it = 0; it < RADIX_KPB / RADIX_TPB; ++it) {
+    const int64_t i = base + it * RADIX_TPB + threadIdx.x;
+    if (i < n) atomicAdd(&cnt[(keys[i] >> shift) & 255], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x < 256) hist[threadIdx.x * nblk + blockIdx.x] = cnt[threadIdx.x];
+}
+
+__global__ void __launch_bounds__(1024) k_radix_scan(int32_t* __restrict__ hist, int total) {
+  __shared__ int wave_tot[16];
+  __shared__ int carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  for (int base = 0; base < total; base += 1024) {
+    const int i = base + threadIdx.x;
+    const int v = (i < total) ? hist[i] : 0;
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int u = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += u;
+    }
+    if (lane == 63) wave_tot[wid] = incl;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wid; ++w) woff += wave_tot[w];
+    const int carry = carry_s;
+    if (i < total) hist[i] = carry + woff + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry_s = carry + woff + incl;
+    __syncthreads();
+  }
+}
+
+__global__ void __launch_bounds__(RADIX_TPB) k_radix_scatter(const int32_t* __restrict__ keys_in,
+                                                             const int32_t* __restrict__ vals_in, int64_t n, int shift,
+                                                             int nblk, const int32_t* __restrict__ hist,
+                                                             int32_t* __restrict__ keys_out,
+                                                             int32_t* __restrict__ vals_out) {
+  __shared__ int base[256];            // running output position per digit for this block
+  __shared__ int wcount[16][256];      // per-wave digit counts, then per-wave bases
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (threadIdx.x < 256) base[threadIdx.x] = hist[threadIdx.x * nblk + blockIdx.x];
+  const int64_t blk0 = (int64_t)blockIdx.x * RADIX_KPB;
+  for (int it = 0; it < RADIX_KPB / RADIX_TPB; ++it) {
+    for (int k = threadIdx.x; k < 16 * 256; k += RADIX_TPB) (&wcount[0][0])[k] = 0;
+    __syncthreads();
+    const int64_t i = blk0 + it * RADIX_TPB + threadIdx.x;
+    const bool ok = i < n;
+    const int key = ok ? keys_in[i] : 0;
+    const int val = ok ? vals_in[i] : 0;
+    const int d = (key >> shift) & 255;
+    // lanes of this wave holding the same digit (invalid lanes form their own class)
+    unsigned long long peers = __ballot(ok);
+    if (!ok) peers = ~peers;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const unsigned long long m = __ballot((d >> b) & 1);
+      peers &= ((d >> b) & 1) ? m : ~m;
+    }
+    const int rank = __popcll(peers & ((1ull << lane) - 1ull));
+    if (ok && rank == 0) wcount[wid][d] = __popcll(peers);
+    __syncthreads();
+    if (threadIdx.x < 256) {
+      int run = base[threadIdx.x];
+      for (int w = 0; w < 16; ++w) {
+        const int t = wcount[w][threadIdx.x];
+        wcount[w][threadIdx.x] = run;
+        run += t;
+      }
+      base[threadIdx.x] = run;
+    }
+    __syncthreads();
+    if (ok) {
+      const int pos = wcount[wid][d] + rank;
+      keys_out[pos] = key;
+      vals_out[pos] = val;
+    }
+    __syncthreads();
+  }
+}
+
+static int radix_sort_pairs(tln_lattice* l, int64_t rows, int bits, hipStream_t s) {
+  const int nblk = (int)tln_cdiv(rows, RADIX_KPB);
+  int32_t* tmp_k = reinterpret_cast<int32_t*>(l->sort_temp);
+  int32_t* tmp_v = tmp_k + l->rows_cap;
+  int32_t* hist = tmp_v + l->rows_cap;
+  const int passes = (bits + 7) / 8;
+  // ping-pong so that the LAST pass lands in sk_out / sv_out
+  const int32_t* src_k = l->sk_in;
+  const int32_t* src_v = l->sv_in;
+  for (int p = 0; p < passes; ++p) {
+    const bool to_out = ((passes - 1 - p) % 2) == 0;
+    int32_t* dst_k = to_out ? l->sk_out : tmp_k;
+    int32_t* dst_v = to_out ? l->sv_out : tmp_v;
+    hipLaunchKernelGGL(k_radix_hist, dim3(nblk), dim3(RADIX_TPB), 0, s, src_k, rows, 8 * p, nblk, hist);
+    hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(1024), 0, s, hist, 256 * nblk);
+    hipLaunchKernelGGL(k_radix_scatter, dim3(nblk), dim3(RADIX_TPB), 0, s, src_k, src_v, rows, 8 * p, nblk, hist, dst_k,
+                       dst_v);
+    src_k = dst_k;
+    src_v = dst_v;
+  }
+  TLN_LAUNCH_CHECK();
+  return TLN_OK;
+}
+
 static int build_csr_sorted(tln_lattice* l, int64_t rows, hipStream_t s) {
-  const int end_bit = bits_for(l->nr_vertices + 1);
-  size_t bytes = l->sort_temp_bytes;
-  TLN_HIP(hipcub::DeviceRadixSort::SortPairs(l->sort_temp, bytes, l->sk_in, l->sk_out, l->sv_in, l->sv_out, (int)rows,
-                                             0, end_bit, s));
+  const int bits = bits_for(l->nr_vertices + 1);
+  int rc = radix_sort_pairs(l, rows, bits, s);
+  if (rc) return rc;
   const int64_t nv = l->nr_vertices;
   hipLaunchKernelGGL(k_seg_start, dim3((unsigned)tln_cdiv(nv + 2, 256)), dim3(256), 0, s, l->sk_out, rows, nv,
                      l->seg_start);
