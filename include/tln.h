@@ -78,6 +78,9 @@ int tln_neighbour_table(tln_lattice_t* l, const int32_t** d_table_out, void* str
 /* GnReluCoarsen / create-coarse-verts (models.py:353): returns the persistent child level,
  * extended (append-only) by the fine vertices added since the last call. */
 int tln_coarsen(tln_lattice_t* fine, tln_lattice_t** coarse_out, void* stream);
+/* once per frame, after tln_distribute: extends the coarse levels and (re)builds every stale neighbour / cross-level
+ * table of the stack in one launch; afterwards the table getters return cached pointers */
+int tln_lattice_prepare_levels(tln_lattice_t* level0, int nr_coarse_levels, void* stream);
 /* [V_coarse,9] rows into the fine level (coarsen conv) / [V_fine,9] rows into the coarse level (finefy) */
 int tln_coarse_to_fine_table(tln_lattice_t* coarse, const int32_t** d_table_out, void* stream);
 int tln_fine_to_coarse_table(tln_lattice_t* coarse, const int32_t** d_table_out, void* stream);

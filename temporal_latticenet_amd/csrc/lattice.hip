@@ -537,6 +537,7 @@ __global__ void __launch_bounds__(1024) k_scan_blocks(int32_t* __restrict__ bloc
     const int vold = ctr[CTR_NV];
     ctr[CTR_VOLD] = vold;
     ctr[CTR_NEW] = total;
+    ctr[CTR_OVERFLOW] = 0;  // accumulated by k_row_indices, which runs after the numbering
     long long vnew = (long long)vold + total;
     ctr[CTR_NV] = (int)(vnew < capacity ? vnew : capacity);
   }
@@ -587,9 +588,64 @@ __global__ void __launch_bounds__(256) k_row_indices(TableRef t, const int32_t* 
   }
 }
 
+// small insertions (the coarse levels embed only the new fine vertices of a frame): count, scan and assign in ONE
+// launch of a single block that walks the rows in order
+__global__ void __launch_bounds__(TLN_SCAN_BLOCK) k_number_small(TableRef t, const int32_t* __restrict__ row_slot,
+                                                                 int64_t rows, int32_t* __restrict__ ctr, int capacity,
+                                                                 int32_t* __restrict__ vkeys) {
+  __shared__ int wave_cnt[TLN_SCAN_BLOCK / 64];
+  __shared__ int running_s;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int vold = ctr[CTR_NV];
+  if (threadIdx.x == 0) running_s = 0;
+  __syncthreads();
+  for (int64_t base = 0; base < rows; base += TLN_SCAN_BLOCK) {
+    const int64_t id = base + threadIdx.x;
+    int slot;
+    const bool f = is_first_touch(t, row_slot, id, rows, slot);
+    const unsigned long long m = __ballot(f);
+    if (lane == 0) wave_cnt[wid] = __popcll(m);
+    __syncthreads();
+    int woff = 0, total = 0;
+    for (int w = 0; w < TLN_SCAN_BLOCK / 64; ++w) {
+      if (w < wid) woff += wave_cnt[w];
+      total += wave_cnt[w];
+    }
+    const int running = running_s;
+    if (f) {
+      const long long v = (long long)vold + running + woff + __popcll(m & ((1ull << lane) - 1ull));
+      if (v < capacity) {
+        t.slot_val[slot] = (int)v;
+        int k0, k1, k2;
+        tln_unpack_key(t.slot_key[slot], k0, k1, k2);
+        *reinterpret_cast<int4*>(vkeys + 4 * v) = make_int4(k0, k1, k2, -(k0 + k1 + k2));
+      } else {
+        t.slot_touch[slot] = 0xFFFFFFFFu;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) running_s = running + total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const int total = running_s;
+    ctr[CTR_VOLD] = vold;
+    ctr[CTR_NEW] = total;
+    ctr[CTR_OVERFLOW] = 0;  // accumulated by k_row_indices, which runs after the numbering
+    const long long vnew = (long long)vold + total;
+    ctr[CTR_NV] = (int)(vnew < capacity ? vnew : capacity);
+  }
+}
+
 static int number_new(tln_lattice* l, int64_t rows, hipStream_t s) {
   const int nblocks = (int)tln_cdiv(rows, TLN_SCAN_BLOCK);
   TableRef t = table_ref(l);
+  if (rows <= 16 * TLN_SCAN_BLOCK) {
+    hipLaunchKernelGGL(k_number_small, dim3(1), dim3(TLN_SCAN_BLOCK), 0, s, t, l->row_slot, rows, l->d_ctr,
+                       (int)l->capacity, l->vkeys);
+    TLN_LAUNCH_CHECK();
+    return TLN_OK;
+  }
   hipLaunchKernelGGL(k_count_new, dim3(nblocks), dim3(TLN_SCAN_BLOCK), 0, s, t, l->row_slot, rows, l->block_cnt);
   hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, l->block_cnt, nblocks, l->d_ctr, (int)l->capacity);
   hipLaunchKernelGGL(k_assign_new, dim3(nblocks), dim3(TLN_SCAN_BLOCK), 0, s, t, l->row_slot, rows, l->block_cnt,
@@ -908,7 +964,6 @@ extern "C" int tln_distribute(tln_lattice_t* l, const float* d_positions, const 
   rc = ensure_slots(l, rows, s);
   if (rc) return rc;
   TableRef t = table_ref(l);
-  TLN_HIP(hipMemsetAsync(l->d_ctr + CTR_OVERFLOW, 0, sizeof(int32_t), s));
   hipLaunchKernelGGL(k_distribute_insert, dim3((unsigned)tln_cdiv(n, 256)), dim3(256), 0, s, d_positions, d_values, n,
                      val_dim, l->scale[0], l->scale[1], l->scale[2], t, l->row_slot, d_weights, d_distributed);
   TLN_LAUNCH_CHECK();
@@ -944,7 +999,6 @@ extern "C" int tln_lattice_insert_keys(tln_lattice_t* l, const int32_t* d_keys, 
   rc = ensure_slots(l, n, s);
   if (rc) return rc;
   TableRef t = table_ref(l);
-  TLN_HIP(hipMemsetAsync(l->d_ctr + CTR_OVERFLOW, 0, sizeof(int32_t), s));
   hipLaunchKernelGGL(k_insert_keys, dim3((unsigned)tln_cdiv(n, 256)), dim3(256), 0, s, d_keys, n, t, l->row_slot);
   TLN_LAUNCH_CHECK();
   rc = number_new(l, n, s);
@@ -993,9 +1047,8 @@ __device__ __forceinline__ void tap_key(int k0, int k1, int k2, int tap, int& n0
 
 // mode 0: same level (query = own keys); mode 1: coarse->fine (query = 2*key into `t` = fine table);
 // mode 2: fine->coarse (query = finefy centre of the fine key into `t` = coarse table)
-__global__ void __launch_bounds__(256) k_neighbour_table(const int32_t* __restrict__ qkeys, int64_t nq, TableRef t,
-                                                         int mode, int32_t* __restrict__ table) {
-  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void table_entry(const int32_t* __restrict__ qkeys, int64_t nq, const TableRef& t, int mode,
+                                            int32_t* __restrict__ table, int64_t gid) {
   const int64_t v = gid / TLN_TAPS;
   const int tap = (int)(gid - v * TLN_TAPS);
   if (v >= nq) return;
@@ -1017,6 +1070,33 @@ __global__ void __launch_bounds__(256) k_neighbour_table(const int32_t* __restri
   if (mode == 0 && tap == 8) res = (int)v;
   else if (tln_key_in_range(n0, n1, n2)) res = probe_find(t, tln_pack_key(n0, n1, n2));
   table[gid] = res;
+}
+
+__global__ void __launch_bounds__(256) k_neighbour_table(const int32_t* __restrict__ qkeys, int64_t nq, TableRef t,
+                                                         int mode, int32_t* __restrict__ table) {
+  table_entry(qkeys, nq, t, mode, table, (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// every stale table of a level stack in ONE launch (a frame needs up to 3 + 2 + 2 of them)
+struct TableJob {
+  const int32_t* qkeys;
+  int64_t nq;
+  TableRef t;
+  int32_t* out;
+  int mode;
+  int block_begin;
+};
+struct TableJobs {
+  TableJob j[8];
+  int n;
+};
+__global__ void __launch_bounds__(256) k_tables_multi(const TableJobs jobs) {
+  int k = 0;
+#pragma unroll
+  for (int i = 1; i < 8; ++i)
+    if (i < jobs.n && (int)blockIdx.x >= jobs.j[i].block_begin) k = i;
+  const TableJob& jb = jobs.j[k];
+  table_entry(jb.qkeys, jb.nq, jb.t, jb.mode, jb.out, (int64_t)(blockIdx.x - jb.block_begin) * blockDim.x + threadIdx.x);
 }
 
 static int ensure_table(int32_t** p, int64_t capacity) {
@@ -1106,5 +1186,64 @@ extern "C" int tln_fine_to_coarse_table(tln_lattice_t* c, const int32_t** d_tabl
     c->f2c_vf = f->nr_vertices;
   }
   *d_table_out = c->f2c;
+  return TLN_OK;
+}
+
+// Build the coarse levels and every stale table of the stack in as few launches as possible: per coarse level one
+// insertion + one numbering launch and one counter read-back, then ONE launch for all neighbour / cross-level
+// tables.  Called once per frame right after tln_distribute; the per-table getters then only return pointers.
+extern "C" int tln_lattice_prepare_levels(tln_lattice_t* l0, int nr_coarse_levels, void* stream_) {
+  TLN_REQUIRE(l0 && nr_coarse_levels >= 0 && nr_coarse_levels <= 3, "bad prepare_levels arguments");
+  hipStream_t s = (hipStream_t)stream_;
+  tln_lattice* lv = l0;
+  for (int i = 0; i < nr_coarse_levels; ++i) {
+    tln_lattice* c = nullptr;
+    int rc = tln_coarsen(lv, &c, stream_);
+    if (rc) return rc;
+    lv = c;
+  }
+  TableJobs jobs{};
+  int blocks = 0;
+  auto add = [&](const int32_t* qkeys, int64_t nq, tln_lattice* target, int mode, int32_t* out) {
+    TableJob& j = jobs.j[jobs.n++];
+    j.qkeys = qkeys;
+    j.nq = nq;
+    j.t = table_ref(target);
+    j.mode = mode;
+    j.out = out;
+    j.block_begin = blocks;
+    blocks += (int)tln_cdiv(nq * TLN_TAPS, 256);
+  };
+  for (tln_lattice* p = l0; p; p = p->coarse) {
+    if (p->nr_vertices <= 0) continue;
+    int rc = ensure_table(&p->nbr, p->capacity);
+    if (rc) return rc;
+    if (p->nbr_built_for != p->nr_vertices) {
+      add(p->vkeys, p->nr_vertices, p, 0, p->nbr);
+      p->nbr_built_for = p->nr_vertices;
+    }
+    if (p->parent && p->parent->nr_vertices > 0) {
+      tln_lattice* f = p->parent;
+      rc = ensure_table(&p->c2f, p->capacity);
+      if (rc) return rc;
+      rc = ensure_table(&p->f2c, f->capacity);
+      if (rc) return rc;
+      if (p->c2f_vc != p->nr_vertices || p->c2f_vf != f->nr_vertices) {
+        add(p->vkeys, p->nr_vertices, f, 1, p->c2f);
+        p->c2f_vc = p->nr_vertices;
+        p->c2f_vf = f->nr_vertices;
+      }
+      if (p->f2c_vc != p->nr_vertices || p->f2c_vf != f->nr_vertices) {
+        add(f->vkeys, f->nr_vertices, p, 2, p->f2c);
+        p->f2c_vc = p->nr_vertices;
+        p->f2c_vf = f->nr_vertices;
+      }
+    }
+    if (jobs.n >= 7) break;
+  }
+  if (jobs.n > 0) {
+    hipLaunchKernelGGL(k_tables_multi, dim3((unsigned)blocks), dim3(256), 0, s, jobs);
+    TLN_LAUNCH_CHECK();
+  }
   return TLN_OK;
 }

@@ -196,6 +196,11 @@ class Lattice:
     def _parent_vertices(self):
         return self._parent.nr_lattice_vertices() if getattr(self, "_parent", None) is not None else -1
 
+    def prepare_levels(self, nr_coarse_levels):
+        """after distribute(): extend the coarse levels and build all their tables in as few launches as possible"""
+        _lib.check(_lib.lib().tln_lattice_prepare_levels(self._h, int(nr_coarse_levels), stream_ptr()),
+                   "tln_lattice_prepare_levels")
+
     def coarsen(self):
         """The persistent coarse level, extended by the vertices added since the last call."""
         p = C.c_void_p()

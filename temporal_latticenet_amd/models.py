@@ -184,6 +184,8 @@ class LNN_SEQ(torch.nn.Module):
             reset_hashmap = False
         with torch.set_grad_enabled(False):
             ls, distributed, indices, weights = self.distribute(ls, positions, values, reset_hashmap)   # :298
+            if hasattr(ls, "prepare_levels"):      # all coarse levels + neighbour tables of the frame in one go
+                ls.prepare_levels(self.nr_downsamples)
         lv, ls = self.point_net_seq(ls, distributed, indices)                        # :303
 
         if early_return and self.sequence_learning and self.rnn_modules[1] == "none" and \

@@ -18,6 +18,13 @@ __all__ = ["LSTMModule", "GRUModule", "CrossframeGlobalAttentionModule", "Tempor
            "PointNetSeqModule"]
 
 
+def _keep(t):
+    """the hidden state kept for the next frame.  The reference clones (lm:30, 56, 63, ...); here nothing mutates a
+    fusion output in place (PointNetSeqModule copies before zeroing row 0), so inference can alias.  The training
+    path keeps the clone: autograd needs the version counters untouched."""
+    return t.clone() if AG.grad_mode() else t
+
+
 def _linear(mod, x, src_rows=None, pad_value=0.0, relu=False, rows=None):
     """torch.nn.Linear `mod` applied per vertex on the matrix cores; rows beyond src_rows read as pad_value"""
     rows = x.shape[0] if rows is None else rows
@@ -42,7 +49,7 @@ class LSTMModule(torch.nn.Module):
 
     def forward(self, lv, ls):
         if self.h_lv is None:
-            self.h_lv = lv.clone()
+            self.h_lv = _keep(lv)
         else:
             self.h_lv = _linear(self.hidden_linear, self.h_lv)                       # lm:32
             V, C = lv.shape
@@ -53,7 +60,7 @@ class LSTMModule(torch.nn.Module):
                     Fn.linear(AG.pad_rows(self.h_lv, V), self.lstm.weight_hh, self.lstm.bias_hh)
                 i, f, g, o = gates.chunk(4, 1)
                 lv = torch.sigmoid(o) * torch.tanh(torch.sigmoid(i) * torch.tanh(g))
-                self.h_lv = lv.clone()
+                self.h_lv = _keep(lv)
                 ls.set_values(lv)
                 return lv, ls
             # gates = lv W_ih^T + b_ih + pad(h) W_hh^T + b_hh  (cell state is zero, lm:36)
@@ -63,7 +70,7 @@ class LSTMModule(torch.nn.Module):
             i, f, g, o = gates.chunk(4, 1)
             c = torch.sigmoid(i) * torch.tanh(g)                                     # f * c0 with c0 = 0
             lv = torch.sigmoid(o) * torch.tanh(c)
-            self.h_lv = lv.clone()
+            self.h_lv = _keep(lv)
             ls.set_values(lv)
         return lv, ls
 
@@ -82,8 +89,8 @@ class GRUModule(torch.nn.Module):
 
     def forward(self, lv, ls):
         if self.h_lv is None:                                                        # lm:54-56
-            new_lv = lv.clone()
-            self.h_lv = lv.clone()
+            new_lv = lv if not AG.grad_mode() else lv.clone()
+            self.h_lv = _keep(lv)
         else:
             self.h_lv = _linear(self.hidden_linear, self.h_lv)                       # lm:58
             # zero padding of h to lv.shape[0] rows (lm:59-60) happens inside the kernel
@@ -92,7 +99,7 @@ class GRUModule(torch.nn.Module):
             else:
                 new_lv = ops.gru_cell(lv, self.h_lv, self.GRU.weight_ih, self.GRU.weight_hh, self.GRU.bias_ih,
                                       self.GRU.bias_hh)                              # lm:62
-            self.h_lv = new_lv.clone()
+            self.h_lv = _keep(new_lv)
             ls.set_values(new_lv)
         return new_lv, ls
 
@@ -114,7 +121,7 @@ class CrossframeGlobalAttentionModule(torch.nn.Module):
 
     def forward(self, lv, ls):
         if self.h_lv is None:
-            self.h_lv = lv.clone()
+            self.h_lv = _keep(lv)
         else:
             V = lv.shape[0]
             Vh = self.h_lv.shape[0]
@@ -132,7 +139,7 @@ class CrossframeGlobalAttentionModule(torch.nn.Module):
                 else:
                     h_lv[Vh:] = 1.0
             lv = h_lv * lv                                                           # lm:112
-            self.h_lv = lv.clone()
+            self.h_lv = _keep(lv)
             ls.set_values(lv)
         return lv, ls
 
@@ -150,12 +157,12 @@ class TemporalMaxPoolModule(torch.nn.Module):
     def forward(self, lv, ls):
         alpha = 0.0
         if self.h_lv is None:
-            self.h_lv = lv.clone()
+            self.h_lv = _keep(lv)
         else:
             pad = lv.shape[0] - self.h_lv.shape[0]
             h_lv = torch.nn.functional.pad(self.h_lv, (0, 0, 0, pad), value=-9999.0)  # lm:138-139
             lv = torch.maximum(h_lv, lv)                                             # lm:141
-            self.h_lv = alpha * h_lv + (1 - alpha) * lv.clone()                      # lm:142
+            self.h_lv = _keep(lv) if alpha == 0.0 else alpha * h_lv + (1 - alpha) * lv   # lm:142
         ls.set_values(lv)
         return lv, ls
 
@@ -180,7 +187,7 @@ class TemporalLinearModule(torch.nn.Module):
                 print("The second dimension of lv and the MLP do not match! Lv is ", lv.shape[1],
                       "output channels is ", self.nr_output_channels)
                 exit(1)
-            self.h_lv = lv.clone()
+            self.h_lv = _keep(lv)
         else:
             self.h_lv = _linear(self.hidden_linear, self.h_lv)                       # lm:172
             V, Vh = lv.shape[0], self.h_lv.shape[0]
@@ -191,7 +198,7 @@ class TemporalLinearModule(torch.nn.Module):
             else:
               lv = ops.gather_gemm(V, self.linear.weight, ops.gemm_src(self.h_lv, src_rows=Vh, pad_value=0.0),
                                  ops.gemm_src(lv), w_is_nk=True, bias=self.linear.bias, relu=True)
-            self.h_lv = lv.clone()
+            self.h_lv = _keep(lv)
         ls.set_values(lv)
         return lv, ls
 
@@ -295,7 +302,7 @@ class CrossframeLocalInterpolationModule(torch.nn.Module):
 
     def forward(self, lv, ls):
         if self.h_lv is None:
-            self.h_lv = lv.clone()
+            self.h_lv = _keep(lv)
         else:
             # h is padded with -999999 inside the kernel (lm:213-215); the padded copy is only kept for the
             # visualiser hooks (lm:219)
@@ -309,7 +316,7 @@ class CrossframeLocalInterpolationModule(torch.nn.Module):
             else:
               lv = ops.gather_gemm(V, self.linear.weight, ops.gemm_src(aflow_vec), ops.gemm_src(lv), w_is_nk=True,
                                  bias=self.linear.bias, relu=True)
-            self.h_lv = lv.clone()
+            self.h_lv = _keep(lv)
         ls.set_values(lv)
         return lv, ls
 
@@ -432,7 +439,9 @@ class PointNetSeqModule(torch.nn.Module):
                 keep[0] = 0
                 distributed_reduced = distributed_reduced * keep
             else:
-                distributed_reduced[0, :] = 0                                        # fresh tensor: in place
+                if self.sequence_learning and self.fusion_module is not None:
+                    distributed_reduced = distributed_reduced.clone()                # the fusion module keeps its own
+                distributed_reduced[0, :] = 0
         lattice_py.set_values(distributed_reduced)
         distributed_reduced, lattice_py = self.last_conv(distributed_reduced, lattice_py)   # lm:573
         lattice_py.set_values(distributed_reduced)
