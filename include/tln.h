@@ -128,6 +128,9 @@ void tln_gemm_force_tiles(int tm, int tn);
 void tln_gemm_force_groups(int groups);
 /* tuning hook: force the split-K slices over the grid and the tile height (wm: 1 = 32 rows, 2 = 64 rows) */
 void tln_gemm_force_splits(int splits, int wm);
+/* diagnostic hook: block (0,0,0) of every following gather-GEMM writes five s_memtime stamps (start, after the
+ * index/GroupNorm prologue, after the K loop, after the reductions, end) to d_buf (5 x u64); NULL switches it off */
+void tln_gemm_debug_stamps(void* d_buf);
 
 /* materialised im2row (API parity with Im2RowLattice / Im2RowIndicesLattice, lm:301-304) */
 int tln_im2row(const float* d_src, int64_t src_rows, int cin, const int32_t* d_table, int64_t M,

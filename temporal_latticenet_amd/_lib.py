@@ -57,6 +57,7 @@ _PROTOS = {
     "tln_gemm_force_tiles": (None, [_i, _i]),
     "tln_gemm_force_groups": (None, [_i]),
     "tln_gemm_force_splits": (None, [_i, _i]),
+    "tln_gemm_debug_stamps": (None, [_vp]),
     "tln_gather_gemm_ex": (_i, [_i64, _i, C.POINTER(GemmSrc), C.POINTER(GemmSrc), _vp, _i, _vp, _vp, _i64, _i, _vp, _i64, _vp, _vp]),
     "tln_gn_gather_gemm": (_i, [C.POINTER(GnDesc), _i64, _i, C.POINTER(GemmSrc), C.POINTER(GemmSrc), _vp, _i, _vp, _vp, _i64, _i, _vp, _i64, _vp, _vp]),
     "tln_groupnorm_partials": (_i, [_vp, _i64, _i, _vp, _vp]),

@@ -61,6 +61,7 @@ struct GemmArgs {
   float* slab;      // split-K partial tiles [S][tiles][TM*TN*16][GT]
   int* counters;    // split-K arrival counters [tiles], zero between launches
   int splits;
+  unsigned long long* dbg;  // diagnostic: s_memtime stamps of block (0,0,0) (tools/gemm_stamps.py), else NULL
 };
 
 template <int WM, int TM, int TN, int BK, int G, bool W_NK, bool VEC>
@@ -79,7 +80,8 @@ __global__ void __launch_bounds__(128 * WM * G) k_gather_gemm(const GemmArgs g) 
   constexpr int B_PASSES = W_NK ? B_PASSES_NK : B_PASSES_KN;
   constexpr int A_TILE = ((BK * LDA + 3) / 4) * 4;
   constexpr int B_TILE = ((BK * LDB + 3) / 4) * 4;
-  constexpr int GROUP_FLOATS = A_TILE + B_TILE;
+  constexpr int BUF_FLOATS = A_TILE + B_TILE;          // one staging buffer of a K-group
+  constexpr int GROUP_FLOATS = 2 * BUF_FLOATS;         // double-buffered: one barrier per chunk
   constexpr int ACC = TM * TN * 16;
   constexpr int RED_FLOATS = (G - 1) * ACC * GT;  // partial accumulators of groups 1..G-1
   constexpr int REGION = (G * GROUP_FLOATS > RED_FLOATS) ? G * GROUP_FLOATS : RED_FLOATS;
@@ -87,8 +89,8 @@ __global__ void __launch_bounds__(128 * WM * G) k_gather_gemm(const GemmArgs g) 
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x % GT, grp = threadIdx.x / GT;
-  float* As = smem + grp * GROUP_FLOATS;
-  float* Bs = As + A_TILE;
+  float* As0 = smem + grp * GROUP_FLOATS;
+  float* Bs0 = As0 + A_TILE;
   int* Is = reinterpret_cast<int*>(smem + REGION);  // [BM][TLN_TAPS] tap indices of source 0, then 1 flag word
 
   const int lane = tid & 63, wid = tid >> 6;
@@ -117,6 +119,8 @@ __global__ void __launch_bounds__(128 * WM * G) k_gather_gemm(const GemmArgs g) 
   const int my_chunks = c_end > c_begin ? c_end - c_begin : 0;
   const int iters = (my_chunks + G - 1) / G;
 
+  const bool stamp = g.dbg && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0;
+  if (stamp) g.dbg[0] = __builtin_amdgcn_s_memtime();
   if (g.s[0].table != nullptr) {
     const int taps = g.s[0].taps;
     for (int i = threadIdx.x; i < BM * taps; i += GT * G) {
@@ -137,14 +141,14 @@ __global__ void __launch_bounds__(128 * WM * G) k_gather_gemm(const GemmArgs g) 
       // four independent accumulation chains keep several partial-sum loads in flight (fixed order => deterministic)
       double sx[4] = {0.0, 0.0, 0.0, 0.0}, sq[4] = {0.0, 0.0, 0.0, 0.0};
       int b = 0;
-      for (; b + 4 <= s.gn_nblk; b += 4) {
-        double2 p[4];
+      for (; b + 8 <= s.gn_nblk; b += 8) {
+        double2 p[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) p[u] = s.gn_part[(int64_t)(b + u) * Cn + c];
+        for (int u = 0; u < 8; ++u) p[u] = s.gn_part[(int64_t)(b + u) * Cn + c];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          sx[u] += p[u].x;
-          sq[u] += p[u].y;
+        for (int u = 0; u < 8; ++u) {
+          sx[u & 3] += p[u].x;
+          sq[u & 3] += p[u].y;
         }
       }
       for (; b < s.gn_nblk; ++b) {
@@ -181,6 +185,7 @@ __global__ void __launch_bounds__(128 * WM * G) k_gather_gemm(const GemmArgs g) 
   }
   const bool pro_lds = gn_lds || g.s[0].scale != nullptr;
   __syncthreads();
+  if (stamp) g.dbg[1] = __builtin_amdgcn_s_memtime();
 
   const int a_kq = tid % KQ;
   const int a_row0 = tid / KQ;
@@ -294,7 +299,9 @@ __global__ void __launch_bounds__(128 * WM * G) k_gather_gemm(const GemmArgs g) 
     }
   };
 
-  auto stage = [&](const float4 (&a_reg)[A_PASSES], const float4 (&b_reg)[B_PASSES]) {
+  auto stage = [&](int buf, const float4 (&a_reg)[A_PASSES], const float4 (&b_reg)[B_PASSES]) {
+    float* As = As0 + buf * BUF_FLOATS;
+    float* Bs = Bs0 + buf * BUF_FLOATS;
 #pragma unroll
     for (int p = 0; p < A_PASSES; ++p) {
       const int row = p * A_ROWS_PASS + a_row0;
@@ -324,9 +331,9 @@ __global__ void __launch_bounds__(128 * WM * G) k_gather_gemm(const GemmArgs g) 
     }
   };
 
-  auto compute = [&]() {
-    const float* ap = As + half * LDA + wm * 32 * TM + l31;
-    const float* bp = Bs + half * LDB + wn * 32 * TN + l31;
+  auto compute = [&](int buf) {
+    const float* ap = As0 + buf * BUF_FLOATS + half * LDA + wm * 32 * TM + l31;
+    const float* bp = Bs0 + buf * BUF_FLOATS + half * LDB + wn * 32 * TN + l31;
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
       float a[TM], b[TN];
@@ -344,27 +351,27 @@ __global__ void __launch_bounds__(128 * WM * G) k_gather_gemm(const GemmArgs g) 
   // iteration `it` of group `grp` handles chunk c_begin + it*G + grp; all groups run `iters` iterations
   float4 a0[A_PASSES], b0[B_PASSES], a1[A_PASSES], b1[B_PASSES];
   auto chunk_of = [&](int it) { return c_begin + it * G + grp; };
-  if (iters > 0 && chunk_of(0) < c_end) prefetch(chunk_of(0), a0, b0);
-  if (iters > 1 && chunk_of(1) < c_end) prefetch(chunk_of(1), a1, b1);
+  auto valid = [&](int it) { return it < iters && chunk_of(it) < c_end; };
+  // software pipeline: global loads two chunks ahead (registers), LDS staging one chunk ahead (other buffer),
+  // MFMAs on the current buffer; ONE barrier per chunk
+  if (valid(0)) prefetch(chunk_of(0), a0, b0);
+  if (valid(1)) prefetch(chunk_of(1), a1, b1);
+  if (valid(0)) stage(0, a0, b0);
+  __syncthreads();
   for (int it = 0; it < iters; it += 2) {
-    {
-      const bool valid = chunk_of(it) < c_end;
-      if (valid) stage(a0, b0);
-      __syncthreads();
-      if (it + 2 < iters && chunk_of(it + 2) < c_end) prefetch(chunk_of(it + 2), a0, b0);
-      if (valid) compute();
-      __syncthreads();
-    }
+    if (valid(it + 2)) prefetch(chunk_of(it + 2), a0, b0);
+    if (valid(it)) compute(0);
+    if (valid(it + 1)) stage(1, a1, b1);
+    __syncthreads();
     if (it + 1 < iters) {
-      const bool valid = chunk_of(it + 1) < c_end;
-      if (valid) stage(a1, b1);
-      __syncthreads();
-      if (it + 3 < iters && chunk_of(it + 3) < c_end) prefetch(chunk_of(it + 3), a1, b1);
-      if (valid) compute();
+      if (valid(it + 3)) prefetch(chunk_of(it + 3), a1, b1);
+      if (valid(it + 1)) compute(1);
+      if (valid(it + 2)) stage(0, a0, b0);
       __syncthreads();
     }
   }
 
+  if (stamp) g.dbg[2] = __builtin_amdgcn_s_memtime();
   // ---- sum the K-groups through LDS in fixed order (the staging tiles are idle now)
   if (G > 1) {
     float* red = smem;
@@ -433,6 +440,7 @@ __global__ void __launch_bounds__(128 * WM * G) k_gather_gemm(const GemmArgs g) 
     }
   }
 
+  if (stamp) g.dbg[3] = __builtin_amdgcn_s_memtime();
   // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -460,6 +468,7 @@ __global__ void __launch_bounds__(128 * WM * G) k_gather_gemm(const GemmArgs g) 
         if (half == 0 && ncol && mrow0 < g.M) g.stats[(mrow0 >> 5) * g.N + n] = make_double2(s1, s2);
       }
     }
+  if (stamp) g.dbg[4] = __builtin_amdgcn_s_memtime();
 }
 
 // ---------------------------------------------------------------------------------------
@@ -530,7 +539,7 @@ static int launch_gemm(GemmArgs& g, int splits, hipStream_t s) {
   constexpr int GT = 128 * WM;
   constexpr int BM = 32 * WM * TM, BN = 64 * TN;
   constexpr int LDA = BM + 1, LDB = W_NK ? BN + 1 : BN;
-  constexpr int GROUP_FLOATS = ((BK * LDA + 3) / 4) * 4 + ((BK * LDB + 3) / 4) * 4;
+  constexpr int GROUP_FLOATS = 2 * (((BK * LDA + 3) / 4) * 4 + ((BK * LDB + 3) / 4) * 4);
   constexpr int ACC = TM * TN * 16;
   constexpr int RED_FLOATS = (G - 1) * ACC * GT;
   constexpr int REGION = (G * GROUP_FLOATS > RED_FLOATS) ? G * GROUP_FLOATS : RED_FLOATS;
@@ -575,6 +584,8 @@ static int dispatch(GemmArgs& g, const Plan& p, hipStream_t s) {
 
 // optional overrides for tuning / tests (0 = heuristic)
 static int g_force_tm = 0, g_force_tn = 0, g_force_groups = 0, g_force_splits = 0, g_force_wm = 0;
+static unsigned long long* g_dbg = nullptr;
+extern "C" void tln_gemm_debug_stamps(void* d_buf) { g_dbg = reinterpret_cast<unsigned long long*>(d_buf); }
 extern "C" void tln_gemm_force_tiles(int tm, int tn) {
   g_force_tm = tm;
   g_force_tn = tn;
@@ -600,7 +611,7 @@ static Plan make_plan(int64_t M, int N, int nchunks) {
     p.wm = 1;
     const int64_t tiles = nblk(32, 64);
     int splits = 1;
-    if (tiles < 160)
+    if (tiles < 64)  // the slab + release/acquire episode costs ~7 us (tools/gemm_stamps.py): only for very few tiles
       while (splits < 4 && tiles * splits * 2 <= 512 && nchunks >= 4 * (splits * 2)) splits *= 2;
     p.splits = splits;
     const int per = (nchunks + splits - 1) / splits;
@@ -650,6 +661,7 @@ extern "C" int tln_gather_gemm_ex(int64_t M, int N, const tln_gemm_src* s0, cons
   g.ld_out = ld_out;
   g.stats = reinterpret_cast<double2*>(d_stats);
   g.splits = 1;
+  g.dbg = g_dbg;
   hipStream_t s = (hipStream_t)stream_;
 
   bool vec = aligned16(d_w);

@@ -712,30 +712,33 @@ __global__ void __launch_bounds__(RADIX_TPB) k_radix_hist(const int32_t* __restr
   if (threadIdx.x < 256) hist[threadIdx.x * nblk + blockIdx.x] = cnt[threadIdx.x];
 }
 
-__global__ void __launch_bounds__(1024) k_radix_scan(int32_t* __restrict__ hist, int total) {
+// exclusive scan of the digit-major table hist[256][nblk], one block: thread (d, q) first sums a quarter of row d,
+// the 1024 partial sums are scanned across the block, then every thread rewrites its quarter as running offsets
+__global__ void __launch_bounds__(1024) k_radix_scan(int32_t* __restrict__ hist, int nblk) {
   __shared__ int wave_tot[16];
-  __shared__ int carry_s;
-  if (threadIdx.x == 0) carry_s = 0;
-  __syncthreads();
+  const int d = threadIdx.x >> 2, q = threadIdx.x & 3;
+  const int per = (nblk + 3) >> 2;
+  const int b0 = q * per, b1 = (b0 + per < nblk) ? b0 + per : nblk;
+  int32_t* row = hist + (int64_t)d * nblk;
+  int s = 0;
+  for (int b = b0; b < b1; ++b) s += row[b];
+  // block-wide exclusive scan of s in thread order (= digit-major, quarter-minor = memory order)
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  for (int base = 0; base < total; base += 1024) {
-    const int i = base + threadIdx.x;
-    const int v = (i < total) ? hist[i] : 0;
-    int incl = v;
+  int incl = s;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int u = __shfl_up(incl, o, 64);
-      if (lane >= o) incl += u;
-    }
-    if (lane == 63) wave_tot[wid] = incl;
-    __syncthreads();
-    int woff = 0;
-    for (int w = 0; w < wid; ++w) woff += wave_tot[w];
-    const int carry = carry_s;
-    if (i < total) hist[i] = carry + woff + incl - v;
-    __syncthreads();
-    if (threadIdx.x == 1023) carry_s = carry + woff + incl;
-    __syncthreads();
+  for (int o = 1; o < 64; o <<= 1) {
+    const int u = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += u;
+  }
+  if (lane == 63) wave_tot[wid] = incl;
+  __syncthreads();
+  int woff = 0;
+  for (int w = 0; w < wid; ++w) woff += wave_tot[w];
+  int run = woff + incl - s;
+  for (int b = b0; b < b1; ++b) {
+    const int v = row[b];
+    row[b] = run;
+    run += v;
   }
 }
 
@@ -801,7 +804,7 @@ static int radix_sort_pairs(tln_lattice* l, int64_t rows, int bits, hipStream_t 
     int32_t* dst_k = to_out ? l->sk_out : tmp_k;
     int32_t* dst_v = to_out ? l->sv_out : tmp_v;
     hipLaunchKernelGGL(k_radix_hist, dim3(nblk), dim3(RADIX_TPB), 0, s, src_k, rows, 8 * p, nblk, hist);
-    hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(1024), 0, s, hist, 256 * nblk);
+    hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(1024), 0, s, hist, nblk);
     hipLaunchKernelGGL(k_radix_scatter, dim3(nblk), dim3(RADIX_TPB), 0, s, src_k, src_v, rows, 8 * p, nblk, hist, dst_k,
                        dst_v);
     src_k = dst_k;
