@@ -56,6 +56,12 @@ int tln_distribute(tln_lattice_t* l, const float* d_positions, const float* d_va
 /* rebuild the CSR from caller-supplied indices (R rows, -1 folded into the tail bucket) */
 int tln_build_csr(tln_lattice_t* l, const int32_t* d_indices, int64_t rows, void* stream);
 
+/* copy the handle's CSR out (any pointer may be NULL): order[rows] = row ids sorted stably by vertex,
+ * sorted_vertex[rows] (rejected rows carry V), seg_start[V+2]; *rows_out = rows of the last build (0 = none).
+ * The reference keeps no such structure (torch_scatter works on the unsorted rows, lm:485); test/debug surface. */
+int tln_lattice_csr(tln_lattice_t* l, int32_t* d_order, int32_t* d_sorted_vertex, int32_t* d_seg_start,
+                    int64_t* rows_out, void* stream);
+
 /* ---- K2 PointNet pool: PointNetSeqModule.forward lm:448-530 --------------------------- */
 /* per-row MLP (nr_layers linears, ReLU between) on distributed[:, :cin] then segment-max by
  * vertex with argmax, barycentric-of-argmax (with the lm:514 clamp quirk), <min_points mask.
@@ -128,6 +134,9 @@ void tln_gemm_force_tiles(int tm, int tn);
 void tln_gemm_force_groups(int groups);
 /* tuning hook: force the split-K slices over the grid and the tile height (wm: 1 = 32 rows, 2 = 64 rows) */
 void tln_gemm_force_splits(int splits, int wm);
+/* tuning hook: the small-M "direct" kernel (operands from global memory, no LDS tiles): 0 = heuristic,
+ * 1 = whenever the shape is eligible (channels multiple of 32, aligned), -1 = never */
+void tln_gemm_force_direct(int mode);
 /* diagnostic hook: block (0,0,0) of every following gather-GEMM writes five s_memtime stamps (start, after the
  * index/GroupNorm prologue, after the K loop, after the reductions, end) to d_buf (5 x u64); NULL switches it off */
 void tln_gemm_debug_stamps(void* d_buf);

@@ -46,6 +46,7 @@ _PROTOS = {
     "tln_lattice_insert_keys": (_i, [_vp, _vp, _i64, _vp, _vp]),
     "tln_distribute": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp]),
     "tln_build_csr": (_i, [_vp, _vp, _i64, _vp]),
+    "tln_lattice_csr": (_i, [_vp, _vp, _vp, _vp, C.POINTER(_i64), _vp]),
     "tln_pointnet_pool": (_i, [_vp, _vp, _i64, _i, _i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i), _i, _vp, _vp]),
     "tln_pointnet_pool_ex": (_i, [_vp, _vp, _i64, _i, _i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i), _i, _vp, _vp, _vp]),
     "tln_neighbour_table": (_i, [_vp, C.POINTER(_vp), _vp]),
@@ -57,6 +58,7 @@ _PROTOS = {
     "tln_gemm_force_tiles": (None, [_i, _i]),
     "tln_gemm_force_groups": (None, [_i]),
     "tln_gemm_force_splits": (None, [_i, _i]),
+    "tln_gemm_force_direct": (None, [_i]),
     "tln_gemm_debug_stamps": (None, [_vp]),
     "tln_gather_gemm_ex": (_i, [_i64, _i, C.POINTER(GemmSrc), C.POINTER(GemmSrc), _vp, _i, _vp, _vp, _i64, _i, _vp, _i64, _vp, _vp]),
     "tln_gn_gather_gemm": (_i, [C.POINTER(GnDesc), _i64, _i, C.POINTER(GemmSrc), C.POINTER(GemmSrc), _vp, _i, _vp, _vp, _i64, _i, _vp, _i64, _vp, _vp]),

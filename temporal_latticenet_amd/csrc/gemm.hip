@@ -472,6 +472,283 @@ __global__ void __launch_bounds__(128 * WM * G) k_gather_gemm(const GemmArgs g) 
 }
 
 // ---------------------------------------------------------------------------------------
+// Small-M variant ("direct"): a lattice level of a few thousand vertices gives ~75 row tiles, far too few to fill
+// 256 CUs with LDS-staged tiles, and nothing is shared between waves at that size anyway.  Here one WAVE owns a
+// 32x32 output tile for a subset of the K chunks and feeds the matrix cores straight from global memory:
+//   * A: lane (row = lane&31, half = lane>>5) loads the 16 channels c0 + 16*half .. +15 of its gathered row as
+//        4 x dwordx4 — exactly its operands of the 16 MFMAs of the chunk (the k order inside a chunk is permuted,
+//        identically for A and B, which the product does not see); no LDS round trip, no transposition, no barrier
+//   * B: [K,N] weights: 16 coalesced dword loads (row c0+16*half+s, column n0 + lane&31); [N,K] weights: 4 x dwordx4
+//   * G waves per block interleave over the chunk list (G = blockDim/64, up to 8) and are summed through LDS in
+//     fixed order; chunk loads run DEPTH chunks ahead in registers
+//   * the tap indices of a lane's row sit in 9 registers; the GroupNorm finalise of the prologue runs while the
+//     first chunk loads are in flight, with all threads sharing the partial-sum reduction
+// Same arithmetic per output as the tiled kernel up to the order of the K summation (chunk interleave).
+// ---------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define TLN_DIRECT_DEPTH 2
+
+template <bool W_NK>
+__global__ void __launch_bounds__(512) k_gather_gemm_direct(const GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int T = blockDim.x, G = T >> 6;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int64_t m0 = (int64_t)blockIdx.x * 32;
+  const int n0 = blockIdx.y * 32;
+  const int64_t m = m0 + l31;
+  const bool mrow = m < g.M;
+  const int n = n0 + l31;
+  const bool ncol = n < g.N;
+
+  // LDS: [region: max(K-group reduction, GroupNorm partial scratch)] [Gsc cin0] [Gsh cin0] [Gch cin0 double2]
+  const int cin0 = g.s[0].cin;
+  const bool gn_lds = g.s[0].gn_part != nullptr;
+  const bool pro_lds = gn_lds || g.s[0].scale != nullptr;
+  int region = (G - 1) * 16 * 64;
+  int J = 1;
+  if (gn_lds) {
+    J = T / cin0;
+    if (J < 1) J = 1;
+    if (J > g.s[0].gn_nblk) J = g.s[0].gn_nblk;
+    const int need = J * cin0 * 4;  // double2 = 4 floats
+    if (need > region) region = need;
+  }
+  float* Gsc = smem + region;
+  float* Gsh = Gsc + cin0;
+  double2* Gch = reinterpret_cast<double2*>(Gsh + cin0);
+
+  const bool stamp = g.dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0;
+  if (stamp) g.dbg[0] = __builtin_amdgcn_s_memtime();
+
+  // tap indices of the block's 32 rows (source 0): one contiguous 1152-byte span of the table -> LDS
+  const int64_t mc = mrow ? m : g.M - 1;  // rows past M work on row M-1 (their outputs are never stored)
+  int* Is = reinterpret_cast<int*>(Gch + cin0);
+  if (g.s[0].table != nullptr) {
+    const int64_t lim = g.M * TLN_TAPS;
+    for (int i = threadIdx.x; i < 32 * TLN_TAPS; i += T) {
+      const int64_t at = m0 * TLN_TAPS + i;
+      Is[i] = at < lim ? g.s[0].table[at] : -1;
+    }
+    __syncthreads();
+  }
+
+  const int cpt0 = cin0 >> 5;
+  const int nch0 = g.s[0].taps * cpt0;
+  const int cpt1 = g.nsrc > 1 ? (g.s[1].cin >> 5) : 1;
+  const int nch1 = g.nsrc > 1 ? g.s[1].taps * cpt1 : 0;
+  const int nchunks = nch0 + nch1;
+  const int iters = (nchunks + G - 1) / G;  // every wave runs the same count; a chunk index past the list is
+                                            // clamped and its A operand zeroed (adds exact zeros)
+  const unsigned nc = (unsigned)(ncol ? n : g.N - 1);  // columns past N are computed on column N-1, never stored
+
+  f32x4 a[TLN_DIRECT_DEPTH][4];
+  float b[TLN_DIRECT_DEPTH][16];
+  int meta[TLN_DIRECT_DEPTH];  // mode (0 zero row, 1 data, 2 pad) | source << 2 | c0 << 3
+
+  // branch-free: every address is clamped into range, the mode decides afterwards what the values mean
+  auto load = [&](int t_raw, f32x4 (&av)[4], float (&bv)[16], int& mt) {
+    const bool live = t_raw < nchunks;
+    const int t = live ? t_raw : nchunks - 1;
+    const int si = (t < nch0) ? 0 : 1;
+    const float* src = si ? g.s[1].src : g.s[0].src;
+    const int32_t* table = si ? g.s[1].table : g.s[0].table;
+    const int64_t src_rows = si ? g.s[1].src_rows : g.s[0].src_rows;
+    const int64_t ld = si ? g.s[1].ld : g.s[0].ld;
+    const int cin = si ? g.s[1].cin : cin0;
+    const int tt = si ? t - nch0 : t;
+    const int cpt = si ? cpt1 : cpt0;
+    const int tap = tt / cpt;
+    const int c0 = (tt - tap * cpt) << 5;
+    const int kb = (si ? g.K0 : 0) + tap * cin + c0;  // first K row of the chunk (wave-uniform)
+    int64_t srow = mc;
+    if (table != nullptr) {
+      srow = (si == 0) ? Is[l31 * TLN_TAPS + tap] : table[mc * TLN_TAPS + tap];
+    }
+    const int mode = (!live || srow < 0) ? 0 : (srow >= src_rows ? 2 : 1);
+    mt = mode | (si << 2) | (c0 << 3);
+    const int64_t sr = mode == 1 ? srow : 0;
+    const f32x4* ap = reinterpret_cast<const f32x4*>(src + sr * ld + c0 + 16 * half);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) av[q] = ap[q];
+    if (!W_NK) {
+      const unsigned loff = (unsigned)(16 * half) * (unsigned)g.ldw + nc;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const float* wq = g.W + (int64_t)(kb + q) * g.ldw;
+        bv[q] = wq[loff];
+      }
+    } else {
+      const f32x4* wp = reinterpret_cast<const f32x4*>(g.W + (int64_t)nc * g.ldw + kb + 16 * half);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 v = wp[q];
+        bv[4 * q] = v[0];
+        bv[4 * q + 1] = v[1];
+        bv[4 * q + 2] = v[2];
+        bv[4 * q + 3] = v[3];
+      }
+    }
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+
+  const int relu0 = g.s[0].relu, relu1 = g.nsrc > 1 ? g.s[1].relu : 0;
+  const float pad0 = g.s[0].pad, pad1 = g.nsrc > 1 ? g.s[1].pad : 0.f;
+  auto compute = [&](const f32x4 (&av)[4], const float (&bv)[16], int mt) {
+    const int mode = mt & 3, si = (mt >> 2) & 1, c0 = mt >> 3;
+    const int cb = c0 + 16 * half;
+    float x[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      x[4 * q] = av[q][0];
+      x[4 * q + 1] = av[q][1];
+      x[4 * q + 2] = av[q][2];
+      x[4 * q + 3] = av[q][3];
+    }
+    if (si == 0 && pro_lds) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(Gsc + cb + 4 * q);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(Gsh + cb + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[4 * q + e] = fmaf(x[4 * q + e], sc[e], sh[e]);
+      }
+    }
+    // ReLU as max(x, floor): floor = 0 with the activation, -inf without (wave-uniform)
+    const float floor_v = (si ? relu1 : relu0) ? 0.f : -__builtin_inff();
+    // a missing neighbour stays an exact zero row, a row past the source is the pad value (no activation)
+    const float other = (mode == 2) ? (si ? pad1 : pad0) : 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) x[q] = (mode == 1) ? fmaxf(x[q], floor_v) : other;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x[q], bv[q], acc, 0, 0, 0);
+  };
+
+  if (stamp) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    g.dbg[5] = __builtin_amdgcn_s_memtime();
+  }
+  // first chunks in flight before the GroupNorm finalise
+#pragma unroll
+  for (int d = 0; d < TLN_DIRECT_DEPTH; ++d) load(wv + d * G, a[d], b[d], meta[d]);
+  if (stamp) g.dbg[6] = __builtin_amdgcn_s_memtime();
+
+  if (gn_lds) {
+    const SrcDev& s = g.s[0];
+    double2* Gp = reinterpret_cast<double2*>(smem);  // [J][cin0]
+    for (int idx = threadIdx.x; idx < J * cin0; idx += T) {
+      const int c = idx % cin0, j = idx / cin0;
+      double sx[2] = {0.0, 0.0}, sq[2] = {0.0, 0.0};
+      int bb = j;
+      for (; bb + J < s.gn_nblk; bb += 2 * J) {  // two independent chains, fixed order
+        const double2 p0 = s.gn_part[(int64_t)bb * cin0 + c];
+        const double2 p1 = s.gn_part[(int64_t)(bb + J) * cin0 + c];
+        sx[0] += p0.x;
+        sq[0] += p0.y;
+        sx[1] += p1.x;
+        sq[1] += p1.y;
+      }
+      if (bb < s.gn_nblk) {
+        const double2 p0 = s.gn_part[(int64_t)bb * cin0 + c];
+        sx[0] += p0.x;
+        sq[0] += p0.y;
+      }
+      Gp[idx] = make_double2(sx[0] + sx[1], sq[0] + sq[1]);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < cin0; c += T) {
+      double sx = 0.0, sq = 0.0;
+      for (int j = 0; j < J; ++j) {
+        sx += Gp[j * cin0 + c].x;
+        sq += Gp[j * cin0 + c].y;
+      }
+      Gch[c] = make_double2(sx, sq);
+    }
+    __syncthreads();
+    const int cpg = cin0 / s.gn_groups;
+    for (int c = threadIdx.x; c < cin0; c += T) {
+      const int g0 = (c / cpg) * cpg;
+      double sx = 0.0, sq = 0.0;
+      for (int j = 0; j < cpg; ++j) {
+        sx += Gch[g0 + j].x;
+        sq += Gch[g0 + j].y;
+      }
+      const double cnt = (double)s.gn_rows * (double)cpg;
+      const double mean = sx / cnt;
+      double var = sq / cnt - mean * mean;
+      if (var < 0.0) var = 0.0;
+      const double rstd = 1.0 / sqrt(var + (double)s.gn_eps);
+      const double gm = s.gn_gamma ? (double)s.gn_gamma[c] : 1.0;
+      const double bt = s.gn_beta ? (double)s.gn_beta[c] : 0.0;
+      Gsc[c] = (float)(gm * rstd);
+      Gsh[c] = (float)(bt - mean * rstd * gm);
+    }
+    __syncthreads();
+  } else if (g.s[0].scale) {
+    for (int c = threadIdx.x; c < cin0; c += T) {
+      Gsc[c] = g.s[0].scale[c];
+      Gsh[c] = g.s[0].shift[c];
+    }
+    __syncthreads();
+  }
+  if (stamp) g.dbg[1] = __builtin_amdgcn_s_memtime();
+
+  // main loop: compute slot d, refill it DEPTH chunks ahead; then drain without loads
+  int it = 0;
+  for (; it + TLN_DIRECT_DEPTH < iters; it += TLN_DIRECT_DEPTH) {
+#pragma unroll
+    for (int d = 0; d < TLN_DIRECT_DEPTH; ++d) {
+      compute(a[d], b[d], meta[d]);
+      load(wv + (it + d + TLN_DIRECT_DEPTH) * G, a[d], b[d], meta[d]);
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < TLN_DIRECT_DEPTH; ++d)
+    if (it + d < iters) compute(a[d], b[d], meta[d]);
+  if (stamp) g.dbg[2] = __builtin_amdgcn_s_memtime();
+
+  // ---- sum the waves through LDS in fixed order 0..G-1 (the GroupNorm scratch is dead: every wave passed the
+  // barrier after its last use)
+  if (G > 1) {
+    float* red = smem;
+    if (wv > 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[((wv - 1) * 16 + r) * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    if (wv > 0) return;
+    for (int gg = 1; gg < G; ++gg)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] += red[((gg - 1) * 16 + r) * 64 + lane];
+  }
+  if (stamp) g.dbg[3] = __builtin_amdgcn_s_memtime();
+
+  // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const float bias = (ncol && g.bias) ? g.bias[n] : 0.f;
+  double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int64_t mr = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    if (!ncol || mr >= g.M) continue;
+    float v = acc[r] + bias;
+    if (g.res) v += g.res[mr * g.ld_res + n];
+    if (g.relu) v = fmaxf(v, 0.f);
+    g.out[mr * g.ld_out + n] = v;
+    s1 += (double)v;
+    s2 += (double)v * (double)v;
+  }
+  if (g.stats) {
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    if (half == 0 && ncol) g.stats[(m0 >> 5) * g.N + n] = make_double2(s1, s2);
+  }
+  if (stamp) g.dbg[4] = __builtin_amdgcn_s_memtime();
+}
+
+// ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -582,7 +859,33 @@ static int dispatch(GemmArgs& g, const Plan& p, hipStream_t s) {
   return launch_gemm<2, 1, 1, BK, 1, W_NK, true>(g, p.splits, s);
 }
 
+template <bool W_NK>
+static int launch_direct(GemmArgs& g, int nchunks, int groups, hipStream_t s) {
+  int G = groups;
+  if (G < 1) G = 1;
+  if (G > 8) G = 8;
+  if (G > nchunks) G = nchunks;
+  const int T = 64 * G;
+  const int cin0 = g.s[0].cin;
+  size_t region = (size_t)(G - 1) * 16 * 64;
+  if (g.s[0].gn_part) {
+    int J = T / cin0;
+    if (J < 1) J = 1;
+    if (J > g.s[0].gn_nblk) J = g.s[0].gn_nblk;
+    const size_t need = (size_t)J * cin0 * 4;
+    if (need > region) region = need;
+  }
+  const size_t lds = (region + (size_t)6 * cin0 + 32 * TLN_TAPS + 4) * sizeof(float);
+  TLN_REQUIRE(lds <= 64 * 1024, "direct gemm: LDS %zu B", lds);
+  dim3 grid((unsigned)tln_cdiv(g.M, 32), (unsigned)tln_cdiv(g.N, 32), 1);
+  g.splits = 1;
+  hipLaunchKernelGGL(k_gather_gemm_direct<W_NK>, grid, dim3(T), lds, s, g);
+  return TLN_OK;
+}
+
 // optional overrides for tuning / tests (0 = heuristic)
+static int g_force_direct = 0;  // 0 heuristic, 1 always when eligible, -1 never
+extern "C" void tln_gemm_force_direct(int mode) { g_force_direct = mode; }
 static int g_force_tm = 0, g_force_tn = 0, g_force_groups = 0, g_force_splits = 0, g_force_wm = 0;
 static unsigned long long* g_dbg = nullptr;
 extern "C" void tln_gemm_debug_stamps(void* d_buf) { g_dbg = reinterpret_cast<unsigned long long*>(d_buf); }
@@ -692,6 +995,25 @@ extern "C" int tln_gather_gemm_ex(int64_t M, int N, const tln_gemm_src* s0, cons
   int nchunks = 0;
   for (int i = 0; i < g.nsrc; ++i) nchunks += g.s[i].taps * ((g.s[i].cin + bk - 1) / bk);
   const Plan p = make_plan(M, N, nchunks);
+  // small M: one wave per 32x32 tile and K subset, operands straight from global memory
+  bool direct_ok = bk32 && g.s[0].cin <= 1024 && tln_cdiv(N, 32) <= 65535;
+  for (int i = 0; i < g.nsrc; ++i) {
+    const SrcDev& d = g.s[i];
+    direct_ok = direct_ok && d.src_rows >= 1 && (d.table == nullptr || d.taps == TLN_TAPS);
+    if (i > 0) direct_ok = direct_ok && d.scale == nullptr;  // only source 0 carries a prologue there
+  }
+  const bool direct_small = p.wm == 1;
+  if (direct_ok && g_force_direct >= 0 && (direct_small || g_force_direct > 0)) {
+    // enough waves to cover the SIMDs a few times over, 2..8 chunks per wave
+    const int64_t tiles = tln_cdiv(M, 32) * tln_cdiv(N, 32);
+    int G = g_force_groups ? g_force_groups : 1;
+    if (!g_force_groups)
+      while (G < 8 && nchunks >= 3 * (G + 1) && tiles * G < 4096) ++G;
+    rc = w_is_nk ? launch_direct<true>(g, nchunks, G, s) : launch_direct<false>(g, nchunks, G, s);
+    if (rc) return rc;
+    TLN_LAUNCH_CHECK();
+    return TLN_OK;
+  }
   if (bk32) rc = w_is_nk ? dispatch<32, true>(g, p, s) : dispatch<32, false>(g, p, s);
   else rc = w_is_nk ? dispatch<16, true>(g, p, s) : dispatch<16, false>(g, p, s);
   if (rc) return rc;

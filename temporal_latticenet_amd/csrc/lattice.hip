@@ -112,8 +112,12 @@ static int ensure_rows(tln_lattice* l, int64_t rows) {
   TLN_HIP(hipMalloc(&l->sv_out, cap * sizeof(int32_t)));
   TLN_HIP(hipMalloc(&l->pieces, (cap / 256 + 2) * 6 * sizeof(double)));
   // radix-sort scratch: ping-pong keys + values and the [256][blocks] digit histogram
-  const size_t bytes = (size_t)cap * 2 * sizeof(int32_t) + (size_t)256 * (cap / 4096 + 2) * sizeof(int32_t);
+  // + the 256 digit bases and the arrival counter of the fused table scan (counter starts, and is left, at zero)
+  const size_t hist_ints = (size_t)256 * (cap / 4096 + 2);
+  const size_t bytes = (size_t)cap * 2 * sizeof(int32_t) + (hist_ints + 256 + 16) * sizeof(int32_t);
   TLN_HIP(hipMalloc(&l->sort_temp, bytes));
+  TLN_HIP(hipMemset(l->sort_temp, 0, bytes));
+  TLN_HIP(hipDeviceSynchronize());
   l->sort_temp_bytes = bytes;
   l->rows_cap = cap;
   return TLN_OK;
@@ -687,9 +691,8 @@ __global__ void __launch_bounds__(256) k_seg_start(const int32_t* __restrict__ s
 }
 
 // ---------------------------------------------------------------------------------------
-// stable LSD radix sort of (vertex index, row id) pairs, 8 bits per pass, three launches per pass:
-//   k_radix_hist    per-block digit counts                      -> hist[digit][block]
-//   k_radix_scan    exclusive scan of the digit-major table (one block)
+// stable LSD radix sort of (vertex index, row id) pairs, 8 bits per pass, two launches per pass:
+//   k_radix_hist    per-block digit counts -> hist[digit][block]; the last block to arrive scans the table
 //   k_radix_scatter ranks inside a wave by ballot multi-split (8 ballots), waves ordered through LDS,
 //                   blocks ordered through the scanned table => stable
 // The keys are vertex indices (< V+1), so a 120k-point frame on a few thousand vertices needs two passes.
@@ -697,9 +700,84 @@ __global__ void __launch_bounds__(256) k_seg_start(const int32_t* __restrict__ s
 #define RADIX_KPB 4096   // keys per block
 #define RADIX_TPB 1024   // threads per block (16 waves)
 
+// Exclusive scan of the digit-major table hist[256][nblk] by one 1024-thread block: wave w owns digit rows
+// 16w..16w+15, scans each along the blocks (coalesced, 64 entries per step) and leaves the within-row exclusive
+// scan in place; the 256 row totals are then scanned into dbase[256]. The scatter adds the two.
+__device__ __forceinline__ void radix_scan_table(int32_t* __restrict__ hist, int nblk, int32_t* __restrict__ dbase,
+                                                 int* tot /* LDS [256] */) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (nblk <= 128) {
+    // the usual case (<= 524k rows): all 32 loads of the wave's 16 rows in flight at once
+    int v0[16], v1[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int32_t* row = hist + (int64_t)(wid * 16 + r) * nblk;
+      v0[r] = (lane < nblk) ? __builtin_nontemporal_load(row + lane) : 0;
+      v1[r] = (lane + 64 < nblk) ? __builtin_nontemporal_load(row + lane + 64) : 0;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int32_t* row = hist + (int64_t)(wid * 16 + r) * nblk;
+      int i0 = v0[r], i1 = v1[r];
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int u0 = __shfl_up(i0, o, 64), u1 = __shfl_up(i1, o, 64);
+        if (lane >= o) {
+          i0 += u0;
+          i1 += u1;
+        }
+      }
+      const int c0 = __shfl(i0, 63, 64);
+      if (lane < nblk) row[lane] = i0 - v0[r];
+      if (lane + 64 < nblk) row[lane + 64] = c0 + i1 - v1[r];
+      if (lane == 63) tot[wid * 16 + r] = c0 + i1;
+    }
+  } else {
+#pragma unroll 4
+    for (int r = 0; r < 16; ++r) {
+      const int d = wid * 16 + r;
+      int32_t* row = hist + (int64_t)d * nblk;
+      int carry = 0;
+      for (int b0 = 0; b0 < nblk; b0 += 64) {
+        const int b = b0 + lane;
+        const int v = (b < nblk) ? __builtin_nontemporal_load(row + b) : 0;
+        int incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const int u = __shfl_up(incl, o, 64);
+          if (lane >= o) incl += u;
+        }
+        if (b < nblk) row[b] = carry + incl - v;
+        carry += __shfl(incl, 63, 64);
+      }
+      if (lane == 0) tot[d] = carry;
+    }
+  }
+  __syncthreads();
+  if (wid == 0) {
+    // 256 totals, 4 per lane, exclusive
+    const int t0 = tot[4 * lane], t1 = tot[4 * lane + 1], t2 = tot[4 * lane + 2], t3 = tot[4 * lane + 3];
+    const int s4 = t0 + t1 + t2 + t3;
+    int incl = s4;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int u = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += u;
+    }
+    const int e = incl - s4;
+    dbase[4 * lane] = e;
+    dbase[4 * lane + 1] = e + t0;
+    dbase[4 * lane + 2] = e + t0 + t1;
+    dbase[4 * lane + 3] = e + t0 + t1 + t2;
+  }
+}
+
+// per-block digit counts -> hist[digit][block]; the block that arrives last scans the table (no extra launch)
 __global__ void __launch_bounds__(RADIX_TPB) k_radix_hist(const int32_t* __restrict__ keys, int64_t n, int shift,
-                                                          int nblk, int32_t* __restrict__ hist) {
+                                                          int nblk, int32_t* __restrict__ hist,
+                                                          int32_t* __restrict__ dbase, unsigned* __restrict__ arrive) {
   __shared__ int cnt[256];
+  __shared__ int is_last;
   if (threadIdx.x < 256) cnt[threadIdx.x] = 0;
   __syncthreads();
   const int64_t base = (int64_t)blockIdx.x * RADIX_KPB;
@@ -709,48 +787,32 @@ __global__ void __launch_bounds__(RADIX_TPB) k_radix_hist(const int32_t* __restr
     if (i < n) atomicAdd(&cnt[(keys[i] >> shift) & 255], 1);
   }
   __syncthreads();
-  if (threadIdx.x < 256) hist[threadIdx.x * nblk + blockIdx.x] = cnt[threadIdx.x];
-}
-
-// exclusive scan of the digit-major table hist[256][nblk], one block: thread (d, q) first sums a quarter of row d,
-// the 1024 partial sums are scanned across the block, then every thread rewrites its quarter as running offsets
-__global__ void __launch_bounds__(1024) k_radix_scan(int32_t* __restrict__ hist, int nblk) {
-  __shared__ int wave_tot[16];
-  const int d = threadIdx.x >> 2, q = threadIdx.x & 3;
-  const int per = (nblk + 3) >> 2;
-  const int b0 = q * per, b1 = (b0 + per < nblk) ? b0 + per : nblk;
-  int32_t* row = hist + (int64_t)d * nblk;
-  int s = 0;
-  for (int b = b0; b < b1; ++b) s += row[b];
-  // block-wide exclusive scan of s in thread order (= digit-major, quarter-minor = memory order)
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  int incl = s;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int u = __shfl_up(incl, o, 64);
-    if (lane >= o) incl += u;
-  }
-  if (lane == 63) wave_tot[wid] = incl;
+  if (threadIdx.x < 256)
+    __hip_atomic_store(&hist[threadIdx.x * nblk + blockIdx.x], cnt[threadIdx.x], __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave's counts are in L2 before thread 0 announces
   __syncthreads();
-  int woff = 0;
-  for (int w = 0; w < wid; ++w) woff += wave_tot[w];
-  int run = woff + incl - s;
-  for (int b = b0; b < b1; ++b) {
-    const int v = row[b];
-    row[b] = run;
-    run += v;
+  if (threadIdx.x == 0) {
+    const unsigned prev = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = (prev == (unsigned)nblk - 1u);
   }
+  __syncthreads();
+  if (!is_last) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  radix_scan_table(hist, nblk, dbase, cnt);
+  if (threadIdx.x == 0) __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __global__ void __launch_bounds__(RADIX_TPB) k_radix_scatter(const int32_t* __restrict__ keys_in,
                                                              const int32_t* __restrict__ vals_in, int64_t n, int shift,
                                                              int nblk, const int32_t* __restrict__ hist,
+                                                             const int32_t* __restrict__ dbase,
                                                              int32_t* __restrict__ keys_out,
                                                              int32_t* __restrict__ vals_out) {
   __shared__ int base[256];            // running output position per digit for this block
   __shared__ int wcount[16][256];      // per-wave digit counts, then per-wave bases
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  if (threadIdx.x < 256) base[threadIdx.x] = hist[threadIdx.x * nblk + blockIdx.x];
+  if (threadIdx.x < 256) base[threadIdx.x] = hist[threadIdx.x * nblk + blockIdx.x] + dbase[threadIdx.x];
   const int64_t blk0 = (int64_t)blockIdx.x * RADIX_KPB;
   for (int it = 0; it < RADIX_KPB / RADIX_TPB; ++it) {
     for (int k = threadIdx.x; k < 16 * 256; k += RADIX_TPB) (&wcount[0][0])[k] = 0;
@@ -795,6 +857,8 @@ static int radix_sort_pairs(tln_lattice* l, int64_t rows, int bits, hipStream_t 
   int32_t* tmp_k = reinterpret_cast<int32_t*>(l->sort_temp);
   int32_t* tmp_v = tmp_k + l->rows_cap;
   int32_t* hist = tmp_v + l->rows_cap;
+  int32_t* dbase = hist + (size_t)256 * (l->rows_cap / 4096 + 2);
+  unsigned* arrive = reinterpret_cast<unsigned*>(dbase + 256);
   const int passes = (bits + 7) / 8;
   // ping-pong so that the LAST pass lands in sk_out / sv_out
   const int32_t* src_k = l->sk_in;
@@ -803,10 +867,9 @@ static int radix_sort_pairs(tln_lattice* l, int64_t rows, int bits, hipStream_t 
     const bool to_out = ((passes - 1 - p) % 2) == 0;
     int32_t* dst_k = to_out ? l->sk_out : tmp_k;
     int32_t* dst_v = to_out ? l->sv_out : tmp_v;
-    hipLaunchKernelGGL(k_radix_hist, dim3(nblk), dim3(RADIX_TPB), 0, s, src_k, rows, 8 * p, nblk, hist);
-    hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(1024), 0, s, hist, nblk);
-    hipLaunchKernelGGL(k_radix_scatter, dim3(nblk), dim3(RADIX_TPB), 0, s, src_k, src_v, rows, 8 * p, nblk, hist, dst_k,
-                       dst_v);
+    hipLaunchKernelGGL(k_radix_hist, dim3(nblk), dim3(RADIX_TPB), 0, s, src_k, rows, 8 * p, nblk, hist, dbase, arrive);
+    hipLaunchKernelGGL(k_radix_scatter, dim3(nblk), dim3(RADIX_TPB), 0, s, src_k, src_v, rows, 8 * p, nblk, hist, dbase,
+                       dst_k, dst_v);
     src_k = dst_k;
     src_v = dst_v;
   }
@@ -844,6 +907,22 @@ extern "C" int tln_build_csr(tln_lattice_t* l, const int32_t* d_indices, int64_t
                      (int32_t)l->nr_vertices, l->sk_in, l->sv_in);
   TLN_LAUNCH_CHECK();
   return build_csr_sorted(l, rows, s);
+}
+
+// read the CSR back (tests, debugging): order[rows], sorted_vertex[rows] (tail bucket = V), seg_start[V+2]
+extern "C" int tln_lattice_csr(tln_lattice_t* l, int32_t* d_order, int32_t* d_sorted_vertex, int32_t* d_seg_start,
+                               int64_t* rows_out, void* stream_) {
+  TLN_REQUIRE(l && rows_out, "bad csr read-out arguments");
+  hipStream_t s = (hipStream_t)stream_;
+  *rows_out = l->csr_rows;
+  if (l->csr_rows <= 0) return TLN_OK;
+  if (d_order) TLN_HIP(hipMemcpyAsync(d_order, l->sv_out, l->csr_rows * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+  if (d_sorted_vertex)
+    TLN_HIP(hipMemcpyAsync(d_sorted_vertex, l->sk_out, l->csr_rows * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+  if (d_seg_start)
+    TLN_HIP(hipMemcpyAsync(d_seg_start, l->seg_start, (l->nr_vertices + 2) * sizeof(int32_t),
+                           hipMemcpyDeviceToDevice, s));
+  return TLN_OK;
 }
 
 // ---------------------------------------------------------------------------------------

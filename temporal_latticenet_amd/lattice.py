@@ -239,6 +239,22 @@ class Lattice:
         self._csr_key = (indices, indices._version)
         return distributed, indices, weights
 
+    def csr(self):
+        """(order, sorted_vertex, seg_start) of the native CSR left by the last distribute / ensure_csr: row ids
+        sorted stably by vertex, rejected rows in the tail bucket V.  Test / debug read-out."""
+        import ctypes
+        rows = ctypes.c_int64(0)
+        _lib.check(_lib.lib().tln_lattice_csr(self._h, None, None, None, ctypes.byref(rows), stream_ptr()),
+                   "tln_lattice_csr")
+        r = rows.value
+        order = torch.empty((r,), dtype=torch.int32, device="cuda")
+        sv = torch.empty((r,), dtype=torch.int32, device="cuda")
+        seg = torch.empty((self.nr_lattice_vertices() + 2,), dtype=torch.int32, device="cuda")
+        if r:
+            _lib.check(_lib.lib().tln_lattice_csr(self._h, _ptr(order), _ptr(sv), _ptr(seg), ctypes.byref(rows),
+                                                  stream_ptr()), "tln_lattice_csr")
+        return order, sv, seg
+
     def ensure_csr(self, indices):
         k = self._csr_key
         if k is not None and k[0] is indices and k[1] == indices._version:

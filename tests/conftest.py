@@ -20,3 +20,14 @@ def gpu():
     from temporal_latticenet_amd import _lib
     _lib.lib()  # raises if the extension was not built: GPU tests never run on a fallback
     return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def _seeded():
+    """every test starts from the same RNG state: the modules' default initialisation (kaiming-uniform through
+    torch's global generator) must not differ from run to run"""
+    import numpy as np
+    import torch
+    torch.manual_seed(20240607)
+    np.random.seed(20240607)
+    yield

@@ -22,7 +22,39 @@ def _run_sequence(gpu, seq, sigma, capacity, subtract_mean=True):
         od, oi, ow = O.distribute(tab, pos, val, [sigma] * 3, subtract_mean)
         outs.append((d.cpu().numpy(), i.cpu().numpy(), w.cpu().numpy(), od, oi, ow))
         assert lat.nr_lattice_vertices() == tab.nr_vertices
+        _check_csr(lat, oi)
     return lat, tab, outs
+
+
+def _check_csr(lat, indices):
+    """the handle's CSR == numpy's stable sort of the rows by vertex (rejected rows in the tail bucket V)"""
+    V = lat.nr_lattice_vertices()
+    key = np.where(indices < 0, V, indices).astype(np.int64)
+    want_order = np.argsort(key, kind="stable").astype(np.int32)
+    order, sv, seg = (x.cpu().numpy() for x in lat.csr())
+    assert np.array_equal(order, want_order), "CSR order must be the stable sort of the rows by vertex"
+    assert np.array_equal(sv, key[want_order].astype(np.int32))
+    assert np.array_equal(seg, np.searchsorted(key[want_order], np.arange(V + 2)).astype(np.int32))
+
+
+@pytest.mark.parametrize("rows,nv", [(1, 5), (4097, 3), (300000, 200), (480000, 70000), (1 << 20, 1 << 17)])
+def test_build_csr_is_a_stable_sort(gpu, rows, nv):
+    """tln_build_csr on caller indices: 1-3 radix passes, ragged last block, -1 rows, heavy duplicates"""
+    from temporal_latticenet_amd.lattice import Lattice
+    lat = Lattice.from_params([0.5] * 3, 1 << 18)
+    rng = np.random.default_rng(rows + nv)
+    # a lattice with exactly nv vertices: insert nv distinct keys
+    k3 = np.stack([np.arange(nv), -np.arange(nv), np.zeros(nv)], 1).astype(np.int32) * 4
+    keys = np.concatenate([k3, -k3.sum(1, keepdims=True)], 1).astype(np.int32)
+    lat.insert_keys(torch.from_numpy(keys).to(gpu))
+    assert lat.nr_lattice_vertices() == nv
+    idx = rng.integers(-1, nv, size=rows).astype(np.int32)
+    idx[rng.random(rows) < 0.3] = nv // 2          # one crowded vertex
+    for rep in range(2):                           # the arrival counter must be back at zero for the second build
+        t = torch.from_numpy(idx).to(gpu)
+        lat.ensure_csr(t)
+        _check_csr(lat, idx)
+        idx = np.roll(idx, 17)
 
 
 @pytest.mark.parametrize("n,sigma", [(20000, 1.0), (120000, 0.6), (5000, 0.2)])
