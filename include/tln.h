@@ -195,9 +195,9 @@ int tln_aflow(const float* d_x, const float* d_h, int64_t V, int64_t Vh, int C, 
 /* gather for the delta-weight head: out [n, 4*(cb+1)] = for r: [w_r * b[idx_r, :cb], w_r] */
 int tln_slice_gather(const float* d_lv, int64_t V, int cb, const int32_t* d_indices, const float* d_weights,
                      int64_t n, float* d_out, void* stream);
-/* out [n,C] = sum_r (w_r + dw_r) * lv[idx_r]   (d_delta may be NULL) */
+/* out [n,C] = sum_r (w_r + dw_r) * lv[idx_r] + bias   (d_delta, d_bias [C] may be NULL) */
 int tln_slice(const float* d_lv, int64_t V, int C, const int32_t* d_indices, const float* d_weights,
-              const float* d_delta, int64_t n, float* d_out, void* stream);
+              const float* d_delta, const float* d_bias, int64_t n, float* d_out, void* stream);
 
 /* ---- K11 plain splat (SplatLatticeModule) ---------------------------------------------- */
 /* out [V, val_dim+1] = sum over rows of w * [values, 1]  (uses the CSR of the last distribute) */
@@ -210,6 +210,101 @@ int tln_scatter_max(const float* d_src, const int64_t* d_index, int64_t rows, in
                     void* stream);
 int tln_scatter_add(const float* d_src, const int64_t* d_index, int64_t rows, int C, int64_t out_rows,
                     float* d_out, void* stream);
+
+/* ======================================================================================================
+ * Frame program: the per-frame forward of LNN_SEQ (models.py:284-476: distribute, PointNet, U-Net of
+ * GroupNorm-ReLU-products, the fusion modules with their hidden states, slice) as TWO native calls per frame
+ * instead of ~150 Python-level operator calls.  The host walks its module tree once (after the lazily created
+ * parameters exist) and describes the frame as a list of ops over numbered buffers ("slots"); the library sizes
+ * the slots from the frame's vertex counts, places them in its own arena and launches the same kernels the
+ * operator API launches, in the same order, so both routes give identical results.
+ *
+ * A slot is [rows, cols] fp32 where rows is symbolic: a lattice level (its current vertex count), the point
+ * count N, 4N, or the row count a hidden state had when it was stored (TLN_ROWS_STATE - id).
+ * Hidden states (GRUModule.h_lv lm:56/63, CrossframeLocalInterpolationModule.h_lv lm:209/230) live in the
+ * program: a STATE_NEW slot is what the module stores this frame, STATE_PREV what it stored on the previous one.
+ * An op may be conditional on whether its state exists yet (first frame of a sequence: lm:54, 208).
+ * ====================================================================================================== */
+typedef struct tln_program tln_program_t;
+
+#define TLN_MAX_LEVELS 8
+#define TLN_MAX_STATES 8
+#define TLN_ROWS_POINTS (-1)      /* N                                   */
+#define TLN_ROWS_POINT_ROWS (-2)  /* 4N                                  */
+#define TLN_ROWS_STATE (-16)      /* TLN_ROWS_STATE - id: rows of state id as stored on the previous frame */
+
+enum { TLN_SLOT_F32 = 0, TLN_SLOT_STATS = 1, TLN_SLOT_STATE_NEW = 2, TLN_SLOT_STATE_PREV = 3, TLN_SLOT_OUT = 4 };
+typedef struct {
+  int rows;   /* >= 0: lattice level; else one of the TLN_ROWS_* codes                              */
+  int cols;
+  int kind;   /* STATS: [ceil(rows/32)][cols] (sum,sumsq) doubles; OUT: the caller's result buffer   */
+  int state;  /* STATE_NEW / STATE_PREV: which hidden state                                          */
+} tln_slot;
+
+enum { TLN_TABLE_NONE = 0, TLN_TABLE_NBR = 1, TLN_TABLE_C2F = 2, TLN_TABLE_F2C = 3 };
+typedef struct {
+  int slot;             /* -1 = absent                                                               */
+  int table;            /* TLN_TABLE_*: NONE => row m itself (1 tap), else 9 taps                     */
+  int level;            /* NBR: the level itself; C2F / F2C: the COARSE level that owns the table     */
+  int relu;             /* ReLU on the operand (after the GroupNorm prologue if any)                  */
+  float pad_value;      /* rows past the slot's row count read as this (hidden-state padding)         */
+  int gn_stats;         /* slot holding the partial sums of `slot` => GroupNorm prologue, or -1       */
+  int gn_groups;
+  float gn_eps;
+  const float* gn_gamma;
+  const float* gn_beta;
+} tln_op_src;
+
+enum {
+  TLN_OP_GEMM = 1,        /* out[:, out_col:out_col+n] = epi([s0 | s1] @ w); rows = rows(out)            */
+  TLN_OP_GN_PARTIALS,     /* stats_out = partial sums of s0.slot                                        */
+  TLN_OP_POOL,            /* PointNet pool of the frame's distributed rows: p[0..3] weights, p[4..7] biases,
+                             i[0] layers, i[1..5] dims, i[6] min_points                                 */
+  TLN_OP_GRU,             /* out = GRUCell(s0.slot, zero-padded s1.slot): p[0..3] = w_ih, w_hh, b_ih, b_hh */
+  TLN_OP_AFLOW,           /* out = AFlow(s0.slot, s1.slot padded with f[2]); table NBR of s0.level; f[0] alpha,
+                             f[1] beta, i[0] use_center, bias                                            */
+  TLN_OP_SLICE_GATHER,    /* out [N, 4*(cols+1)] from s0.slot and the frame's indices / weights          */
+  TLN_OP_SLICE,           /* out [N, cols] = blend of s0.slot rows, s1.slot = delta weights (or -1), bias */
+  TLN_OP_COPY,            /* out[:, out_col:out_col+cols(s0)] = s0.slot                                  */
+  TLN_OP_ZERO_ROW0,       /* out[0, :] = 0 (lm:569-570)                                                  */
+  TLN_OP_STOP_IF_EARLY    /* early_return frames end here; s0.slot is what the frame returns            */
+};
+typedef struct {
+  int kind;
+  int cond_state;         /* -1: always; else run only if (state exists) == cond_has                    */
+  int cond_has;
+  int out, out_col, n;
+  int stats_out;          /* GEMM: slot for the partial sums of the output, or -1                        */
+  tln_op_src s0, s1;
+  int residual;           /* slot or -1                                                                  */
+  int relu, w_is_nk;
+  const float* w;
+  const float* bias;
+  const float* p[8];
+  int i[8];
+  float f[4];
+} tln_op;
+
+int tln_program_create(tln_program_t** out, const tln_slot* slots, int n_slots, const tln_op* ops, int n_ops,
+                       int n_states, int nr_coarse_levels);
+int tln_program_destroy(tln_program_t* p);
+/* forget all hidden states (LNN_SEQ.reset_sequence, models.py:252-263) */
+int tln_program_reset(tln_program_t* p);
+/* K1 of the frame (DistributeLatticeModule models.py:298 + every coarse level and table): v_out receives the
+ * vertex count of levels 0..nr_coarse_levels.  The distributed / indices / weights rows stay in the program. */
+int tln_program_begin_frame(tln_program_t* p, tln_lattice_t* l, const float* d_positions, const float* d_values,
+                            int64_t n, int val_dim, int reset_hashmap, int subtract_mean, int64_t* v_out,
+                            void* stream);
+/* the rest of the frame.  early != 0: stop at the program's STOP_IF_EARLY op and copy that slot to d_out;
+ * else the TLN_SLOT_OUT slot is d_out.  d_out must hold out_rows x out_cols floats (checked). */
+int tln_program_run(tln_program_t* p, int early, float* d_out, int64_t out_rows, int out_cols, void* stream);
+/* device pointers of the current frame's K1 outputs ([4N, 3+val_dim+1], [4N], [4N]); valid until the next frame */
+int tln_program_frame_rows(tln_program_t* p, const float** d_distributed, const int32_t** d_indices,
+                           const float** d_weights, int64_t* rows, int* cols);
+/* hidden-state exchange with the operator-level route: rows / existence, copy out, copy in */
+int tln_program_state_info(const tln_program_t* p, int id, int64_t* rows, int* cols, int* exists);
+int tln_program_state_get(tln_program_t* p, int id, float* d_out, void* stream);
+int tln_program_state_set(tln_program_t* p, int id, const float* d_in, int64_t rows, void* stream);
 
 #ifdef __cplusplus
 }

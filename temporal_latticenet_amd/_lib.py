@@ -31,6 +31,26 @@ class GnDesc(C.Structure):
     ]
 
 
+class Slot(C.Structure):
+    """tln_slot"""
+    _fields_ = [("rows", C.c_int), ("cols", C.c_int), ("kind", C.c_int), ("state", C.c_int)]
+
+
+class OpSrc(C.Structure):
+    """tln_op_src"""
+    _fields_ = [("slot", C.c_int), ("table", C.c_int), ("level", C.c_int), ("relu", C.c_int),
+                ("pad_value", C.c_float), ("gn_stats", C.c_int), ("gn_groups", C.c_int), ("gn_eps", C.c_float),
+                ("gn_gamma", C.c_void_p), ("gn_beta", C.c_void_p)]
+
+
+class Op(C.Structure):
+    """tln_op"""
+    _fields_ = [("kind", C.c_int), ("cond_state", C.c_int), ("cond_has", C.c_int), ("out", C.c_int),
+                ("out_col", C.c_int), ("n", C.c_int), ("stats_out", C.c_int), ("s0", OpSrc), ("s1", OpSrc),
+                ("residual", C.c_int), ("relu", C.c_int), ("w_is_nk", C.c_int), ("w", C.c_void_p),
+                ("bias", C.c_void_p), ("p", C.c_void_p * 8), ("i", C.c_int * 8), ("f", C.c_float * 4)]
+
+
 _vp, _i64, _i, _f = C.c_void_p, C.c_int64, C.c_int, C.c_float
 _PROTOS = {
     "tln_last_error": (C.c_char_p, []),
@@ -71,10 +91,20 @@ _PROTOS = {
     "tln_gru_cell": (_i, [_vp, _vp, _i64, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "tln_aflow": (_i, [_vp, _vp, _i64, _i64, _i, _vp, _f, _f, _f, _i, _vp, _vp, _vp, _vp, _vp]),
     "tln_slice_gather": (_i, [_vp, _i64, _i, _vp, _vp, _i64, _vp, _vp]),
-    "tln_slice": (_i, [_vp, _i64, _i, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "tln_slice": (_i, [_vp, _i64, _i, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "tln_splat": (_i, [_vp, _vp, _i, _vp, _i64, _vp, _vp]),
     "tln_scatter_max": (_i, [_vp, _vp, _i64, _i, _i64, _vp, _vp, _vp, _i64, _vp]),
     "tln_scatter_add": (_i, [_vp, _vp, _i64, _i, _i64, _vp, _vp]),
+    "tln_program_create": (_i, [C.POINTER(_vp), C.POINTER(Slot), _i, C.POINTER(Op), _i, _i, _i]),
+    "tln_program_destroy": (_i, [_vp]),
+    "tln_program_reset": (_i, [_vp]),
+    "tln_program_begin_frame": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, C.POINTER(_i64), _vp]),
+    "tln_program_run": (_i, [_vp, _i, _vp, _i64, _i, _vp]),
+    "tln_program_frame_rows": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i64),
+                                    C.POINTER(_i)]),
+    "tln_program_state_info": (_i, [_vp, _i, C.POINTER(_i64), C.POINTER(_i), C.POINTER(_i)]),
+    "tln_program_state_get": (_i, [_vp, _i, _vp, _vp]),
+    "tln_program_state_set": (_i, [_vp, _i, _vp, _i64, _vp]),
 }
 
 _lib = None

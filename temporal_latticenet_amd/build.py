@@ -16,6 +16,7 @@ SOURCES = {
     "pool.hip": [],
     "gemm.hip": [],
     "fused.hip": [],
+    "program.hip": [],
 }
 COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-I" + INCLUDE, "-Wall", "-Wno-unused-function"]
 

@@ -306,7 +306,8 @@ extern "C" int tln_slice_gather(const float* d_lv, int64_t V, int cb, const int3
 
 __global__ void __launch_bounds__(256) k_slice(const float* __restrict__ lv, int64_t V, int C,
                                                const int32_t* __restrict__ indices, const float* __restrict__ weights,
-                                               const float* __restrict__ delta, int64_t n, float* __restrict__ out) {
+                                               const float* __restrict__ delta, const float* __restrict__ bias,
+                                               int64_t n, float* __restrict__ out) {
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t p = gid / C;
   if (p >= n) return;
@@ -319,16 +320,16 @@ __global__ void __launch_bounds__(256) k_slice(const float* __restrict__ lv, int
     if (delta) w += delta[4 * p + r];
     if (idx >= 0 && idx < V) acc = fmaf(w, lv[(int64_t)idx * C + c], acc);
   }
-  out[gid] = acc;
+  out[gid] = bias ? acc + bias[c] : acc;
 }
 
 extern "C" int tln_slice(const float* d_lv, int64_t V, int C, const int32_t* d_indices, const float* d_weights,
-                         const float* d_delta, int64_t n, float* d_out, void* stream_) {
+                         const float* d_delta, const float* d_bias, int64_t n, float* d_out, void* stream_) {
   TLN_REQUIRE(d_lv && d_indices && d_weights && d_out && C > 0, "null argument");
   if (n <= 0) return TLN_OK;
   const int64_t total = n * C;
   hipLaunchKernelGGL(k_slice, dim3((unsigned)tln_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream_, d_lv, V, C,
-                     d_indices, d_weights, d_delta, n, d_out);
+                     d_indices, d_weights, d_delta, d_bias, n, d_out);
   TLN_LAUNCH_CHECK();
   return TLN_OK;
 }

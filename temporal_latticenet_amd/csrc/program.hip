@@ -1,0 +1,576 @@
+// Frame program interpreter (include/tln.h "Frame program"): the per-frame forward of LNN_SEQ
+// (reference seq_lattice/models.py:284-476) driven from native code.  Host-only logic: every op resolves its
+// slots to device pointers and calls the same C-ABI entry points the operator-level route calls
+// (tln_gather_gemm_ex, tln_pointnet_pool, tln_gru_cell, tln_aflow, tln_slice...), so the two routes launch
+// identical kernels with identical arguments.
+//
+// Memory: temporaries live in ONE arena owned by the program.  Before a frame is launched the op list is walked
+// once without launching anything to find the arena high-water mark for this frame's vertex counts (the walk is
+// deterministic, the real pass repeats it), the arena grows if needed, then the ops are launched.  A temporary is
+// released right after the last op that reads it; everything is stream-ordered, so reuse needs no events.
+// Hidden states sit in two buffers per state (previous / new) that swap when the frame that wrote one ends.
+#include <map>
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+constexpr size_t kAlign = 256;
+inline size_t align_up(size_t b) { return (b + kAlign - 1) / kAlign * kAlign; }
+
+// first-fit allocator over [0, capacity) with coalescing; offsets only, so it also serves the dry pass
+struct Arena {
+  std::map<size_t, size_t> free_;  // offset -> size
+  size_t high = 0;
+  void reset() {
+    free_.clear();
+    free_[0] = (size_t)1 << 60;
+    high = 0;
+  }
+  size_t alloc(size_t bytes) {
+    bytes = align_up(bytes ? bytes : 1);
+    for (auto it = free_.begin(); it != free_.end(); ++it) {
+      if (it->second >= bytes) {
+        const size_t off = it->first, rest = it->second - bytes;
+        free_.erase(it);
+        if (rest) free_[off + bytes] = rest;
+        if (off + bytes > high) high = off + bytes;
+        return off;
+      }
+    }
+    return (size_t)-1;  // unreachable: the last block is practically unbounded
+  }
+  void release(size_t off, size_t bytes) {
+    bytes = align_up(bytes ? bytes : 1);
+    auto it = free_.emplace(off, bytes).first;
+    auto nx = std::next(it);
+    if (nx != free_.end() && it->first + it->second == nx->first) {
+      it->second += nx->second;
+      free_.erase(nx);
+    }
+    if (it != free_.begin()) {
+      auto pv = std::prev(it);
+      if (pv->first + pv->second == it->first) {
+        pv->second += it->second;
+        free_.erase(it);
+      }
+    }
+  }
+};
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+
+int ensure_buf(DevBuf& b, size_t bytes, hipStream_t s, bool keep_contents = false) {
+  if (bytes <= b.bytes) return TLN_OK;
+  size_t want = b.bytes ? b.bytes : (size_t)1 << 20;
+  while (want < bytes) want += want / 2 + kAlign;
+  want = align_up(want);
+  void* np = nullptr;
+  TLN_HIP(hipStreamSynchronize(s));
+  TLN_HIP(hipMalloc(&np, want));
+  if (keep_contents && b.p && b.bytes) TLN_HIP(hipMemcpy(np, b.p, b.bytes, hipMemcpyDeviceToDevice));
+  if (b.p) (void)hipFree(b.p);
+  b.p = np;
+  b.bytes = want;
+  return TLN_OK;
+}
+
+struct SlotRt {
+  bool live = false;
+  size_t off = 0, bytes = 0;
+  int64_t rows = 0;
+  char* ptr = nullptr;  // resolved device pointer (real pass)
+};
+
+}  // namespace
+
+struct tln_program {
+  std::vector<tln_slot> slots;
+  std::vector<tln_op> ops;
+  std::vector<int> last_use;  // op index after which a temporary slot can go
+  int n_states = 0, n_coarse = 0;
+  // sequence state
+  DevBuf state_buf[TLN_MAX_STATES][2];
+  int64_t state_rows[TLN_MAX_STATES] = {0};
+  int state_cols[TLN_MAX_STATES] = {0};
+  int state_cur[TLN_MAX_STATES] = {0};  // which of the two buffers holds the stored state
+  bool state_has[TLN_MAX_STATES] = {false};
+  // frame state
+  tln_lattice_t* lat = nullptr;
+  tln_lattice_t* levels[TLN_MAX_LEVELS] = {nullptr};
+  int64_t V[TLN_MAX_LEVELS] = {0};
+  int64_t N = 0;
+  int dist_cols = 0;
+  bool frame_open = false;
+  DevBuf k1;  // distributed | indices | weights
+  float* d_dist = nullptr;
+  int32_t* d_idx = nullptr;
+  float* d_w = nullptr;
+  DevBuf arena;
+  Arena alloc;
+  std::vector<SlotRt> rt;
+};
+
+namespace {
+
+int64_t slot_rows(const tln_program* p, const tln_slot& s) {
+  if (s.kind == TLN_SLOT_STATE_PREV) return p->state_rows[s.state];
+  if (s.rows >= 0) return p->V[s.rows];
+  if (s.rows == TLN_ROWS_POINTS) return p->N;
+  if (s.rows == TLN_ROWS_POINT_ROWS) return 4 * p->N;
+  return p->state_rows[TLN_ROWS_STATE - s.rows];
+}
+
+size_t slot_bytes(const tln_slot& s, int64_t rows) {
+  if (s.kind == TLN_SLOT_STATS) return (size_t)tln_cdiv(rows, 32) * s.cols * 2 * sizeof(double);
+  return (size_t)rows * s.cols * sizeof(float);
+}
+
+bool cond_ok(const tln_program* p, const tln_op& o) {
+  if (o.cond_state < 0) return true;
+  return (p->state_has[o.cond_state] ? 1 : 0) == (o.cond_has ? 1 : 0);
+}
+
+// slots an op reads / writes
+template <class F>
+void for_inputs(const tln_op& o, F f) {
+  if (o.s0.slot >= 0) f(o.s0.slot);
+  if (o.s1.slot >= 0) f(o.s1.slot);
+  if (o.s0.gn_stats >= 0) f(o.s0.gn_stats);
+  if (o.s1.gn_stats >= 0) f(o.s1.gn_stats);
+  if (o.residual >= 0) f(o.residual);
+}
+template <class F>
+void for_outputs(const tln_op& o, F f) {
+  if (o.out >= 0) f(o.out);
+  if (o.stats_out >= 0) f(o.stats_out);
+}
+
+// One walk over the op list.  dry: only the arena bookkeeping (to size the arena); else launch.
+int walk(tln_program* p, bool dry, int early, float* d_out, int64_t out_rows, int out_cols, hipStream_t s) {
+  const int n_ops = (int)p->ops.size();
+  p->alloc.reset();
+  for (auto& r : p->rt) r = SlotRt();
+  bool wrote[TLN_MAX_STATES] = {false};
+  int64_t new_rows[TLN_MAX_STATES] = {0};
+  char* base = reinterpret_cast<char*>(p->arena.p);
+  bool finished = false;
+
+  auto tmp_alloc = [&](size_t bytes, size_t* off) {
+    *off = p->alloc.alloc(bytes);
+    return base ? base + *off : nullptr;
+  };
+
+  // make sure slot `id` has storage (called for op outputs)
+  auto materialise = [&](int id) -> int {
+    const tln_slot& sl = p->slots[id];
+    SlotRt& r = p->rt[id];
+    if (r.live) return TLN_OK;
+    r.rows = slot_rows(p, sl);
+    r.bytes = slot_bytes(sl, r.rows);
+    if (sl.kind == TLN_SLOT_STATE_NEW) {
+      const int st = sl.state;
+      if (!dry) {
+        DevBuf& b = p->state_buf[st][1 - p->state_cur[st]];
+        int rc = ensure_buf(b, r.bytes ? r.bytes : kAlign, s);
+        if (rc) return rc;
+        r.ptr = reinterpret_cast<char*>(b.p);
+      }
+      wrote[st] = true;
+      new_rows[st] = r.rows;
+      p->state_cols[st] = sl.cols;
+    } else if (sl.kind == TLN_SLOT_OUT) {
+      if (!dry) {
+        TLN_REQUIRE(d_out && r.rows == out_rows && sl.cols == out_cols,
+                    "program output is [%lld,%d], caller gave [%lld,%d]", (long long)r.rows, sl.cols,
+                    (long long)out_rows, out_cols);
+        r.ptr = reinterpret_cast<char*>(d_out);
+      }
+    } else if (sl.kind == TLN_SLOT_STATE_PREV) {
+      TLN_REQUIRE(false, "a stored hidden state cannot be an op output");
+    } else {
+      r.ptr = tmp_alloc(r.bytes, &r.off);
+    }
+    r.live = true;
+    return TLN_OK;
+  };
+
+  auto resolve_in = [&](int id) -> int {
+    const tln_slot& sl = p->slots[id];
+    SlotRt& r = p->rt[id];
+    if (sl.kind == TLN_SLOT_STATE_PREV) {
+      TLN_REQUIRE(p->state_has[sl.state], "op reads hidden state %d before it exists", sl.state);
+      r.rows = p->state_rows[sl.state];
+      r.bytes = slot_bytes(sl, r.rows);
+      r.ptr = reinterpret_cast<char*>(p->state_buf[sl.state][p->state_cur[sl.state]].p);
+      r.live = true;
+      return TLN_OK;
+    }
+    TLN_REQUIRE(r.live, "op reads slot %d before anything wrote it", id);
+    return TLN_OK;
+  };
+
+  auto fptr = [&](int id) { return reinterpret_cast<float*>(p->rt[id].ptr); };
+
+  for (int oi = 0; oi < n_ops && !finished; ++oi) {
+    const tln_op& o = p->ops[oi];
+    if (!cond_ok(p, o)) continue;
+    int rc = TLN_OK;
+    for_inputs(o, [&](int id) {
+      if (!rc) rc = resolve_in(id);
+    });
+    if (rc) return rc;
+    if (o.kind != TLN_OP_ZERO_ROW0 && o.kind != TLN_OP_STOP_IF_EARLY) {
+      for_outputs(o, [&](int id) {
+        if (!rc) rc = materialise(id);
+      });
+      if (rc) return rc;
+    }
+    // op-local scratch (released right after the op)
+    size_t scratch_off[3] = {0, 0, 0}, scratch_bytes[3] = {0, 0, 0};
+    char* scratch[3] = {nullptr, nullptr, nullptr};
+    auto want_scratch = [&](int k, size_t bytes) {
+      scratch_bytes[k] = bytes;
+      scratch[k] = tmp_alloc(bytes, &scratch_off[k]);
+    };
+
+    switch (o.kind) {
+      case TLN_OP_GEMM: {
+        const tln_slot& so = p->slots[o.out];
+        const int64_t M = p->rt[o.out].rows;
+        if (o.s0.gn_stats >= 0) want_scratch(0, (size_t)2 * p->slots[o.s0.slot].cols * sizeof(float));
+        if (dry) break;
+        tln_gemm_src a[2];
+        const tln_op_src* os[2] = {&o.s0, &o.s1};
+        for (int k = 0; k < 2; ++k) {
+          if (os[k]->slot < 0) continue;
+          const tln_slot& ss = p->slots[os[k]->slot];
+          tln_gemm_src& g = a[k];
+          g = tln_gemm_src{};
+          g.d_src = fptr(os[k]->slot);
+          g.src_rows = p->rt[os[k]->slot].rows;
+          g.ld = ss.cols;
+          g.cin = ss.cols;
+          g.taps = os[k]->table == TLN_TABLE_NONE ? 1 : TLN_TAPS;
+          g.pad_value = os[k]->pad_value;
+          g.relu = os[k]->relu;
+          if (os[k]->table != TLN_TABLE_NONE) {
+            tln_lattice_t* lv = p->levels[os[k]->level];
+            TLN_REQUIRE(lv, "op %d: level %d does not exist", oi, os[k]->level);
+            const int32_t* tp = nullptr;
+            if (os[k]->table == TLN_TABLE_NBR) rc = tln_neighbour_table(lv, &tp, s);
+            else if (os[k]->table == TLN_TABLE_C2F) rc = tln_coarse_to_fine_table(lv, &tp, s);
+            else rc = tln_fine_to_coarse_table(lv, &tp, s);
+            if (rc) return rc;
+            g.d_table = tp;
+          }
+          if (os[k]->gn_stats >= 0) {
+            TLN_REQUIRE(k == 0, "only source 0 takes a GroupNorm prologue");
+            g.d_gn_partials = p->rt[os[k]->gn_stats].ptr;
+            g.d_gn_gamma = os[k]->gn_gamma;
+            g.d_gn_beta = os[k]->gn_beta;
+            g.gn_rows = p->rt[os[k]->slot].rows;
+            g.gn_groups = os[k]->gn_groups;
+            g.gn_eps = os[k]->gn_eps;
+            g.d_scale = reinterpret_cast<float*>(scratch[0]);
+            g.d_shift = g.d_scale + ss.cols;
+          }
+        }
+        const float* res = o.residual >= 0 ? fptr(o.residual) : nullptr;
+        const int64_t ld_res = o.residual >= 0 ? p->slots[o.residual].cols : 0;
+        rc = tln_gather_gemm_ex(M, o.n, &a[0], o.s1.slot >= 0 ? &a[1] : nullptr, o.w, o.w_is_nk, o.bias, res, ld_res,
+                                o.relu, fptr(o.out) + o.out_col, so.cols,
+                                o.stats_out >= 0 ? p->rt[o.stats_out].ptr : nullptr, s);
+        if (rc) return rc;
+        break;
+      }
+      case TLN_OP_GN_PARTIALS: {
+        if (dry) break;
+        const tln_slot& ss = p->slots[o.s0.slot];
+        if (p->rt[o.s0.slot].rows > 0) {
+          rc = tln_groupnorm_partials(fptr(o.s0.slot), p->rt[o.s0.slot].rows, ss.cols, p->rt[o.stats_out].ptr, s);
+          if (rc) return rc;
+        }
+        break;
+      }
+      case TLN_OP_POOL: {
+        if (dry) break;
+        const int nl = o.i[0];
+        const float* w[4] = {o.p[0], o.p[1], o.p[2], o.p[3]};
+        const float* b[4] = {o.p[4], o.p[5], o.p[6], o.p[7]};
+        int dims[6] = {o.i[1], o.i[2], o.i[3], o.i[4], o.i[5], 0};
+        rc = tln_pointnet_pool(p->lat, p->d_dist, 4 * p->N, p->dist_cols, nl, w, b, dims, o.i[6], fptr(o.out), s);
+        if (rc) return rc;
+        break;
+      }
+      case TLN_OP_GRU: {
+        const int64_t Vr = p->rt[o.out].rows;
+        const int Cn = p->slots[o.out].cols;
+        want_scratch(0, (size_t)Vr * 6 * Cn * sizeof(float));
+        if (dry) break;
+        rc = tln_gru_cell(fptr(o.s0.slot), fptr(o.s1.slot), Vr, p->rt[o.s1.slot].rows, Cn, o.p[0], o.p[1], o.p[2], o.p[3],
+                          fptr(o.out), reinterpret_cast<float*>(scratch[0]), Vr * 6 * Cn, s);
+        if (rc) return rc;
+        break;
+      }
+      case TLN_OP_AFLOW: {
+        const int64_t Vr = p->rt[o.out].rows;
+        const int Cn = p->slots[o.out].cols;
+        want_scratch(0, (size_t)Vr * TLN_TAPS * sizeof(float));
+        want_scratch(1, (size_t)Vr * TLN_TAPS * sizeof(int32_t));
+        if (dry) break;
+        const int32_t* tp = nullptr;
+        TLN_REQUIRE(p->levels[o.s0.level], "op %d: level %d does not exist", oi, o.s0.level);
+        rc = tln_neighbour_table(p->levels[o.s0.level], &tp, s);
+        if (rc) return rc;
+        rc = tln_aflow(fptr(o.s0.slot), fptr(o.s1.slot), Vr, p->rt[o.s1.slot].rows, Cn, tp, o.f[0], o.f[1], o.f[2],
+                       o.i[0], o.bias, fptr(o.out), reinterpret_cast<float*>(scratch[0]),
+                       reinterpret_cast<int32_t*>(scratch[1]), s);
+        if (rc) return rc;
+        break;
+      }
+      case TLN_OP_SLICE_GATHER: {
+        if (dry) break;
+        rc = tln_slice_gather(fptr(o.s0.slot), p->rt[o.s0.slot].rows, p->slots[o.s0.slot].cols, p->d_idx, p->d_w, p->N,
+                              fptr(o.out), s);
+        if (rc) return rc;
+        break;
+      }
+      case TLN_OP_SLICE: {
+        if (dry) break;
+        rc = tln_slice(fptr(o.s0.slot), p->rt[o.s0.slot].rows, p->slots[o.s0.slot].cols, p->d_idx, p->d_w,
+                       o.s1.slot >= 0 ? fptr(o.s1.slot) : nullptr, o.bias, p->N, fptr(o.out), s);
+        if (rc) return rc;
+        break;
+      }
+      case TLN_OP_COPY: {
+        if (dry) break;
+        const tln_slot& ss = p->slots[o.s0.slot];
+        const tln_slot& so = p->slots[o.out];
+        const int64_t rows = p->rt[o.s0.slot].rows;
+        TLN_REQUIRE(rows == p->rt[o.out].rows && o.out_col + ss.cols <= so.cols, "op %d: copy shapes", oi);
+        if (rows > 0)
+          TLN_HIP(hipMemcpy2DAsync(fptr(o.out) + o.out_col, (size_t)so.cols * sizeof(float), fptr(o.s0.slot),
+                                   (size_t)ss.cols * sizeof(float), (size_t)ss.cols * sizeof(float), (size_t)rows,
+                                   hipMemcpyDeviceToDevice, s));
+        break;
+      }
+      case TLN_OP_ZERO_ROW0: {
+        TLN_REQUIRE(p->rt[o.out].live, "op %d: zero-row on an unwritten slot", oi);
+        if (dry) break;
+        if (p->rt[o.out].rows > 0)
+          TLN_HIP(hipMemsetAsync(fptr(o.out), 0, (size_t)p->slots[o.out].cols * sizeof(float), s));
+        break;
+      }
+      case TLN_OP_STOP_IF_EARLY: {
+        if (!early) break;
+        finished = true;
+        if (dry) break;
+        const tln_slot& ss = p->slots[o.s0.slot];
+        const int64_t rows = p->rt[o.s0.slot].rows;
+        TLN_REQUIRE(d_out && rows == out_rows && ss.cols == out_cols,
+                    "early-return value is [%lld,%d], caller gave [%lld,%d]", (long long)rows, ss.cols,
+                    (long long)out_rows, out_cols);
+        if (rows > 0)
+          TLN_HIP(hipMemcpyAsync(d_out, fptr(o.s0.slot), (size_t)rows * ss.cols * sizeof(float),
+                                 hipMemcpyDeviceToDevice, s));
+        break;
+      }
+      default:
+        TLN_REQUIRE(false, "op %d: unknown kind %d", oi, o.kind);
+    }
+    for (int k = 0; k < 3; ++k)
+      if (scratch_bytes[k]) p->alloc.release(scratch_off[k], scratch_bytes[k]);
+    // temporaries nobody reads any more
+    auto drop = [&](int id) {
+      SlotRt& r = p->rt[id];
+      if (r.live && p->last_use[id] <= oi && p->slots[id].kind != TLN_SLOT_STATE_NEW &&
+          p->slots[id].kind != TLN_SLOT_STATE_PREV && p->slots[id].kind != TLN_SLOT_OUT) {
+        p->alloc.release(r.off, r.bytes);
+        r.live = false;
+      }
+    };
+    for_inputs(o, drop);
+    for_outputs(o, drop);
+  }
+  if (!dry) {
+    for (int st = 0; st < p->n_states; ++st)
+      if (wrote[st]) {
+        p->state_cur[st] = 1 - p->state_cur[st];
+        p->state_rows[st] = new_rows[st];
+        p->state_has[st] = true;
+      }
+  }
+  return TLN_OK;
+}
+
+}  // namespace
+
+extern "C" int tln_program_create(tln_program_t** out, const tln_slot* slots, int n_slots, const tln_op* ops, int n_ops,
+                                  int n_states, int nr_coarse_levels) {
+  TLN_REQUIRE(out && slots && ops && n_slots > 0 && n_ops > 0, "null argument");
+  TLN_REQUIRE(n_states >= 0 && n_states <= TLN_MAX_STATES, "at most %d hidden states", TLN_MAX_STATES);
+  TLN_REQUIRE(nr_coarse_levels >= 0 && nr_coarse_levels < TLN_MAX_LEVELS, "at most %d levels", TLN_MAX_LEVELS);
+  tln_program* p = new tln_program();
+  p->slots.assign(slots, slots + n_slots);
+  p->ops.assign(ops, ops + n_ops);
+  p->n_states = n_states;
+  p->n_coarse = nr_coarse_levels;
+  p->rt.resize(n_slots);
+  p->last_use.assign(n_slots, -1);
+  auto fail = [&](const char* what, int oi) {
+    tln_set_error("program op %d: %s", oi, what);
+    delete p;
+    return TLN_E_INVALID;
+  };
+  for (int i = 0; i < n_slots; ++i) {
+    const tln_slot& s = p->slots[i];
+    const bool rows_ok = (s.rows >= 0 && s.rows <= nr_coarse_levels) || s.rows == TLN_ROWS_POINTS ||
+                         s.rows == TLN_ROWS_POINT_ROWS || (s.rows <= TLN_ROWS_STATE && TLN_ROWS_STATE - s.rows < n_states);
+    if (!rows_ok || s.cols <= 0) return fail("bad slot rows / cols", -1 - i);
+    if ((s.kind == TLN_SLOT_STATE_NEW || s.kind == TLN_SLOT_STATE_PREV) && (s.state < 0 || s.state >= n_states))
+      return fail("bad state id", -1 - i);
+  }
+  for (int oi = 0; oi < n_ops; ++oi) {
+    const tln_op& o = p->ops[oi];
+    bool ok = true;
+    auto chk = [&](int id) {
+      if (id < 0 || id >= n_slots) ok = false;
+      else p->last_use[id] = oi;
+    };
+    for_inputs(o, chk);
+    for_outputs(o, chk);
+    if (!ok) return fail("slot id out of range", oi);
+    if (o.cond_state >= n_states) return fail("bad condition state", oi);
+    if (o.kind == TLN_OP_GEMM && (!o.w || o.n <= 0 || o.s0.slot < 0)) return fail("incomplete GEMM", oi);
+  }
+  *out = p;
+  return TLN_OK;
+}
+
+extern "C" int tln_program_destroy(tln_program_t* p) {
+  if (!p) return TLN_OK;
+  (void)hipDeviceSynchronize();
+  for (int st = 0; st < TLN_MAX_STATES; ++st)
+    for (int k = 0; k < 2; ++k)
+      if (p->state_buf[st][k].p) (void)hipFree(p->state_buf[st][k].p);
+  if (p->k1.p) (void)hipFree(p->k1.p);
+  if (p->arena.p) (void)hipFree(p->arena.p);
+  delete p;
+  return TLN_OK;
+}
+
+extern "C" int tln_program_reset(tln_program_t* p) {
+  TLN_REQUIRE(p, "null program");
+  for (int st = 0; st < TLN_MAX_STATES; ++st) {
+    p->state_has[st] = false;
+    p->state_rows[st] = 0;
+  }
+  p->frame_open = false;
+  return TLN_OK;
+}
+
+extern "C" int tln_program_begin_frame(tln_program_t* p, tln_lattice_t* l, const float* d_positions,
+                                       const float* d_values, int64_t n, int val_dim, int reset_hashmap,
+                                       int subtract_mean, int64_t* v_out, void* stream_) {
+  TLN_REQUIRE(p && l && d_positions && v_out && n > 0 && val_dim >= 0, "bad frame arguments");
+  hipStream_t s = (hipStream_t)stream_;
+  const int cols = 3 + val_dim + 1;
+  const size_t dist_b = align_up((size_t)4 * n * cols * sizeof(float)), idx_b = align_up((size_t)4 * n * sizeof(int32_t));
+  int rc = ensure_buf(p->k1, dist_b + 2 * idx_b, s);
+  if (rc) return rc;
+  char* b = reinterpret_cast<char*>(p->k1.p);
+  p->d_dist = reinterpret_cast<float*>(b);
+  p->d_idx = reinterpret_cast<int32_t*>(b + dist_b);
+  p->d_w = reinterpret_cast<float*>(b + dist_b + idx_b);
+  if (reset_hashmap) {
+    rc = tln_lattice_clear(l, s);
+    if (rc) return rc;
+  }
+  rc = tln_distribute(l, d_positions, d_values, n, val_dim, subtract_mean, p->d_dist, p->d_idx, p->d_w, s);
+  if (rc) return rc;
+  rc = tln_lattice_prepare_levels(l, p->n_coarse, s);
+  if (rc) return rc;
+  p->lat = l;
+  p->N = n;
+  p->dist_cols = cols;
+  tln_lattice_t* lv = l;
+  for (int i = 0; i <= p->n_coarse; ++i) {
+    p->levels[i] = lv;
+    p->V[i] = tln_lattice_nr_vertices(lv);
+    v_out[i] = p->V[i];
+    if (i < p->n_coarse) {
+      tln_lattice_t* c = nullptr;
+      rc = tln_coarsen(lv, &c, s);
+      if (rc) return rc;
+      lv = c;
+    }
+  }
+  p->frame_open = true;
+  return TLN_OK;
+}
+
+extern "C" int tln_program_run(tln_program_t* p, int early, float* d_out, int64_t out_rows, int out_cols,
+                               void* stream_) {
+  TLN_REQUIRE(p && p->frame_open, "tln_program_run without tln_program_begin_frame");
+  hipStream_t s = (hipStream_t)stream_;
+  int rc = walk(p, true, early, nullptr, out_rows, out_cols, s);
+  if (rc) return rc;
+  rc = ensure_buf(p->arena, p->alloc.high + kAlign, s);
+  if (rc) return rc;
+  rc = walk(p, false, early, d_out, out_rows, out_cols, s);
+  p->frame_open = false;
+  return rc;
+}
+
+extern "C" int tln_program_frame_rows(tln_program_t* p, const float** d_distributed, const int32_t** d_indices,
+                                      const float** d_weights, int64_t* rows, int* cols) {
+  TLN_REQUIRE(p && p->d_dist, "no frame yet");
+  if (d_distributed) *d_distributed = p->d_dist;
+  if (d_indices) *d_indices = p->d_idx;
+  if (d_weights) *d_weights = p->d_w;
+  if (rows) *rows = 4 * p->N;
+  if (cols) *cols = p->dist_cols;
+  return TLN_OK;
+}
+
+extern "C" int tln_program_state_info(const tln_program_t* p, int id, int64_t* rows, int* cols, int* exists) {
+  TLN_REQUIRE(p && id >= 0 && id < p->n_states, "bad state id");
+  if (rows) *rows = p->state_rows[id];
+  if (cols) *cols = p->state_cols[id];
+  if (exists) *exists = p->state_has[id] ? 1 : 0;
+  return TLN_OK;
+}
+
+extern "C" int tln_program_state_get(tln_program_t* p, int id, float* d_out, void* stream_) {
+  TLN_REQUIRE(p && id >= 0 && id < p->n_states && d_out, "bad state id");
+  TLN_REQUIRE(p->state_has[id], "hidden state %d does not exist", id);
+  const size_t bytes = (size_t)p->state_rows[id] * p->state_cols[id] * sizeof(float);
+  if (bytes)
+    TLN_HIP(hipMemcpyAsync(d_out, p->state_buf[id][p->state_cur[id]].p, bytes, hipMemcpyDeviceToDevice,
+                           (hipStream_t)stream_));
+  return TLN_OK;
+}
+
+extern "C" int tln_program_state_set(tln_program_t* p, int id, const float* d_in, int64_t rows, void* stream_) {
+  TLN_REQUIRE(p && id >= 0 && id < p->n_states && d_in && rows >= 0, "bad state id");
+  int cols = p->state_cols[id];
+  if (cols == 0)
+    for (const tln_slot& s : p->slots)
+      if (s.kind == TLN_SLOT_STATE_NEW && s.state == id) cols = s.cols;
+  TLN_REQUIRE(cols > 0, "hidden state %d has no width", id);
+  hipStream_t s = (hipStream_t)stream_;
+  const size_t bytes = (size_t)rows * cols * sizeof(float);
+  DevBuf& b = p->state_buf[id][p->state_cur[id]];
+  int rc = ensure_buf(b, bytes ? bytes : kAlign, s);
+  if (rc) return rc;
+  if (bytes) TLN_HIP(hipMemcpyAsync(b.p, d_in, bytes, hipMemcpyDeviceToDevice, s));
+  p->state_rows[id] = rows;
+  p->state_cols[id] = cols;
+  p->state_has[id] = true;
+  return TLN_OK;
+}

@@ -140,6 +140,8 @@ class FrameShardRunner:
         self._recv_now = False
         self._send_now = False
         self._slots = []
+        # the hidden-state hand-off hangs on the fusion modules' forward hooks: stay on the operator-level route
+        model.use_frame_program = False
         self._install_hooks()
 
     # ---- hidden-state hand-off ----------------------------------------------------------------

@@ -1,0 +1,395 @@
+"""Frame program: LNN_SEQ.forward (reference seq_lattice/models.py:284-476) of one frame as two native calls.
+
+The operator-level route (models.py / lattice_modules.py / seq_modules.py of this package) makes ~150 Python-level
+calls per frame; on a lattice of a few thousand vertices that host work is as long as the kernels.  Here the module
+tree is walked ONCE, after the lazily created parameters exist, and turned into the op list of include/tln.h
+("Frame program"); every later inference frame is `tln_program_begin_frame` + `tln_program_run`.  The ops call the
+same C-ABI entry points with the same arguments in the same order as the modules do, so both routes produce
+identical tensors (tests/test_gpu_engine.py compares them bit for bit).
+
+Supported: experiment none / slice_no_deform / pointnet_no_local_mean, fusion modules none / gru / aflow in every
+slot (the BASELINE configurations).  Anything else, gradients, dropout in training mode and the AFlow
+visualisation hooks stay on the operator-level route (compile_model returns None).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .lattice import stream_ptr
+from .lattice_modules import BottleneckBlock, NO_MEAN_EXPERIMENTS, ResnetBlock
+from .seq_modules import CrossframeLocalInterpolationModule, GRUModule
+
+ROWS_POINTS, ROWS_POINT_ROWS, ROWS_STATE = -1, -2, -16
+SLOT_F32, SLOT_STATS, SLOT_STATE_NEW, SLOT_STATE_PREV, SLOT_OUT = 0, 1, 2, 3, 4
+TABLE_NONE, TABLE_NBR, TABLE_C2F, TABLE_F2C = 0, 1, 2, 3
+(OP_GEMM, OP_GN_PARTIALS, OP_POOL, OP_GRU, OP_AFLOW, OP_SLICE_GATHER, OP_SLICE, OP_COPY, OP_ZERO_ROW0,
+ OP_STOP_IF_EARLY) = range(1, 11)
+
+
+class NotReady(Exception):
+    """a lazily created parameter does not exist yet (the module has not seen a frame)"""
+
+
+class Unsupported(Exception):
+    """the configuration needs the operator-level route"""
+
+
+class Val:
+    """a [rows, cols] value of the program: its slot, its level (or row code) and, if a product left them, the
+    slot with the GroupNorm partial sums of it"""
+
+    def __init__(self, slot, rows, cols, stats=None):
+        self.slot, self.rows, self.cols, self.stats = slot, rows, cols, stats
+
+
+def _p(t):
+    if t is None:
+        return None
+    if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
+        raise Unsupported("parameter is not a contiguous fp32 device tensor")
+    return t.data_ptr()
+
+
+def _need(x, what):
+    if x is None:
+        raise NotReady(what)
+    return x
+
+
+class Builder:
+    def __init__(self):
+        self.slots, self.ops, self.keep = [], [], []
+        self.n_states = 0
+
+    # ---- slots
+    def slot(self, rows, cols, kind=SLOT_F32, state=-1):
+        self.slots.append((rows, cols, kind, state))
+        return len(self.slots) - 1
+
+    def new_state(self, level, cols):
+        sid = self.n_states
+        self.n_states += 1
+        new = self.slot(level, cols, SLOT_STATE_NEW, sid)
+        prev = self.slot(level, cols, SLOT_STATE_PREV, sid)
+        return sid, new, prev
+
+    # ---- ops
+    def op(self, kind, **kw):
+        o = dict(kind=kind, cond_state=-1, cond_has=0, out=-1, out_col=0, n=0, stats_out=-1, s0=None, s1=None,
+                 residual=-1, relu=0, w_is_nk=0, w=None, bias=None, p=[None] * 8, i=[0] * 8, f=[0.0] * 4)
+        o.update(kw)
+        self.ops.append(o)
+        return o
+
+    @staticmethod
+    def src(val, table=TABLE_NONE, level=0, relu=False, pad_value=0.0, gn=None):
+        """gn = torch.nn.GroupNorm whose statistics are val.stats"""
+        d = dict(slot=val.slot, table=table, level=level, relu=1 if relu else 0, pad_value=float(pad_value), gn_stats=-1,
+                 gn_groups=0, gn_eps=0.0, gn_gamma=None, gn_beta=None)
+        if gn is not None:
+            assert val.stats is not None
+            d.update(gn_stats=val.stats, gn_groups=gn.num_groups, gn_eps=float(gn.eps), gn_gamma=_p(gn.weight),
+                     gn_beta=_p(gn.bias))
+        return d
+
+    def with_stats(self, val):
+        """GroupNorm needs the partial sums of val; a product's epilogue leaves them, anything else gets one pass"""
+        if val.stats is None:
+            val.stats = self.slot(val.rows, val.cols, SLOT_STATS)
+            self.op(OP_GN_PARTIALS, s0=self.src(val), stats_out=val.stats)
+        return val
+
+    def gemm(self, rows, n, weight, w_is_nk, s0, s1=None, bias=None, residual=None, relu=False, stats=True, cond=None,
+             out=None, out_col=0, out_cols=None):
+        self.keep.append(weight)
+        if out is None:
+            out = self.slot(rows, n if out_cols is None else out_cols)
+        st = self.slot(rows, n, SLOT_STATS) if stats else -1
+        o = self.op(OP_GEMM, out=out, out_col=out_col, n=n, stats_out=st, s0=s0, s1=s1,
+                    residual=residual.slot if residual is not None else -1, relu=1 if relu else 0,
+                    w_is_nk=1 if w_is_nk else 0, w=_p(weight), bias=_p(bias))
+        if cond is not None:
+            o["cond_state"], o["cond_has"] = cond
+        return Val(out, rows, n if out_cols is None else out_cols, st if stats else None)
+
+    # ---- modules (same order of C-ABI calls as the operator-level forward of each class)
+    def tap_product(self, mod, x, rows, table, level, norm=None, residual=None, out=None, out_col=0, out_cols=None):
+        """_TapConv._product: [GroupNorm+ReLU prologue ->] 9-tap product, partial sums of the output"""
+        w = _need(mod.weight, "conv weight")
+        gn = None
+        if norm is not None:
+            gn = _need(norm.norm, "GroupNorm")
+            x = self.with_stats(x)
+        return self.gemm(rows, w.shape[1], w, False, self.src(x, table, level, relu=norm is not None, gn=gn),
+                         bias=mod.bias, residual=residual, out=out, out_col=out_col, out_cols=out_cols)
+
+    def gn_relu_1x1(self, mod, x, residual=None):
+        lin = _need(mod.linear.linear, "1x1 weight")
+        gn = _need(mod.norm.norm, "GroupNorm")
+        x = self.with_stats(x)
+        return self.gemm(x.rows, lin.weight.shape[0], lin.weight, True, self.src(x, relu=True, gn=gn), bias=lin.bias,
+                         residual=residual)
+
+    def gn_relu_conv(self, mod, x, level, residual=None):
+        if mod.drop is not None and mod.drop.prob > 0.0:
+            self.uses_dropout = True
+        return self.tap_product(mod.conv, x, level, TABLE_NBR, level, mod.norm, residual)
+
+    def block(self, mod, x, level):
+        if isinstance(mod, ResnetBlock):
+            t = self.gn_relu_conv(mod.conv1, x, level)
+            return self.gn_relu_conv(mod.conv2, t, level, residual=x)
+        if isinstance(mod, BottleneckBlock):
+            t = self.gn_relu_1x1(mod.contract, x)
+            t = self.gn_relu_conv(mod.conv, t, level)
+            return self.gn_relu_1x1(mod.expand, t, residual=x)
+        raise Unsupported(type(mod).__name__)
+
+    def fusion(self, mod, x, level):
+        """GRUModule (lm:42-66) / CrossframeLocalInterpolationModule (lm:188-235); the module's output IS the
+        state it stores.  First frame of a sequence: the state is the input itself (lm:54-56, 208-209)."""
+        if mod is None:
+            return x
+        sid, new, prev = self.new_state(level, x.cols)
+        prev_val = Val(prev, ROWS_STATE - sid, x.cols)
+        self.op(OP_COPY, out=new, s0=self.src(x), cond_state=sid, cond_has=0)
+        if isinstance(mod, GRUModule):
+            g = mod.GRU
+            h1 = self.gemm(ROWS_STATE - sid, x.cols, mod.hidden_linear.weight, True, self.src(prev_val),
+                           bias=mod.hidden_linear.bias, stats=False, cond=(sid, 1))        # lm:58
+            self.keep += [g.weight_ih, g.weight_hh, g.bias_ih, g.bias_hh]
+            self.op(OP_GRU, out=new, s0=self.src(x), s1=self.src(h1), cond_state=sid, cond_has=1,
+                    p=[_p(g.weight_ih), _p(g.weight_hh), _p(g.bias_ih), _p(g.bias_hh)] + [None] * 4)   # lm:59-62
+        elif isinstance(mod, CrossframeLocalInterpolationModule):
+            a = mod.AFLOW
+            if a.first_time:
+                raise NotReady("AFLOW parameters")
+            av = self.slot(level, x.cols)
+            self.keep.append(a.bias)
+            self.op(OP_AFLOW, out=av, s0=dict(self.src(x), level=level), s1=self.src(prev_val), cond_state=sid,
+                    cond_has=1, bias=_p(a.bias) if a.use_bias else None,
+                    f=[float(a.alpha), float(a.beta), -999999.0, 0.0], i=[1 if a.use_center else 0] + [0] * 7)
+            self.gemm(level, x.cols, mod.linear.weight, True, self.src(Val(av, level, x.cols)), self.src(x),
+                      bias=mod.linear.bias, relu=True, stats=False, cond=(sid, 1), out=new)  # lm:223-227
+        else:
+            raise Unsupported(type(mod).__name__)
+        return Val(new, level, x.cols)
+
+
+def _walk_model(model):
+    """mirrors LNN_SEQ.forward (this package's models.py, reference models.py:284-476)"""
+    b = Builder()
+    b.uses_dropout = False
+    seq = model.sequence_learning
+    rnn = model.rnn_modules if seq else ["none"] * 4
+    for k in rnn:
+        if k not in ("none", "gru", "aflow"):
+            raise Unsupported("fusion module " + k)
+    pn = model.point_net_seq
+    if pn.experiment not in ("none", "slice_no_deform", "pointnet_no_local_mean"):
+        raise Unsupported("experiment " + pn.experiment)
+    if pn.first_time:
+        raise NotReady("PointNet layers")
+    if len(pn.layers) > 4:
+        raise Unsupported("more than four PointNet layers")
+
+    # ---- PointNetSeqModule.forward (lm:407-576)
+    dims = [pn.layers[0].weight.shape[1]] + [l.weight.shape[0] for l in pn.layers]
+    pooled = Val(b.slot(0, 2 * dims[-1]), 0, 2 * dims[-1])
+    ws = [l.weight for l in pn.layers]
+    bs = [l.bias for l in pn.layers]
+    b.keep += ws + bs
+    b.op(OP_POOL, out=pooled.slot, p=[_p(w) for w in ws] + [None] * (4 - len(ws)) + [_p(x) for x in bs] +
+         [None] * (4 - len(bs)), i=[len(ws)] + dims + [0] * (5 - len(dims)) + [4, 0])
+    fm = pn.fusion_module if seq else None
+    x = b.fusion(fm, pooled, 0)
+    if fm is not None:                                   # the stored state keeps its row 0 (lm:569-570 on a copy)
+        q = Val(b.slot(0, x.cols), 0, x.cols)
+        b.op(OP_COPY, out=q.slot, s0=b.src(x))
+        x = q
+    b.op(OP_ZERO_ROW0, out=x.slot)
+    lv = b.tap_product(_need(getattr(pn, "last_conv", None), "last_conv"), x, 0, TABLE_NBR, 0)      # lm:573
+
+    stopped = False
+
+    def stop(v):
+        nonlocal stopped
+        if not stopped:
+            b.op(OP_STOP_IF_EARLY, s0=b.src(v))
+            b.stop_shape = (v.rows, v.cols)
+            stopped = True
+
+    if seq and rnn[1] == "none" and rnn[2] == "none" and rnn[3] == "none":                          # models:307
+        stop(lv)
+    fusion = list(model.recurrent_fusion_modules) if seq else [None, None, None]
+    skips = []
+    level = 0
+    for i in range(model.nr_downsamples):                                                            # models:314
+        for blk in model.resnet_blocks_per_down_lvl_list[i]:
+            lv = b.block(blk, lv, level)
+        skips.append((lv, level))
+        if i == 0:
+            lv = b.fusion(fusion[0], lv, level)                                                      # models:341
+            if seq and rnn[2] == "none" and rnn[3] == "none":                                        # models:346
+                stop(lv)
+        cm = model.coarsens_list[i]
+        lv = b.tap_product(cm.coarse, lv, level + 1, TABLE_C2F, level + 1, cm.norm)                  # models:353
+        level += 1
+    for blk in model.resnet_blocks_bottleneck:                                                       # models:361
+        lv = b.block(blk, lv, level)
+    lv = b.fusion(fusion[1], lv, level)                                                              # models:381
+    i = 0
+    for i in range(model.nr_downsamples):                                                            # models:390
+        fine, fine_level = skips.pop()
+        fm_ = model.finefy_list[i]
+        w = _need(fm_.fine.weight, "finefy weight")
+        n_f = w.shape[1]
+        if model.do_concat_for_vertical_connection:                                                  # models:401
+            cat = b.slot(fine_level, n_f + fine.cols)
+            b.tap_product(fm_.fine, lv, fine_level, TABLE_F2C, level, fm_.norm, out=cat, out_col=0,
+                          out_cols=n_f + fine.cols)                                                  # models:398
+            b.op(OP_COPY, out=cat, out_col=n_f, s0=b.src(fine))
+            lv = Val(cat, fine_level, n_f + fine.cols)
+        else:
+            lv = b.tap_product(fm_.fine, lv, fine_level, TABLE_F2C, level, fm_.norm, residual=fine)
+            lv.stats = lv.stats      # the epilogue's partial sums already include the residual
+        level = fine_level
+        if i == model.nr_downsamples - 1:
+            lv = b.fusion(fusion[2], lv, level)                                                      # models:424
+            if seq:
+                stop(lv)                                                                             # models:427
+    for blk in model.resnet_blocks_per_up_lvl_list[i]:                                               # models:435-437
+        lv = b.block(blk, lv, level)
+
+    # ---- SliceFastCUDALatticeModule.forward (models:465)
+    sl = model.slice_fast_cuda
+    clasify = _need(sl.linear_clasify, "slice parameters")
+    if sl.dropout is not None and sl.dropout.prob > 0.0:
+        b.uses_dropout = True
+    delta = None
+    if sl.experiment != "slice_no_deform":
+        t = lv
+        for m in sl.stepdown:
+            t = b.gn_relu_1x1(m, t)
+        t = b.gn_relu_1x1(sl.bottleneck, t)
+        g = Val(b.slot(ROWS_POINTS, 4 * (t.cols + 1)), ROWS_POINTS, 4 * (t.cols + 1))
+        b.op(OP_SLICE_GATHER, out=g.slot, s0=b.src(t))
+        hdn = b.gemm(ROWS_POINTS, g.cols, sl.linear_pre_deltaW.weight, True, b.src(g), relu=True, stats=False)
+        delta = b.gemm(ROWS_POINTS, 4, sl.linear_deltaW.weight, True, b.src(hdn), bias=sl.linear_deltaW.bias,
+                       stats=False)
+    scores = b.gemm(level, clasify.weight.shape[0], clasify.weight, True, b.src(lv), stats=False)
+    out = b.slot(ROWS_POINTS, clasify.weight.shape[0], SLOT_OUT)
+    b.keep.append(clasify.bias)
+    b.op(OP_SLICE, out=out, s0=b.src(scores), s1=b.src(delta) if delta is not None else None, bias=_p(clasify.bias))
+    b.out_shape = (ROWS_POINTS, clasify.weight.shape[0])
+    if not stopped:
+        b.stop_shape = None
+    return b
+
+
+def _fill_src(dst, d):
+    if d is None:
+        dst.slot = -1
+        dst.gn_stats = -1
+        return
+    dst.slot, dst.table, dst.level, dst.relu = d["slot"], d["table"], d["level"], d["relu"]
+    dst.pad_value, dst.gn_stats, dst.gn_groups, dst.gn_eps = d["pad_value"], d["gn_stats"], d["gn_groups"], d["gn_eps"]
+    dst.gn_gamma, dst.gn_beta = d["gn_gamma"], d["gn_beta"]
+
+
+class FrameProgram:
+    """native per-frame forward of one LNN_SEQ instance (inference)"""
+
+    def __init__(self, model, builder):
+        self.model = model
+        self.nr_coarse = model.nr_downsamples
+        self.stop_shape, self.out_shape = builder.stop_shape, builder.out_shape
+        self.uses_dropout = builder.uses_dropout
+        self._keep = builder.keep
+        self.n_ops, self.n_slots, self.n_states = len(builder.ops), len(builder.slots), builder.n_states
+        slots = (_lib.Slot * len(builder.slots))()
+        for k, (rows, cols, kind, state) in enumerate(builder.slots):
+            slots[k].rows, slots[k].cols, slots[k].kind, slots[k].state = rows, cols, kind, state
+        ops = (_lib.Op * len(builder.ops))()
+        for k, o in enumerate(builder.ops):
+            d = ops[k]
+            d.kind, d.cond_state, d.cond_has = o["kind"], o["cond_state"], o["cond_has"]
+            d.out, d.out_col, d.n, d.stats_out = o["out"], o["out_col"], o["n"], o["stats_out"]
+            _fill_src(d.s0, o["s0"])
+            _fill_src(d.s1, o["s1"])
+            d.residual, d.relu, d.w_is_nk, d.w, d.bias = o["residual"], o["relu"], o["w_is_nk"], o["w"], o["bias"]
+            for j in range(8):
+                d.p[j] = o["p"][j]
+                d.i[j] = o["i"][j]
+            for j in range(4):
+                d.f[j] = o["f"][j]
+        h = C.c_void_p()
+        _lib.check(_lib.lib().tln_program_create(C.byref(h), slots, len(builder.slots), ops, len(builder.ops),
+                                                 builder.n_states, self.nr_coarse), "tln_program_create")
+        self._h = h
+        self._v = (C.c_int64 * (self.nr_coarse + 1))()
+        self.subtract_mean = model.distribute.experiment not in NO_MEAN_EXPERIMENTS
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                _lib.lib().tln_program_destroy(h)
+            except Exception:
+                pass
+
+    def reset(self):
+        _lib.check(_lib.lib().tln_program_reset(self._h), "tln_program_reset")
+
+    def _rows(self, code, n):
+        return n if code == ROWS_POINTS else (4 * n if code == ROWS_POINT_ROWS else int(self._v[code]))
+
+    def run_frame(self, ls, positions, values, reset_hashmap, early_return):
+        """-> (tensor, ls): the early-return lattice values [V, C] or the class scores [N, nr_classes]"""
+        positions = positions.contiguous().float()
+        n = positions.shape[0]
+        if values is None or values.numel() == 0:
+            values, val_dim = None, 0
+        else:
+            values = values.contiguous().float()
+            val_dim = values.shape[1]
+        lib, s = _lib.lib(), stream_ptr()
+        _lib.check(lib.tln_program_begin_frame(self._h, ls._h, positions.data_ptr(),
+                                               values.data_ptr() if values is not None else None, n, val_dim,
+                                               1 if reset_hashmap else 0, 1 if self.subtract_mean else 0, self._v, s),
+                   "tln_program_begin_frame")
+        ls._csr_key = None
+        early = bool(early_return) and self.stop_shape is not None
+        rows_code, cols = self.stop_shape if early else self.out_shape
+        rows = self._rows(rows_code, n)
+        out = torch.empty((rows, cols), dtype=torch.float32, device="cuda")
+        _lib.check(lib.tln_program_run(self._h, 1 if early else 0, out.data_ptr(), rows, cols, s), "tln_program_run")
+        ls.set_values(out)
+        return out, ls
+
+    def state(self, sid):
+        """copy of hidden state `sid` (None if it does not exist yet)"""
+        rows, cols, has = C.c_int64(), C.c_int(), C.c_int()
+        _lib.check(_lib.lib().tln_program_state_info(self._h, sid, C.byref(rows), C.byref(cols), C.byref(has)),
+                   "tln_program_state_info")
+        if not has.value:
+            return None
+        t = torch.empty((rows.value, cols.value), dtype=torch.float32, device="cuda")
+        _lib.check(_lib.lib().tln_program_state_get(self._h, sid, t.data_ptr(), stream_ptr()), "tln_program_state_get")
+        return t
+
+
+def params_key(model):
+    """identity + in-place version of every parameter: a program is rebuilt when any of them was re-allocated or
+    written (optimizer step, load_state_dict) since it was compiled — AFlow's alpha / beta are baked in by value"""
+    return tuple((p.data_ptr(), p._version) for p in model.parameters())
+
+
+def compile_model(model):
+    """FrameProgram for `model`, or None when the configuration / state needs the operator-level route"""
+    try:
+        b = _walk_model(model)
+    except (NotReady, Unsupported):
+        return None
+    return FrameProgram(model, b)

@@ -419,7 +419,6 @@ class SliceFastCUDALatticeModule(torch.nn.Module):
             delta = ops.gather_gemm(n, self.linear_deltaW.weight, ops.gemm_src(hdn), w_is_nk=True,
                                     bias=self.linear_deltaW.bias)
         scores = ops.gather_gemm(lv.shape[0], self.linear_clasify.weight, ops.gemm_src(lv), w_is_nk=True)
-        out = ops.slice_blend(scores, indices, weights, delta)
-        out = out + self.linear_clasify.bias
+        out = ops.slice_blend(scores, indices, weights, delta, self.linear_clasify.bias)
         ls.set_values(lv)
         return out

@@ -167,9 +167,38 @@ class LNN_SEQ(torch.nn.Module):
         if experiment != "none":
             print("-------------------------------\nUSING EXPERIMENT " + experiment + "\n-------------------------------")
 
+    # ---- frame program (engine.py): the same forward as below, as two native calls per inference frame
+    use_frame_program = True
+
+    def _fusion_modules_in_state_order(self):
+        mods = [self.point_net_seq.fusion_module] + list(self.recurrent_fusion_modules) if self.sequence_learning else []
+        return [m for m in mods if m is not None]
+
+    def _program_for_this_frame(self, vis_aflow):
+        """decided at the first frame of a sequence; a frame that needs the operator-level route (gradients,
+        visualisation hooks) takes the hidden states with it"""
+        from . import engine
+        wanted = self.use_frame_program and not torch.is_grad_enabled() and not vis_aflow
+        if self.first_sequence or not self.sequence_learning:
+            self._program_active = False
+            if wanted:
+                key = engine.params_key(self)
+                if getattr(self, "_program", None) is None or self._program_key != key:
+                    self._program, self._program_key = engine.compile_model(self), key
+                prog = self._program
+                if prog is not None and not (self.training and prog.uses_dropout):
+                    prog.reset()
+                    self._program_active = True
+        elif getattr(self, "_program_active", False) and not wanted:
+            for sid, m in enumerate(self._fusion_modules_in_state_order()):
+                m.h_lv = self._program.state(sid)
+            self._program_active = False
+        return self._program if getattr(self, "_program_active", False) else None
+
     def reset_sequence(self):                                                        # models.py:252-263
         self.h_lv = None
         self.first_sequence = True
+        self._program_active = False
         self.start_time = None
         self.lattice_neighbors_previous_index_list, self.avg_position_per_vertex_list, self.weight_vis_list = [], [], []
         if self.sequence_learning:
@@ -182,6 +211,13 @@ class LNN_SEQ(torch.nn.Module):
         reset_hashmap = True                                                         # models.py:287-289
         if self.sequence_learning and not self.first_sequence:
             reset_hashmap = False
+        prog = self._program_for_this_frame(vis_aflow)
+        if prog is not None:
+            out, ls = prog.run_frame(ls, positions, values, reset_hashmap, early_return)
+            self.first_sequence = False
+            if early_return and prog.stop_shape is not None:
+                return out, out, ls
+            return self.logsoftmax(out), out, ls
         with torch.set_grad_enabled(False):
             ls, distributed, indices, weights = self.distribute(ls, positions, values, reset_hashmap)   # :298
             if hasattr(ls, "prepare_levels"):      # all coarse levels + neighbour tables of the frame in one go

@@ -225,12 +225,13 @@ def slice_gather(lv, indices, weights):
     return out
 
 
-def slice_blend(lv, indices, weights, delta=None):
+def slice_blend(lv, indices, weights, delta=None, bias=None):
     lv = _f32c(lv)
     n = indices.shape[0] // 4
     out = torch.empty((n, lv.shape[1]), dtype=torch.float32, device="cuda")
     _lib.check(_lib.lib().tln_slice(_ptr(lv), lv.shape[0], lv.shape[1], _ptr(indices.contiguous()),
-                                    _ptr(_f32c(weights)), _ptr(_f32c(delta)), n, _ptr(out), stream_ptr()), "tln_slice")
+                                    _ptr(_f32c(weights)), _ptr(_f32c(delta)), _ptr(_f32c(bias)), n, _ptr(out),
+                                    stream_ptr()), "tln_slice")
     return out
 
 

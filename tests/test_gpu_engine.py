@@ -1,0 +1,112 @@
+"""GPU: the frame program (temporal_latticenet_amd/engine.py, include/tln.h "Frame program") against the
+operator-level route of the same model: identical kernels in identical order, so the tensors must be EQUAL, for
+every frame of a sequence including the early-return values (models.py:307, 346, 427)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import build_model, make_config, make_lattice, oracle_from_model, randomize_parameters
+from temporal_latticenet_amd.synthetic import make_sequence
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(model, contents, seq, gpu, switch_off_at=None):
+    lat = make_lattice(contents)
+    outs, used = [], []
+    with torch.no_grad():
+        for t, (pos, val) in enumerate(seq):
+            if switch_off_at is not None and t == switch_off_at:
+                model.use_frame_program = False
+            a, b, lat = model(lat, torch.from_numpy(pos).to(gpu), torch.from_numpy(val).to(gpu), t != len(seq) - 1, False)
+            outs.append((a.clone(), b.clone()))
+            used.append(bool(getattr(model, "_program_active", False)))
+    model.reset_sequence()
+    return outs, used
+
+
+def _prepared(contents, seq, gpu, nr_classes=26, seed=3):
+    model = build_model(contents, nr_classes=nr_classes).eval()
+    model.use_frame_program = False
+    _run(model, contents, seq, gpu)                    # lazily created parameters
+    randomize_parameters(model, seed=seed)
+    return model
+
+
+@pytest.mark.parametrize("rnn,seq_learning,frames", [
+    (("gru", "gru", "aflow", "gru"), True, 4),         # the pretrained configuration (cfg:59)
+    (("aflow", "none", "gru", "aflow"), True, 3),
+    (("gru", "none", "none", "none"), True, 3),        # early frames return right after the PointNet (models.py:307)
+    (("none", "gru", "none", "none"), True, 3),        # ... after the middle fusion (models.py:346)
+    (("gru", "none", "none", "none"), False, 1),       # no sequence learning
+])
+def test_program_equals_operator_route(gpu, rnn, seq_learning, frames):
+    contents = make_config(rnn_modules=rnn, sequence_learning=seq_learning, frames=frames, sigma=0.7)
+    seq = make_sequence(12000, frames, seed=17)
+    model = _prepared(contents, seq, gpu)
+    ref, used = _run(model, contents, seq, gpu)
+    assert not any(used)
+    model.use_frame_program = True
+    for rep in range(2):                               # twice: hidden states must reset with the sequence
+        got, used = _run(model, contents, seq, gpu)
+        assert all(used), "the frame program was not used: %s" % (used,)
+        for t in range(frames):
+            for k in range(2):
+                assert got[t][k].shape == ref[t][k].shape
+                assert torch.equal(got[t][k], ref[t][k]), "frame %d output %d differs (max %.3e)" % (
+                    t, k, float((got[t][k] - ref[t][k]).abs().max()))
+
+
+def test_program_matches_oracle(gpu):
+    contents = make_config(rnn_modules=("gru", "gru", "aflow", "gru"), frames=3, sigma=0.6)
+    seq = make_sequence(15000, 3, seed=31)
+    model = _prepared(contents, seq, gpu, seed=1)
+    model.use_frame_program = True
+    got, used = _run(model, contents, seq, gpu)
+    assert all(used)
+    oracle = oracle_from_model(model, contents)
+    for t, (pos, val) in enumerate(seq):
+        want = oracle.forward(pos, val, early_return=(t != len(seq) - 1))
+        g = got[t][1].cpu()
+        assert g.shape == want.shape
+        err = float((g - want).abs().max())
+        assert err <= 1e-4 * max(1.0, float(want.abs().max())), "frame %d: %.3e" % (t, err)
+
+
+def test_hidden_states_follow_a_frame_that_needs_the_operator_route(gpu):
+    """frames 0-1 through the program, frames 2-3 through the modules: the states are handed over"""
+    contents = make_config(rnn_modules=("gru", "gru", "aflow", "gru"), frames=4, sigma=0.7)
+    seq = make_sequence(9000, 4, seed=5)
+    model = _prepared(contents, seq, gpu)
+    ref, _ = _run(model, contents, seq, gpu)
+    model.use_frame_program = True
+    got, used = _run(model, contents, seq, gpu, switch_off_at=2)
+    assert used == [True, True, False, False]
+    for t in range(4):
+        assert torch.equal(got[t][1], ref[t][1]), "frame %d" % t
+
+
+def test_unsupported_configuration_stays_on_the_operator_route(gpu):
+    contents = make_config(rnn_modules=("maxpool", "linear", "lstm", "cga"), frames=2, sigma=0.8)
+    seq = make_sequence(6000, 2, seed=6)
+    model = _prepared(contents, seq, gpu)
+    model.use_frame_program = True
+    _, used = _run(model, contents, seq, gpu)
+    assert not any(used)
+
+
+def test_program_is_rebuilt_after_a_parameter_update(gpu):
+    contents = make_config(rnn_modules=("gru", "gru", "aflow", "gru"), frames=2, sigma=0.8)
+    seq = make_sequence(6000, 2, seed=8)
+    model = _prepared(contents, seq, gpu)
+    model.use_frame_program = True
+    a, _ = _run(model, contents, seq, gpu)
+    with torch.no_grad():
+        model.recurrent_fusion_modules[1].AFLOW.alpha.fill_(0.25)      # baked into the program by value
+        model.slice_fast_cuda.linear_clasify.bias.add_(1.0)
+    b, used = _run(model, contents, seq, gpu)
+    assert all(used)
+    model.use_frame_program = False
+    c, _ = _run(model, contents, seq, gpu)
+    assert torch.equal(b[-1][1], c[-1][1])
+    assert not torch.equal(a[-1][1], b[-1][1])
