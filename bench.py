@@ -5,7 +5,9 @@
 
 One STEP = one 4-frame sequence (120k points/frame, sigma 0.6, 26 classes, rnn_modules=[gru,gru,aflow,gru], the
 reference's pretrained configuration) through LNN_SEQ.forward: distribute -> PointNet pool -> U-Net of lattice
-convolutions with GRU/AFlow fusion -> slice, inference mode, inputs already resident in HBM.
+convolutions with GRU/AFlow fusion -> slice, inference mode, inputs already resident in HBM — on EVERY one of the
+--streams (default 4) independent sequence streams of a GPU (sequences are independent units, train_ln.py:236-239;
+temporal_latticenet_amd/streams.py).  value = clouds of all streams and ranks / wall time.
 
 --mode sequences (default): every rank runs its own sequences (a sequence owns its lattice and hidden state,
     train_ln.py:236-239), so N GPUs shard the stream of sequences with no data-path collective.
@@ -26,6 +28,10 @@ import os
 import sys
 import time
 
+# concurrent sequence streams want one hardware queue each (HIP's default of 4 is shared with the null stream, so two
+# of four streams would serialise); read by the HIP runtime when it initialises, i.e. before the first device call
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -42,6 +48,9 @@ def parse():
     ap.add_argument("--sigma", type=float, default=0.6)
     ap.add_argument("--rnn", type=str, default="gru,gru,aflow,gru")
     ap.add_argument("--mode", choices=["sequences", "frames"], default="sequences")
+    ap.add_argument("--streams", type=int, default=4,
+                    help="independent sequences in flight per GPU (one HIP stream + host thread + model replica each); "
+                         "one step = one sequence on every stream")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) on the GPU node; gloo for rehearsals")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: all ranks use cuda:0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -137,9 +146,18 @@ def main():
                 for i in range(n):
                     runner.run_sequence(mine, keys[i])
         else:
+            # every stream gets its own synthetic drive (different seed => different vertex counts per stream)
+            from temporal_latticenet_amd.streams import SequenceStreams
+            S = max(1, args.streams)
+            with quiet:
+                pool = SequenceStreams(model, lambda: build_model(contents).eval(), lambda: make_lattice(contents),
+                                       frames, S)
+            per_stream = [frames] + [
+                [(torch.from_numpy(p).cuda(), torch.from_numpy(v).cuda())
+                 for p, v in make_sequence(args.points, args.frames, seed=seed + 1000 * i)] for i in range(1, S)]
+
             def run_steps(n):
-                for _ in range(n):
-                    run_sequence(model, lattice, frames)
+                pool.run([[per_stream[i]] * n for i in range(S)])
 
         run_steps(args.warmup)
         barrier()
@@ -158,60 +176,74 @@ def main():
             vcounts.append([lat.nr_lattice_vertices(), l1.nr_lattice_vertices(), l1.coarsen().nr_lattice_vertices()])
         model.reset_sequence()
 
-        # ---- roofline pass: per-launch HIP-event timing of the dominant kernel over the same workload ----
+        # ---- roofline pass: the dominant kernel (gather-GEMM, fp32 MFMA) over the same workload.  The frame program
+        # remembers the resolved arguments of every gather-GEMM launch of a frame; right after the frame those launches
+        # are replayed back to back between two HIP events on the launch stream (tln_program_replay_gemms), so the
+        # average covers kernel time plus the launch gap and nothing else.
         roof = None
         if rank == 0:
-            # (through the operator-level route, whose wrappers carry the HIP-event hooks; the frame program used in
-            # the timed region launches the very same kernels with the same arguments, tests/test_gpu_engine.py)
-            model.use_frame_program = False
-            ops.profile_begin()
-            reps = max(2, min(args.steps, 5))
-            for _ in range(reps):
-                run_sequence(model, lattice, frames)
-            rec = ops.profile_end()
-            model.use_frame_program = True
-            breakdown = {}
-            for name, ms, meta in rec:
-                d = breakdown.setdefault(name, [0, 0.0])
-                d[0] += 1
-                d[1] += ms
-            g = [(ms, meta) for name, ms, meta in rec if name == "gather_gemm"]
-            tot_ms = sum(ms for ms, _ in g)
-            tot_fl = sum(gemm_flops(m) for _, m in g)
-            tot_by = sum(gemm_bytes(m) for _, m in g)
-            big = [(ms, m) for ms, m in g if m["taps"] == 9 and m["cin"] == 192]
-            big_tf = sum(gemm_flops(m) for _, m in big) / (sum(ms for ms, _ in big) * 1e-3) / 1e12 if big else None
-            achieved = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
-            roof = {"kernel": "k_gather_gemm", "bound": "mfma", "achieved": round(achieved, 3),
-                    "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-                    "traffic": None, "launches_per_step": len(g) // reps,
-                    "avg_launch_us": round(tot_ms * 1e3 / max(len(g), 1), 2),
-                    "flops_per_launch": tot_fl / max(len(g), 1), "algorithmic_bytes_per_launch": tot_by / max(len(g), 1),
-                    "largest_shape_TFLOPs": round(big_tf, 2) if big_tf else None,
-                    "share_of_step_time": round((tot_ms / reps) / (elapsed / args.steps * 1e3), 3)}
-            # HBM-side traffic per launch cannot be read from inside the process: it comes from the two rocprofv3 --pmc
-            # passes of this same workload (FETCH_SIZE, WRITE_SIZE) summarised by tools/pmc_summary.py
-            pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            default_workload = (args.points, args.frames, args.sigma, args.rnn) == (120000, 4, 0.6, "gru,gru,aflow,gru")
-            if os.path.exists(pmc) and default_workload:
-                with open(pmc) as f:
-                    roof["traffic"] = round(json.load(f)["hbm_bytes_per_launch"])
-                roof["traffic_unit"] = "B per launch (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc passes, profiles/pmc_traffic.json)"
+            reps = 5
+            tot_ms, tot_n, tot_fl, tot_by = 0.0, 0, 0.0, 0.0
+            lat = make_lattice(contents)
+            for t, (pos, val) in enumerate(frames):
+                model(lat, pos, val, t != len(frames) - 1, False)
+                prog = getattr(model, "_program", None)
+                if prog is None or not getattr(model, "_program_active", False):
+                    break
+                prog.capture_gemms(True)
+                if t == 0:      # capture starts with the NEXT frame: run frame 0 again on a fresh lattice
+                    model.reset_sequence()
+                    lat = make_lattice(contents)
+                    model(lat, pos, val, t != len(frames) - 1, False)
+                ms, n, fl, by = prog.replay_gemms(reps)
+                tot_ms, tot_n, tot_fl, tot_by = tot_ms + ms, tot_n + n, tot_fl + fl, tot_by + by
+            model.reset_sequence()
+            if getattr(model, "_program", None) is not None:
+                model._program.capture_gemms(False)
+            if tot_n:
+                achieved = tot_fl / (tot_ms * 1e-3) / 1e12
+                roof = {"kernel": "k_gather_gemm", "bound": "mfma", "achieved": round(achieved, 3),
+                        "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+                        "traffic": None, "launches_per_step": tot_n // reps,
+                        "avg_launch_us": round(tot_ms * 1e3 / tot_n, 2),
+                        "flops_per_launch": tot_fl / tot_n, "algorithmic_bytes_per_launch": tot_by / tot_n,
+                        "note": "every gather-GEMM op of one 4-frame sequence (the GRU cell's two internal products "
+                                "excluded), replayed back to back on one stream running alone"}
+                # HBM-side traffic per launch cannot be read from inside the process: it comes from the two rocprofv3
+                # --pmc passes of this same workload (FETCH_SIZE, WRITE_SIZE) summarised by tools/pmc_summary.py
+                pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+                default_workload = (args.points, args.frames, args.sigma, args.rnn) == (120000, 4, 0.6, "gru,gru,aflow,gru")
+                if os.path.exists(pmc) and default_workload:
+                    with open(pmc) as f:
+                        roof["traffic"] = round(json.load(f)["hbm_bytes_per_launch"])
+                    roof["traffic_unit"] = "B per launch (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc passes, " \
+                                           "profiles/pmc_traffic.json)"
             if args.breakdown:
-                for k, (cnt, ms) in sorted(breakdown.items(), key=lambda kv: -kv[1][1]):
-                    print("  %-16s %5d calls/step %9.3f ms/step" % (k, cnt // reps, ms / reps), file=sys.stderr)
-                shapes = {}
-                for ms, m in g:
-                    key = (m["M"] // 100 * 100, m["cin"], m["taps"], m["N"])
-                    d = shapes.setdefault(key, [0, 0.0, 0.0])
+                model.use_frame_program = False
+                ops.profile_begin()
+                for _ in range(3):
+                    run_sequence(model, lattice, frames)
+                rec = ops.profile_end()
+                model.use_frame_program = True
+                breakdown, shapes = {}, {}
+                for name, ms, meta in rec:
+                    d = breakdown.setdefault(name, [0, 0.0])
                     d[0] += 1
                     d[1] += ms
-                    d[2] += gemm_flops(m)
-                print("  gather_gemm by shape (M~, cin, taps, N): calls/step, us/call, TFLOP/s", file=sys.stderr)
+                    if name == "gather_gemm":
+                        key = (meta["M"] // 100 * 100, meta["cin"], meta["taps"], meta["N"])
+                        e = shapes.setdefault(key, [0, 0.0, 0.0])
+                        e[0] += 1
+                        e[1] += ms
+                        e[2] += gemm_flops(meta)
+                for k, (cnt, ms) in sorted(breakdown.items(), key=lambda kv: -kv[1][1]):
+                    print("  %-16s %5d calls/step %9.3f ms/step" % (k, cnt // 3, ms / 3), file=sys.stderr)
+                print("  gather_gemm by shape (M~, cin, taps, N): calls/step, us/call (HIP events around each operator "
+                      "call), TFLOP/s", file=sys.stderr)
                 for k, (cnt, ms, fl) in sorted(shapes.items(), key=lambda kv: -kv[1][1])[:24]:
-                    print("    %-22s %4.1f %8.1f %7.2f" % (k, cnt / reps, ms * 1e3 / cnt, fl / ms / 1e9), file=sys.stderr)
+                    print("    %-22s %4.1f %8.1f %7.2f" % (k, cnt / 3, ms * 1e3 / cnt, fl / ms / 1e9), file=sys.stderr)
 
-    groups = plan.nr_groups if frames_mode else args.gpus
+    groups = plan.nr_groups if frames_mode else args.gpus * max(1, args.streams)
     clouds = groups * args.steps * args.frames
     value = clouds / elapsed
 
@@ -222,7 +254,8 @@ def main():
     if rank == 0:
         par = ("frames of a sequence sharded over %d ranks (key all-gather + hidden-state hand-off), %d group(s)"
                % (plan.group_size, plan.nr_groups)) if frames_mode else \
-            "one sequence stream per GPU (no data-path collective)"
+            "%d independent sequence stream(s) per GPU, each on its own HIP stream; one step = one %d-frame sequence on " \
+            "every stream (no data-path collective)" % (max(1, args.streams), args.frames)
         line = {
             "metric": "point-clouds/sec (120k pts, sigma=0.6, 4-frame seq)",
             "value": round(value, 3), "unit": "clouds/s", "n_gpus": args.gpus, "steps": args.steps,

@@ -298,6 +298,13 @@ int tln_program_begin_frame(tln_program_t* p, tln_lattice_t* l, const float* d_p
 /* the rest of the frame.  early != 0: stop at the program's STOP_IF_EARLY op and copy that slot to d_out;
  * else the TLN_SLOT_OUT slot is d_out.  d_out must hold out_rows x out_cols floats (checked). */
 int tln_program_run(tln_program_t* p, int early, float* d_out, int64_t out_rows, int out_cols, void* stream);
+/* measurement (bench.py roofline): with capture on, tln_program_run remembers the resolved arguments of every
+ * gather-GEMM it launches; replay launches that list `reps` times back to back between two HIP events on `stream`
+ * and returns the elapsed milliseconds, the number of launches and their algorithmic flops / bytes.
+ * The frame's buffers are still in place, so the replays recompute the same values. */
+int tln_program_capture_gemms(tln_program_t* p, int enable);
+int tln_program_replay_gemms(tln_program_t* p, int reps, double* ms_total, int64_t* launches, double* flops,
+                             double* bytes, void* stream);
 /* device pointers of the current frame's K1 outputs ([4N, 3+val_dim+1], [4N], [4N]); valid until the next frame */
 int tln_program_frame_rows(tln_program_t* p, const float** d_distributed, const int32_t** d_indices,
                            const float** d_weights, int64_t* rows, int* cols);

@@ -100,6 +100,9 @@ _PROTOS = {
     "tln_program_reset": (_i, [_vp]),
     "tln_program_begin_frame": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, C.POINTER(_i64), _vp]),
     "tln_program_run": (_i, [_vp, _i, _vp, _i64, _i, _vp]),
+    "tln_program_capture_gemms": (_i, [_vp, _i]),
+    "tln_program_replay_gemms": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(C.c_double),
+                                      C.POINTER(C.c_double), _vp]),
     "tln_program_frame_rows": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i64),
                                     C.POINTER(_i)]),
     "tln_program_state_info": (_i, [_vp, _i, C.POINTER(_i64), C.POINTER(_i), C.POINTER(_i)]),

@@ -641,22 +641,24 @@ __global__ void __launch_bounds__(512) k_gather_gemm_direct(const GemmArgs g) {
     double2* Gp = reinterpret_cast<double2*>(smem);  // [J][cin0]
     for (int idx = threadIdx.x; idx < J * cin0; idx += T) {
       const int c = idx % cin0, j = idx / cin0;
-      double sx[2] = {0.0, 0.0}, sq[2] = {0.0, 0.0};
-      int bb = j;
-      for (; bb + J < s.gn_nblk; bb += 2 * J) {  // two independent chains, fixed order
-        const double2 p0 = s.gn_part[(int64_t)bb * cin0 + c];
-        const double2 p1 = s.gn_part[(int64_t)(bb + J) * cin0 + c];
-        sx[0] += p0.x;
-        sq[0] += p0.y;
-        sx[1] += p1.x;
-        sq[1] += p1.y;
+      // partial blocks j, j+J, j+2J, ...: eight loads in flight per batch, added in block order (deterministic)
+      double sx = 0.0, sq = 0.0;
+      for (int bb = j; bb < s.gn_nblk; bb += 8 * J) {
+        double2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int b = bb + u * J;
+          const int bc = b < s.gn_nblk ? b : j;  // clamped address, masked below
+          v[u] = s.gn_part[(int64_t)bc * cin0 + c];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (bb + u * J < s.gn_nblk) {
+            sx += v[u].x;
+            sq += v[u].y;
+          }
       }
-      if (bb < s.gn_nblk) {
-        const double2 p0 = s.gn_part[(int64_t)bb * cin0 + c];
-        sx[0] += p0.x;
-        sq[0] += p0.y;
-      }
-      Gp[idx] = make_double2(sx[0] + sx[1], sq[0] + sq[1]);
+      Gp[idx] = make_double2(sx, sq);
     }
     __syncthreads();
     for (int c = threadIdx.x; c < cin0; c += T) {
@@ -779,31 +781,40 @@ static int fill_src(SrcDev& d, const tln_gemm_src* s) {
   return TLN_OK;
 }
 
-// split-K workspace (slabs + arrival counters), one per process; the library serialises on the caller's stream
-// (a handle / op set is used from one stream at a time, INTEGRATION.md "Threading")
-static float* g_slab = nullptr;
-static size_t g_slab_floats = 0;
-static int* g_counters = nullptr;
-static size_t g_counter_ints = 0;
+// split-K workspace (slabs + arrival counters), one per stream: independent sequences may run concurrently on
+// several streams (one host thread each), and a slab is only safe under the stream order of its own launches
+#include <mutex>
+#include <unordered_map>
+struct SplitKWs {
+  float* slab = nullptr;
+  size_t slab_floats = 0;
+  int* counters = nullptr;
+  size_t counter_ints = 0;
+};
+static std::mutex g_ws_mutex;
+static std::unordered_map<hipStream_t, SplitKWs> g_ws;
 
-static int ensure_splitk_ws(size_t slab_floats, size_t counters, hipStream_t s) {
-  if (slab_floats > g_slab_floats) {
+static int ensure_splitk_ws(size_t slab_floats, size_t counters, hipStream_t s, SplitKWs* out) {
+  std::lock_guard<std::mutex> lock(g_ws_mutex);
+  SplitKWs& w = g_ws[s];
+  if (slab_floats > w.slab_floats) {
     TLN_HIP(hipStreamSynchronize(s));
-    if (g_slab) (void)hipFree(g_slab);
-    g_slab = nullptr;
-    size_t want = slab_floats < (size_t)(16u << 20) ? (size_t)(16u << 20) : slab_floats;  // >= 64 MB
-    TLN_HIP(hipMalloc(&g_slab, want * sizeof(float)));
-    g_slab_floats = want;
+    if (w.slab) (void)hipFree(w.slab);
+    w.slab = nullptr;
+    size_t want = slab_floats < (size_t)(4u << 20) ? (size_t)(4u << 20) : slab_floats;  // >= 16 MB
+    TLN_HIP(hipMalloc(&w.slab, want * sizeof(float)));
+    w.slab_floats = want;
   }
-  if (counters > g_counter_ints) {
+  if (counters > w.counter_ints) {
     TLN_HIP(hipStreamSynchronize(s));
-    if (g_counters) (void)hipFree(g_counters);
-    g_counters = nullptr;
+    if (w.counters) (void)hipFree(w.counters);
+    w.counters = nullptr;
     size_t want = counters < 65536 ? 65536 : counters;
-    TLN_HIP(hipMalloc(&g_counters, want * sizeof(int)));
-    TLN_HIP(hipMemsetAsync(g_counters, 0, want * sizeof(int), s));
-    g_counter_ints = want;
+    TLN_HIP(hipMalloc(&w.counters, want * sizeof(int)));
+    TLN_HIP(hipMemsetAsync(w.counters, 0, want * sizeof(int), s));
+    w.counter_ints = want;
   }
+  *out = w;
   return TLN_OK;
 }
 
@@ -835,10 +846,11 @@ static int launch_gemm(GemmArgs& g, int splits, hipStream_t s) {
   g.splits = splits;
   if (splits > 1) {
     const size_t ntiles = (size_t)grid.x * grid.y;
-    int rc = ensure_splitk_ws((size_t)splits * ntiles * ACC * GT, ntiles, s);
+    SplitKWs w;
+    int rc = ensure_splitk_ws((size_t)splits * ntiles * ACC * GT, ntiles, s, &w);
     if (rc) return rc;
-    g.slab = g_slab;
-    g.counters = g_counters;
+    g.slab = w.slab;
+    g.counters = w.counters;
   }
   hipLaunchKernelGGL(kern, grid, dim3(GT * G), lds, s, g);
   return TLN_OK;
@@ -1007,8 +1019,12 @@ extern "C" int tln_gather_gemm_ex(int64_t M, int N, const tln_gemm_src* s0, cons
     // enough waves to cover the SIMDs a few times over, 2..8 chunks per wave
     const int64_t tiles = tln_cdiv(M, 32) * tln_cdiv(N, 32);
     int G = g_force_groups ? g_force_groups : 1;
-    if (!g_force_groups)
-      while (G < 8 && nchunks >= 3 * (G + 1) && tiles * G < 4096) ++G;
+    if (!g_force_groups) {
+      // as many waves per tile as keep ALL blocks resident at once: 256 CUs x floor(12 / G) blocks (3 waves per SIMD
+      // at this kernel's VGPR count), and at least 3 chunks per wave
+      for (int cand = 2; cand <= 8; ++cand)
+        if (nchunks >= 3 * cand && tiles <= (int64_t)256 * (12 / cand)) G = cand;
+    }
     rc = w_is_nk ? launch_direct<true>(g, nchunks, G, s) : launch_direct<false>(g, nchunks, G, s);
     if (rc) return rc;
     TLN_LAUNCH_CHECK();

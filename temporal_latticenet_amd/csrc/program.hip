@@ -79,6 +79,23 @@ int ensure_buf(DevBuf& b, size_t bytes, hipStream_t s, bool keep_contents = fals
   return TLN_OK;
 }
 
+// one resolved gather-GEMM launch of the last frame (measurement: tln_program_replay_gemms)
+struct GemmCall {
+  int64_t M;
+  int N;
+  tln_gemm_src a[2];
+  bool two;
+  const float* w;
+  int w_is_nk;
+  const float* bias;
+  const float* res;
+  int64_t ld_res;
+  int relu;
+  float* out;
+  int64_t ld_out;
+  void* stats;
+};
+
 struct SlotRt {
   bool live = false;
   size_t off = 0, bytes = 0;
@@ -113,6 +130,8 @@ struct tln_program {
   DevBuf arena;
   Arena alloc;
   std::vector<SlotRt> rt;
+  bool capture = false;
+  std::vector<GemmCall> calls;
 };
 
 namespace {
@@ -286,6 +305,12 @@ int walk(tln_program* p, bool dry, int early, float* d_out, int64_t out_rows, in
                                 o.relu, fptr(o.out) + o.out_col, so.cols,
                                 o.stats_out >= 0 ? p->rt[o.stats_out].ptr : nullptr, s);
         if (rc) return rc;
+        if (p->capture && M > 0) {
+          GemmCall c{M, o.n, {a[0], a[1]}, o.s1.slot >= 0, o.w, o.w_is_nk, o.bias, res, ld_res, o.relu,
+                     fptr(o.out) + o.out_col, so.cols, o.stats_out >= 0 ? p->rt[o.stats_out].ptr : nullptr};
+          if (!c.two) c.a[1] = tln_gemm_src{};
+          p->calls.push_back(c);
+        }
         break;
       }
       case TLN_OP_GN_PARTIALS: {
@@ -522,9 +547,66 @@ extern "C" int tln_program_run(tln_program_t* p, int early, float* d_out, int64_
   if (rc) return rc;
   rc = ensure_buf(p->arena, p->alloc.high + kAlign, s);
   if (rc) return rc;
+  p->calls.clear();
   rc = walk(p, false, early, d_out, out_rows, out_cols, s);
   p->frame_open = false;
   return rc;
+}
+
+// ---- measurement: the gather-GEMM launches of the last frame, replayed back to back between two HIP events ------
+extern "C" int tln_program_capture_gemms(tln_program_t* p, int enable) {
+  TLN_REQUIRE(p, "null program");
+  p->capture = enable != 0;
+  if (!p->capture) p->calls.clear();
+  return TLN_OK;
+}
+
+extern "C" int tln_program_replay_gemms(tln_program_t* p, int reps, double* ms_total, int64_t* launches, double* flops,
+                                        double* bytes, void* stream_) {
+  TLN_REQUIRE(p && reps > 0 && ms_total && launches && flops && bytes, "bad replay arguments");
+  hipStream_t s = (hipStream_t)stream_;
+  *ms_total = 0.0;
+  *launches = 0;
+  *flops = 0.0;
+  *bytes = 0.0;
+  if (p->calls.empty()) return TLN_OK;
+  hipEvent_t e0, e1;
+  TLN_HIP(hipEventCreate(&e0));
+  TLN_HIP(hipEventCreate(&e1));
+  auto launch_all = [&]() -> int {
+    for (const GemmCall& c : p->calls) {
+      int rc = tln_gather_gemm_ex(c.M, c.N, &c.a[0], c.two ? &c.a[1] : nullptr, c.w, c.w_is_nk, c.bias, c.res, c.ld_res,
+                                  c.relu, c.out, c.ld_out, c.stats, s);
+      if (rc) return rc;
+    }
+    return TLN_OK;
+  };
+  int rc = launch_all();  // warm
+  if (!rc) {
+    TLN_HIP(hipEventRecord(e0, s));
+    for (int r = 0; r < reps && !rc; ++r) rc = launch_all();
+    TLN_HIP(hipEventRecord(e1, s));
+    TLN_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    TLN_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *ms_total = ms;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (rc) return rc;
+  for (const GemmCall& c : p->calls) {
+    const double K = (double)c.a[0].taps * c.a[0].cin + (c.two ? (double)c.a[1].taps * c.a[1].cin : 0.0);
+    const double cin = (double)c.a[0].cin + (c.two ? (double)c.a[1].cin : 0.0);
+    *flops += 2.0 * (double)c.M * K * c.N;
+    // algorithmic bytes: every source row once, the output once, the weights, the tap table,
+    // the residual if any
+    *bytes += 4.0 * ((double)c.M * cin + (double)c.M * c.N + K * c.N) + 4.0 * (double)c.M * c.a[0].taps +
+              (c.res ? 4.0 * (double)c.M * c.N : 0.0);
+  }
+  *launches = (int64_t)p->calls.size() * reps;
+  *flops *= reps;
+  *bytes *= reps;
+  return TLN_OK;
 }
 
 extern "C" int tln_program_frame_rows(tln_program_t* p, const float** d_distributed, const int32_t** d_indices,

@@ -368,6 +368,17 @@ class FrameProgram:
         ls.set_values(out)
         return out, ls
 
+    def capture_gemms(self, enable=True):
+        _lib.check(_lib.lib().tln_program_capture_gemms(self._h, 1 if enable else 0), "tln_program_capture_gemms")
+
+    def replay_gemms(self, reps=5):
+        """(ms, launches, flops, algorithmic bytes) of the last frame's gather-GEMM launches replayed `reps` times
+        back to back between two HIP events on the current stream"""
+        ms, n, fl, by = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
+        _lib.check(_lib.lib().tln_program_replay_gemms(self._h, reps, C.byref(ms), C.byref(n), C.byref(fl),
+                                                       C.byref(by), stream_ptr()), "tln_program_replay_gemms")
+        return ms.value, n.value, fl.value, by.value
+
     def state(self, sid):
         """copy of hidden state `sid` (None if it does not exist yet)"""
         rows, cols, has = C.c_int64(), C.c_int(), C.c_int()

@@ -1,0 +1,122 @@
+"""Several independent sequences at once on one GPU: one HIP stream, one host thread and one model replica per
+sequence stream, all replicas sharing the same parameter tensors.
+
+Why: a frame at sigma=0.6 touches a few thousand lattice vertices, so its ~75 launches are latency-bound and leave most
+of the 256 CUs idle; sequences are independent units (a fresh lattice and fresh hidden states per sequence,
+train_ln.py:236-239), so running a few of them concurrently fills the machine without any change to the arithmetic —
+every stream computes exactly what it would compute alone (tests/test_gpu_streams.py).  The frame program
+(engine.py) keeps the host cost per frame at two native calls, which release the GIL, so plain threads scale.
+"""
+import contextlib
+import io
+import os
+import queue
+import threading
+
+# one hardware queue per stream: HIP's default of 4 is shared with the null stream, so two of four concurrent streams
+# would serialise (measured: 1.9k vs 2.8k clouds/s).  Only effective if the HIP runtime has not initialised yet.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+import torch  # noqa: E402
+
+__all__ = ["share_parameters", "SequenceStreams"]
+
+
+def share_parameters(replica, base):
+    """make every parameter / buffer of `replica` the SAME tensor object as in `base` (both already ran one sequence,
+    so their lazily created parameters exist)"""
+    base_params = dict(base.named_parameters())
+    base_bufs = dict(base.named_buffers())
+    mods = dict(replica.named_modules())
+    for name, _ in list(replica.named_parameters()):
+        owner, _, leaf = name.rpartition(".")
+        if name not in base_params:
+            raise KeyError("parameter %s exists in the replica only" % name)
+        mods[owner]._parameters[leaf] = base_params[name]
+    for name, _ in list(replica.named_buffers()):
+        owner, _, leaf = name.rpartition(".")
+        if name in base_bufs:
+            mods[owner]._buffers[leaf] = base_bufs[name]
+    return replica
+
+
+class SequenceStreams:
+    """S replicas of a model on S HIP streams.  `run(batches)` pushes batch i (a list of sequences, each a list of
+    (positions, values) frames resident on the device) through replica i in its own thread and returns, per stream,
+    the per-sequence outputs of the last frame."""
+
+    def __init__(self, base_model, make_model, make_lattice, warm_sequence, n_streams):
+        self.models = [base_model]
+        self.make_lattice = make_lattice
+        quiet = contextlib.redirect_stdout(io.StringIO())
+        for _ in range(n_streams - 1):
+            with quiet, torch.no_grad():
+                m = make_model()
+                m.train(base_model.training)
+                lat = make_lattice()
+                for t, (p, v) in enumerate(warm_sequence):           # creates the lazily built parameters
+                    m(lat, p, v, t != len(warm_sequence) - 1, False)
+                m.reset_sequence()
+            self.models.append(share_parameters(m, base_model))
+        self.streams = [torch.cuda.Stream() for _ in range(n_streams)]
+        self.lattices = [make_lattice() for _ in range(n_streams)]
+        # persistent workers (a fresh host thread pays HIP's per-thread set-up on its first call)
+        self._jobs = [queue.Queue() for _ in range(n_streams)]
+        self._done = queue.Queue()
+        self._threads = [threading.Thread(target=self._loop, args=(i,), daemon=True) for i in range(1, n_streams)]
+        for t in self._threads:
+            t.start()
+
+    def __len__(self):
+        return len(self.models)
+
+    def close(self):
+        for i in range(1, len(self.models)):
+            self._jobs[i].put(None)
+        for t in self._threads:
+            t.join()
+        self._threads = []
+
+    def _loop(self, i):
+        torch.cuda.set_device(self.streams[i].device)
+        while True:
+            job = self._jobs[i].get()
+            if job is None:
+                return
+            self._done.put((i,) + self._work(i, *job))
+
+    def _work(self, i, sequences, keep_outputs):
+        try:
+            model, lat = self.models[i], self.lattices[i]
+            outs = []
+            with torch.no_grad(), torch.cuda.stream(self.streams[i]):
+                for seq in sequences:
+                    for t, (p, v) in enumerate(seq):
+                        out, raw, lat = model(lat, p, v, t != len(seq) - 1, False)
+                    model.reset_sequence()
+                    if keep_outputs:
+                        outs.append(raw)
+                self.streams[i].synchronize()
+            return outs, None
+        except BaseException as e:      # surfaced by run()
+            return None, e
+
+    def run(self, batches, keep_outputs=False):
+        n = len(self.models)
+        assert len(batches) == n
+        cur = torch.cuda.current_stream()
+        for s in self.streams:           # inputs prepared on the caller's stream are ready for every worker
+            s.wait_stream(cur)
+        for i in range(1, n):
+            self._jobs[i].put((batches[i], keep_outputs))
+        results, errors = [None] * n, [None] * n
+        results[0], errors[0] = self._work(0, batches[0], keep_outputs)
+        for _ in range(1, n):
+            i, outs, err = self._done.get()
+            results[i], errors[i] = outs, err
+        for e in errors:
+            if e is not None:
+                raise e
+        for s in self.streams:
+            cur.wait_stream(s)
+        return results

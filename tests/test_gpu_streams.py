@@ -1,0 +1,43 @@
+"""GPU: independent sequences on concurrent HIP streams (temporal_latticenet_amd/streams.py) compute exactly what each
+would compute alone — same kernels, per-stream lattices, hidden states and workspaces."""
+import pytest
+import torch
+
+from tests.helpers import build_model, make_config, make_lattice, randomize_parameters
+from temporal_latticenet_amd.streams import SequenceStreams
+from temporal_latticenet_amd.synthetic import make_sequence
+
+pytestmark = pytest.mark.gpu
+
+
+def _alone(model, contents, seq):
+    lat = make_lattice(contents)
+    with torch.no_grad():
+        for t, (p, v) in enumerate(seq):
+            a, b, lat = model(lat, p, v, t != len(seq) - 1, False)
+    model.reset_sequence()
+    return b.clone()
+
+
+@pytest.mark.parametrize("frame_program", [True, False])
+def test_concurrent_streams_equal_the_single_stream_results(gpu, frame_program):
+    contents = make_config(rnn_modules=("gru", "gru", "aflow", "gru"), frames=3, sigma=0.7)
+    S = 3
+    seqs = [[(torch.from_numpy(p).to(gpu), torch.from_numpy(v).to(gpu)) for p, v in make_sequence(9000 + 500 * s, 3, seed=70 + s)]
+            for s in range(2 * S)]
+    model = build_model(contents).eval()
+    _alone(model, contents, seqs[0])
+    randomize_parameters(model, seed=9)
+    model.use_frame_program = frame_program
+    want = [_alone(model, contents, s) for s in seqs]
+    pool = SequenceStreams(model, lambda: build_model(contents).eval(), lambda: make_lattice(contents), seqs[0], S)
+    for m in pool.models:
+        m.use_frame_program = frame_program
+    assert pool.models[1].point_net_seq.layers[0].weight is model.point_net_seq.layers[0].weight
+    for rep in range(3):
+        got = pool.run([[seqs[i], seqs[S + i]] for i in range(S)], keep_outputs=True)
+        for i in range(S):
+            assert torch.equal(got[i][0], want[i]), "stream %d, first sequence" % i
+            assert torch.equal(got[i][1], want[S + i]), "stream %d, second sequence" % i
+    if frame_program:
+        assert all(getattr(m, "_program", None) is not None for m in pool.models)
