@@ -479,7 +479,7 @@ __global__ void __launch_bounds__(128 * WM * G) k_gather_gemm(const GemmArgs g) 
 //        4 x dwordx4 — exactly its operands of the 16 MFMAs of the chunk (the k order inside a chunk is permuted,
 //        identically for A and B, which the product does not see); no LDS round trip, no transposition, no barrier
 //   * B: [K,N] weights: 16 coalesced dword loads (row c0+16*half+s, column n0 + lane&31); [N,K] weights: 4 x dwordx4
-//   * G waves per block interleave over the chunk list (G = blockDim/64, up to 8) and are summed through LDS in
+//   * G waves per block interleave over the chunk list (G = blockDim/64, up to 12) and are summed through LDS in
 //     fixed order; chunk loads run DEPTH chunks ahead in registers
 //   * the tap indices of a lane's row sit in 9 registers; the GroupNorm finalise of the prologue runs while the
 //     first chunk loads are in flight, with all threads sharing the partial-sum reduction
@@ -489,7 +489,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define TLN_DIRECT_DEPTH 2
 
 template <bool W_NK>
-__global__ void __launch_bounds__(512) k_gather_gemm_direct(const GemmArgs g) {
+__global__ void __launch_bounds__(768) k_gather_gemm_direct(const GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int T = blockDim.x, G = T >> 6;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -505,7 +505,7 @@ __global__ void __launch_bounds__(512) k_gather_gemm_direct(const GemmArgs g) {
   const int cin0 = g.s[0].cin;
   const bool gn_lds = g.s[0].gn_part != nullptr;
   const bool pro_lds = gn_lds || g.s[0].scale != nullptr;
-  int region = (G - 1) * 16 * 64;
+  int region = G * 16 * 64 + 4 * T;  // G parked accumulator tiles + the statistics partials of the epilogue
   int J = 1;
   if (gn_lds) {
     J = T / cin0;
@@ -520,6 +520,15 @@ __global__ void __launch_bounds__(512) k_gather_gemm_direct(const GemmArgs g) {
 
   const bool stamp = g.dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0;
   if (stamp) g.dbg[0] = __builtin_amdgcn_s_memtime();
+
+  // small operands needed much later: asked for now, so that their latency hides behind everything else
+  const int ncb = n0 + (threadIdx.x & 31);
+  const float bias_r = (g.bias && ncb < g.N) ? g.bias[ncb] : 0.f;
+  float gamma_r = 1.f, beta_r = 0.f;
+  if (gn_lds && (int)threadIdx.x < cin0) {
+    if (g.s[0].gn_gamma) gamma_r = g.s[0].gn_gamma[threadIdx.x];
+    if (g.s[0].gn_beta) beta_r = g.s[0].gn_beta[threadIdx.x];
+  }
 
   // tap indices of the block's 32 rows (source 0): one contiguous 1152-byte span of the table -> LDS
   const int64_t mc = mrow ? m : g.M - 1;  // rows past M work on row M-1 (their outputs are never stored)
@@ -661,30 +670,26 @@ __global__ void __launch_bounds__(512) k_gather_gemm_direct(const GemmArgs g) {
       Gp[idx] = make_double2(sx, sq);
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < cin0; c += T) {
-      double sx = 0.0, sq = 0.0;
-      for (int j = 0; j < J; ++j) {
-        sx += Gp[j * cin0 + c].x;
-        sq += Gp[j * cin0 + c].y;
-      }
-      Gch[c] = make_double2(sx, sq);
-    }
-    __syncthreads();
+    // group statistics straight from the J x cin0 partials (every thread of a group repeats the group's sum: no
+    // second LDS round, no second barrier), fixed order => deterministic
     const int cpg = cin0 / s.gn_groups;
     for (int c = threadIdx.x; c < cin0; c += T) {
       const int g0 = (c / cpg) * cpg;
       double sx = 0.0, sq = 0.0;
-      for (int j = 0; j < cpg; ++j) {
-        sx += Gch[g0 + j].x;
-        sq += Gch[g0 + j].y;
-      }
+      for (int ch = 0; ch < cpg; ++ch)
+        for (int j = 0; j < J; ++j) {
+          const double2 v = Gp[j * cin0 + g0 + ch];
+          sx += v.x;
+          sq += v.y;
+        }
       const double cnt = (double)s.gn_rows * (double)cpg;
       const double mean = sx / cnt;
       double var = sq / cnt - mean * mean;
       if (var < 0.0) var = 0.0;
       const double rstd = 1.0 / sqrt(var + (double)s.gn_eps);
-      const double gm = s.gn_gamma ? (double)s.gn_gamma[c] : 1.0;
-      const double bt = s.gn_beta ? (double)s.gn_beta[c] : 0.0;
+      const bool mine = c == (int)threadIdx.x;  // c >= T only when cin0 > T: those load their affine pair here
+      const double gm = mine ? (double)gamma_r : (s.gn_gamma ? (double)s.gn_gamma[c] : 1.0);
+      const double bt = mine ? (double)beta_r : (s.gn_beta ? (double)s.gn_beta[c] : 0.0);
       Gsc[c] = (float)(gm * rstd);
       Gsh[c] = (float)(bt - mean * rstd * gm);
     }
@@ -712,40 +717,48 @@ __global__ void __launch_bounds__(512) k_gather_gemm_direct(const GemmArgs g) {
     if (it + d < iters) compute(a[d], b[d], meta[d]);
   if (stamp) g.dbg[2] = __builtin_amdgcn_s_memtime();
 
-  // ---- sum the waves through LDS in fixed order 0..G-1 (the GroupNorm scratch is dead: every wave passed the
-  // barrier after its last use)
-  if (G > 1) {
-    float* red = smem;
-    if (wv > 0) {
+  // ---- all waves park their accumulators in LDS (the GroupNorm scratch is dead: every wave passed the barrier
+  // after its last use); then the WHOLE block finishes the tile: thread t owns column t&31 and rows t>>5, +T/32, ...
+  // sums the G partial tiles in fixed order 0..G-1, applies the epilogue and stores coalesced rows.
+  float* red = smem;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) red[((wv - 1) * 16 + r) * 64 + lane] = acc[r];
-    }
-    __syncthreads();
-    if (wv > 0) return;
-    for (int gg = 1; gg < G; ++gg)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] += red[((gg - 1) * 16 + r) * 64 + lane];
-  }
+  for (int r = 0; r < 16; ++r) red[(wv * 16 + r) * 64 + lane] = acc[r];
+  __syncthreads();
   if (stamp) g.dbg[3] = __builtin_amdgcn_s_memtime();
-
-  // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-  const float bias = (ncol && g.bias) ? g.bias[n] : 0.f;
-  double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int64_t mr = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-    if (!ncol || mr >= g.M) continue;
-    float v = acc[r] + bias;
-    if (g.res) v += g.res[mr * g.ld_res + n];
-    if (g.relu) v = fmaxf(v, 0.f);
-    g.out[mr * g.ld_out + n] = v;
-    s1 += (double)v;
-    s2 += (double)v * (double)v;
-  }
-  if (g.stats) {
-    s1 += __shfl_xor(s1, 32, 64);
-    s2 += __shfl_xor(s2, 32, 64);
-    if (half == 0 && ncol) g.stats[(m0 >> 5) * g.N + n] = make_double2(s1, s2);
+  {
+    const int col = threadIdx.x & 31;
+    const int nn = n0 + col;
+    const bool cok = nn < g.N;
+    const int rstep = T >> 5;
+    double s1 = 0.0, s2 = 0.0;
+    for (int row = threadIdx.x >> 5; row < 32; row += rstep) {
+      // C/D layout of the MFMA: element (row, col) sits in register (row&3) + 4*(row>>3) of lane ((row>>2)&1)*32 + col
+      const int idx = ((row & 3) + 4 * (row >> 3)) * 64 + ((row >> 2) & 1) * 32 + col;
+      float v = red[idx];
+      for (int w = 1; w < G; ++w) v += red[w * 1024 + idx];
+      const int64_t mr = m0 + row;
+      if (cok && mr < g.M) {
+        v += bias_r;
+        if (g.res) v += g.res[mr * g.ld_res + nn];
+        if (g.relu) v = fmaxf(v, 0.f);
+        g.out[mr * g.ld_out + nn] = v;
+        s1 += (double)v;
+        s2 += (double)v * (double)v;
+      }
+    }
+    if (g.stats) {  // per-column (sum, sumsq) over the tile's rows: partials per row group, combined in fixed order
+      double2* sp = reinterpret_cast<double2*>(smem + G * 1024);
+      sp[threadIdx.x] = make_double2(s1, s2);
+      __syncthreads();
+      if (threadIdx.x < 32 && cok) {
+        double t1 = 0.0, t2 = 0.0;
+        for (int k = 0; k < rstep; ++k) {
+          t1 += sp[k * 32 + threadIdx.x].x;
+          t2 += sp[k * 32 + threadIdx.x].y;
+        }
+        g.stats[(m0 >> 5) * g.N + nn] = make_double2(t1, t2);
+      }
+    }
   }
   if (stamp) g.dbg[4] = __builtin_amdgcn_s_memtime();
 }
@@ -875,11 +888,11 @@ template <bool W_NK>
 static int launch_direct(GemmArgs& g, int nchunks, int groups, hipStream_t s) {
   int G = groups;
   if (G < 1) G = 1;
-  if (G > 8) G = 8;
+  if (G > 12) G = 12;
   if (G > nchunks) G = nchunks;
   const int T = 64 * G;
   const int cin0 = g.s[0].cin;
-  size_t region = (size_t)(G - 1) * 16 * 64;
+  size_t region = (size_t)G * 16 * 64 + (size_t)4 * T;
   if (g.s[0].gn_part) {
     int J = T / cin0;
     if (J < 1) J = 1;
@@ -888,7 +901,15 @@ static int launch_direct(GemmArgs& g, int nchunks, int groups, hipStream_t s) {
     if (need > region) region = need;
   }
   const size_t lds = (region + (size_t)6 * cin0 + 32 * TLN_TAPS + 4) * sizeof(float);
-  TLN_REQUIRE(lds <= 64 * 1024, "direct gemm: LDS %zu B", lds);
+  TLN_REQUIRE(lds <= 96 * 1024, "direct gemm: LDS %zu B", lds);
+  if (lds > 48 * 1024) {
+    static size_t attr_bytes = 0;  // per instantiation
+    if (lds > attr_bytes) {
+      TLN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gather_gemm_direct<W_NK>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+      attr_bytes = 96 * 1024;
+    }
+  }
   dim3 grid((unsigned)tln_cdiv(g.M, 32), (unsigned)tln_cdiv(g.N, 32), 1);
   g.splits = 1;
   hipLaunchKernelGGL(k_gather_gemm_direct<W_NK>, grid, dim3(T), lds, s, g);
@@ -1020,10 +1041,17 @@ extern "C" int tln_gather_gemm_ex(int64_t M, int N, const tln_gemm_src* s0, cons
     const int64_t tiles = tln_cdiv(M, 32) * tln_cdiv(N, 32);
     int G = g_force_groups ? g_force_groups : 1;
     if (!g_force_groups) {
-      // as many waves per tile as keep ALL blocks resident at once: 256 CUs x floor(12 / G) blocks (3 waves per SIMD
-      // at this kernel's VGPR count), and at least 3 chunks per wave
-      for (int cand = 2; cand <= 8; ++cand)
-        if (nchunks >= 3 * cand && tiles <= (int64_t)256 * (12 / cand)) G = cand;
+      // waves per tile: the fewest chunks per wave (down to 2: both in flight before the first MFMA) that still keeps
+      // ALL blocks resident at once: 256 CUs x floor(12 / G) blocks (3 waves per SIMD at this kernel's VGPR count)
+      int best_iters = nchunks;
+      for (int cand = 2; cand <= 12; ++cand) {
+        const int it = (nchunks + cand - 1) / cand;
+        if (it < 2 || tiles > (int64_t)256 * (12 / cand)) continue;
+        if (it < best_iters) {
+          best_iters = it;
+          G = cand;
+        }
+      }
     }
     rc = w_is_nk ? launch_direct<true>(g, nchunks, G, s) : launch_direct<false>(g, nchunks, G, s);
     if (rc) return rc;
