@@ -114,7 +114,7 @@ static int ensure_rows(tln_lattice* l, int64_t rows) {
   // radix-sort scratch: ping-pong keys + values and the [256][blocks] digit histogram
   // + the 256 digit bases and the arrival counter of the fused table scan (counter starts, and is left, at zero)
   const size_t hist_ints = (size_t)256 * (cap / 4096 + 2);
-  const size_t bytes = (size_t)cap * 2 * sizeof(int32_t) + (hist_ints + 256 + 16) * sizeof(int32_t);
+  const size_t bytes = (size_t)cap * 2 * sizeof(int32_t) + (hist_ints + 256 + 16 + 3 * 256) * sizeof(int32_t);
   TLN_HIP(hipMalloc(&l->sort_temp, bytes));
   TLN_HIP(hipMemset(l->sort_temp, 0, bytes));
   TLN_HIP(hipDeviceSynchronize());
@@ -451,10 +451,18 @@ __global__ void __launch_bounds__(256) k_distribute_insert(const float* __restri
 }
 
 // coarse embedding of the fine vertices [first, first+count)
+// With fine_ctr != NULL `count` is only an upper bound known to the host; the true number of fine vertices is read
+// from the fine level's device counters and the rows beyond it are marked empty.
 __global__ void __launch_bounds__(256) k_coarsen_insert(const int32_t* __restrict__ fine_keys, int64_t first,
-                                                        int64_t count, TableRef t, int32_t* __restrict__ row_slot) {
+                                                        int64_t count, TableRef t, int32_t* __restrict__ row_slot,
+                                                        const int32_t* __restrict__ fine_ctr) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
+  if (fine_ctr != nullptr && first + i >= (int64_t)fine_ctr[CTR_NV]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) row_slot[4 * i + r] = -1;
+    return;
+  }
   const int32_t* fk = fine_keys + 4 * (first + i);
   int rem0[4], rank[4], bn[4];
   coarse_simplex(fk[0], fk[1], fk[2], rem0, rank, bn);
@@ -578,8 +586,11 @@ __global__ void __launch_bounds__(TLN_SCAN_BLOCK) k_assign_new(TableRef t, const
 // phase C: per-row vertex index (+ sort input for the CSR)
 __global__ void __launch_bounds__(256) k_row_indices(TableRef t, const int32_t* __restrict__ row_slot, int64_t rows,
                                                      int32_t* __restrict__ indices, int32_t* __restrict__ ctr,
-                                                     int32_t* __restrict__ sk_in, int32_t* __restrict__ sv_in) {
+                                                     int32_t* __restrict__ sk_in, int32_t* __restrict__ sv_in,
+                                                     int32_t* __restrict__ sort_totals) {
   const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (sort_totals)                                        // digit totals of the radix passes that follow
+    for (int64_t i = id; i < 3 * 256; i += (int64_t)gridDim.x * blockDim.x) sort_totals[i] = 0;
   if (id >= rows) return;
   const int slot = row_slot[id];
   int idx = -1;
@@ -712,8 +723,8 @@ __device__ __forceinline__ void radix_scan_table(int32_t* __restrict__ hist, int
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int32_t* row = hist + (int64_t)(wid * 16 + r) * nblk;
-      v0[r] = (lane < nblk) ? __builtin_nontemporal_load(row + lane) : 0;
-      v1[r] = (lane + 64 < nblk) ? __builtin_nontemporal_load(row + lane + 64) : 0;
+      v0[r] = (lane < nblk) ? __hip_atomic_load(row + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+      v1[r] = (lane + 64 < nblk) ? __hip_atomic_load(row + lane + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -740,7 +751,7 @@ __device__ __forceinline__ void radix_scan_table(int32_t* __restrict__ hist, int
       int carry = 0;
       for (int b0 = 0; b0 < nblk; b0 += 64) {
         const int b = b0 + lane;
-        const int v = (b < nblk) ? __builtin_nontemporal_load(row + b) : 0;
+        const int v = (b < nblk) ? __hip_atomic_load(row + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
         int incl = v;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -792,17 +803,42 @@ __global__ void __launch_bounds__(RADIX_TPB) k_radix_hist(const int32_t* __restr
                        __HIP_MEMORY_SCOPE_AGENT);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave's counts are in L2 before thread 0 announces
   __syncthreads();
+  // the counts above are agent-scope atomic stores (written through to the point of coherence) and the scan reads
+  // them with agent-scope atomic loads, so the hand-off needs no cache-wide release / acquire (each costs several
+  // microseconds on the 8-XCD part): completed stores -> barrier -> relaxed arrival count is enough
   if (threadIdx.x == 0) {
-    const unsigned prev = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned prev = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     is_last = (prev == (unsigned)nblk - 1u);
   }
   __syncthreads();
   if (!is_last) return;
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   radix_scan_table(hist, nblk, dbase, cnt);
   if (threadIdx.x == 0) __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// few blocks (<= 256, i.e. up to a million rows): NO table scan at all.  The histogram kernel writes its counts
+// block-major and adds them to 256 global digit totals (integer atomics: order-independent); every scatter block
+// then derives its own bases: digit prefix from the totals + the counts of the blocks before it.
+__global__ void __launch_bounds__(RADIX_TPB) k_radix_hist_t(const int32_t* __restrict__ keys, int64_t n, int shift,
+                                                            int32_t* __restrict__ hist_t, int32_t* __restrict__ total) {
+  __shared__ int cnt[256];
+  if (threadIdx.x < 256) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * RADIX_KPB;
+#pragma unroll
+  for (int it = 0; it < RADIX_KPB / RADIX_TPB; ++it) {
+    const int64_t i = base + it * RADIX_TPB + threadIdx.x;
+    if (i < n) atomicAdd(&cnt[(keys[i] >> shift) & 255], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x < 256) {
+    const int c = cnt[threadIdx.x];
+    hist_t[blockIdx.x * 256 + threadIdx.x] = c;
+    if (c) atomicAdd(&total[threadIdx.x], c);
+  }
+}
+
+template <bool BLOCK_MAJOR>
 __global__ void __launch_bounds__(RADIX_TPB) k_radix_scatter(const int32_t* __restrict__ keys_in,
                                                              const int32_t* __restrict__ vals_in, int64_t n, int shift,
                                                              int nblk, const int32_t* __restrict__ hist,
@@ -812,7 +848,38 @@ __global__ void __launch_bounds__(RADIX_TPB) k_radix_scatter(const int32_t* __re
   __shared__ int base[256];            // running output position per digit for this block
   __shared__ int wcount[16][256];      // per-wave digit counts, then per-wave bases
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  if (threadIdx.x < 256) base[threadIdx.x] = hist[threadIdx.x * nblk + blockIdx.x] + dbase[threadIdx.x];
+  if (!BLOCK_MAJOR) {
+    if (threadIdx.x < 256) base[threadIdx.x] = hist[threadIdx.x * nblk + blockIdx.x] + dbase[threadIdx.x];
+  } else {
+    // hist = [block][256] counts, dbase = the 256 digit totals.  Thread (q, d) sums the blocks b' = q, q+4, ... before
+    // this one; the four quarters and the exclusive digit prefix are combined through LDS (wcount is free here).
+    int* part = &wcount[0][0];         // [4][256] quarter sums, then [256] digit totals at +1024
+    const int d = threadIdx.x & 255, q = threadIdx.x >> 8;
+    int run = 0;
+    for (int b = q; b < (int)blockIdx.x; b += 4) run += hist[b * 256 + d];
+    part[q * 256 + d] = run;
+    if (threadIdx.x < 256) part[1024 + d] = dbase[d];
+    __syncthreads();
+    // exclusive prefix of the digit totals: threads 0..255 = 4 waves of 64 digits
+    int t = 0, incl = 0;
+    if (threadIdx.x < 256) {
+      t = part[1024 + d];
+      incl = t;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int u = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += u;
+      }
+      if (lane == 63) part[1280 + wid] = incl;
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) {
+      int woff = 0;
+      for (int w = 0; w < wid; ++w) woff += part[1280 + w];
+      base[d] = woff + incl - t + (part[d] + part[256 + d]) + (part[512 + d] + part[768 + d]);
+    }
+    __syncthreads();                   // wcount is reused below
+  }
   const int64_t blk0 = (int64_t)blockIdx.x * RADIX_KPB;
   for (int it = 0; it < RADIX_KPB / RADIX_TPB; ++it) {
     for (int k = threadIdx.x; k < 16 * 256; k += RADIX_TPB) (&wcount[0][0])[k] = 0;
@@ -852,6 +919,10 @@ __global__ void __launch_bounds__(RADIX_TPB) k_radix_scatter(const int32_t* __re
   }
 }
 
+// scratch behind the ping-pong buffers: hist | dbase[256] | arrive[16] | totals[3][256]
+static int32_t* sort_hist(tln_lattice* l) { return reinterpret_cast<int32_t*>(l->sort_temp) + 2 * l->rows_cap; }
+static int32_t* sort_totals(tln_lattice* l) { return sort_hist(l) + (size_t)256 * (l->rows_cap / 4096 + 2) + 256 + 16; }
+
 static int radix_sort_pairs(tln_lattice* l, int64_t rows, int bits, hipStream_t s) {
   const int nblk = (int)tln_cdiv(rows, RADIX_KPB);
   int32_t* tmp_k = reinterpret_cast<int32_t*>(l->sort_temp);
@@ -859,6 +930,7 @@ static int radix_sort_pairs(tln_lattice* l, int64_t rows, int bits, hipStream_t 
   int32_t* hist = tmp_v + l->rows_cap;
   int32_t* dbase = hist + (size_t)256 * (l->rows_cap / 4096 + 2);
   unsigned* arrive = reinterpret_cast<unsigned*>(dbase + 256);
+  int32_t* totals = sort_totals(l);
   const int passes = (bits + 7) / 8;
   // ping-pong so that the LAST pass lands in sk_out / sv_out
   const int32_t* src_k = l->sk_in;
@@ -867,9 +939,17 @@ static int radix_sort_pairs(tln_lattice* l, int64_t rows, int bits, hipStream_t 
     const bool to_out = ((passes - 1 - p) % 2) == 0;
     int32_t* dst_k = to_out ? l->sk_out : tmp_k;
     int32_t* dst_v = to_out ? l->sv_out : tmp_v;
-    hipLaunchKernelGGL(k_radix_hist, dim3(nblk), dim3(RADIX_TPB), 0, s, src_k, rows, 8 * p, nblk, hist, dbase, arrive);
-    hipLaunchKernelGGL(k_radix_scatter, dim3(nblk), dim3(RADIX_TPB), 0, s, src_k, src_v, rows, 8 * p, nblk, hist, dbase,
-                       dst_k, dst_v);
+    if (nblk <= 256 && passes <= 3) {
+      // totals[p] were zeroed by the kernel that produced the sort input (k_row_indices / k_csr_input)
+      int32_t* total = totals + 256 * p;
+      hipLaunchKernelGGL(k_radix_hist_t, dim3(nblk), dim3(RADIX_TPB), 0, s, src_k, rows, 8 * p, hist, total);
+      hipLaunchKernelGGL(k_radix_scatter<true>, dim3(nblk), dim3(RADIX_TPB), 0, s, src_k, src_v, rows, 8 * p, nblk, hist,
+                         total, dst_k, dst_v);
+    } else {
+      hipLaunchKernelGGL(k_radix_hist, dim3(nblk), dim3(RADIX_TPB), 0, s, src_k, rows, 8 * p, nblk, hist, dbase, arrive);
+      hipLaunchKernelGGL(k_radix_scatter<false>, dim3(nblk), dim3(RADIX_TPB), 0, s, src_k, src_v, rows, 8 * p, nblk, hist,
+                         dbase, dst_k, dst_v);
+    }
     src_k = dst_k;
     src_v = dst_v;
   }
@@ -890,8 +970,10 @@ static int build_csr_sorted(tln_lattice* l, int64_t rows, hipStream_t s) {
 }
 
 __global__ void __launch_bounds__(256) k_csr_input(const int32_t* __restrict__ indices, int64_t rows, int32_t nv,
-                                                   int32_t* __restrict__ sk_in, int32_t* __restrict__ sv_in) {
+                                                   int32_t* __restrict__ sk_in, int32_t* __restrict__ sv_in,
+                                                   int32_t* __restrict__ sort_totals) {
   const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (int64_t i = id; i < 3 * 256; i += (int64_t)gridDim.x * blockDim.x) sort_totals[i] = 0;  // radix digit totals
   if (id >= rows) return;
   const int idx = indices[id];
   sk_in[id] = (idx < 0 || idx >= nv) ? nv : idx;
@@ -904,7 +986,7 @@ extern "C" int tln_build_csr(tln_lattice_t* l, const int32_t* d_indices, int64_t
   int rc = ensure_rows(l, rows);
   if (rc) return rc;
   hipLaunchKernelGGL(k_csr_input, dim3((unsigned)tln_cdiv(rows, 256)), dim3(256), 0, s, d_indices, rows,
-                     (int32_t)l->nr_vertices, l->sk_in, l->sv_in);
+                     (int32_t)l->nr_vertices, l->sk_in, l->sv_in, sort_totals(l));
   TLN_LAUNCH_CHECK();
   return build_csr_sorted(l, rows, s);
 }
@@ -1052,7 +1134,7 @@ extern "C" int tln_distribute(tln_lattice_t* l, const float* d_positions, const 
   rc = number_new(l, rows, s);
   if (rc) return rc;
   hipLaunchKernelGGL(k_row_indices, dim3((unsigned)tln_cdiv(rows, 256)), dim3(256), 0, s, t, l->row_slot, rows,
-                     d_indices, l->d_ctr, l->sk_in, l->sv_in);
+                     d_indices, l->d_ctr, l->sk_in, l->sv_in, sort_totals(l));
   TLN_LAUNCH_CHECK();
   rc = fetch_counters(l, s);
   if (rc) return rc;
@@ -1086,7 +1168,7 @@ extern "C" int tln_lattice_insert_keys(tln_lattice_t* l, const int32_t* d_keys, 
   rc = number_new(l, n, s);
   if (rc) return rc;
   hipLaunchKernelGGL(k_row_indices, dim3((unsigned)tln_cdiv(n, 256)), dim3(256), 0, s, t, l->row_slot, n,
-                     d_indices_out, l->d_ctr, (int32_t*)nullptr, (int32_t*)nullptr);
+                     d_indices_out, l->d_ctr, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr);
   TLN_LAUNCH_CHECK();
   l->csr_rows = -1;
   return fetch_counters(l, s);
@@ -1224,7 +1306,7 @@ extern "C" int tln_coarsen(tln_lattice_t* fine, tln_lattice_t** coarse_out, void
     rc = ensure_slots(c, rows, s);
     if (rc) return rc;
     hipLaunchKernelGGL(k_coarsen_insert, dim3((unsigned)tln_cdiv(count, 256)), dim3(256), 0, s, fine->vkeys, first,
-                       count, table_ref(c), c->row_slot);
+                       count, table_ref(c), c->row_slot, (const int32_t*)nullptr);
     TLN_LAUNCH_CHECK();
     rc = number_new(c, rows, s);
     if (rc) return rc;
@@ -1234,6 +1316,38 @@ extern "C" int tln_coarsen(tln_lattice_t* fine, tln_lattice_t** coarse_out, void
     c->csr_rows = -1;
   }
   *coarse_out = c;
+  return TLN_OK;
+}
+
+// tln_coarsen without the host round trip: `fine_bound` >= the fine level's current vertex count (exact for level 0,
+// previous count + 4 x the finer level's growth otherwise); the kernels read the true count from the fine level's
+// device counters.  The caller fetches the new counts of all levels at once afterwards.
+static int coarsen_deferred(tln_lattice* fine, int64_t fine_bound, hipStream_t s) {
+  if (!fine->coarse) {
+    double sg[3] = {fine->sigmas[0] * 2, fine->sigmas[1] * 2, fine->sigmas[2] * 2};
+    tln_lattice* c = nullptr;
+    int rc = lattice_alloc(&c, fine->pos_dim, sg, fine->capacity, fine->level + 1);
+    if (rc) return rc;
+    c->parent = fine;
+    fine->coarse = c;
+    rc = tln_lattice_clear(c, s);
+    if (rc) return rc;
+  }
+  tln_lattice* c = fine->coarse;
+  if (fine_bound > fine->capacity) fine_bound = fine->capacity;
+  const int64_t first = c->embedded_fine, bound = fine_bound - first;
+  if (bound <= 0) return TLN_OK;
+  const int64_t rows = 4 * bound;
+  int rc = ensure_rows(c, rows);
+  if (rc) return rc;
+  rc = ensure_slots(c, rows, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_coarsen_insert, dim3((unsigned)tln_cdiv(bound, 256)), dim3(256), 0, s, fine->vkeys, first, bound,
+                     table_ref(c), c->row_slot, (const int32_t*)fine->d_ctr);
+  TLN_LAUNCH_CHECK();
+  rc = number_new(c, rows, s);
+  if (rc) return rc;
+  c->csr_rows = -1;
   return TLN_OK;
 }
 
@@ -1277,12 +1391,33 @@ extern "C" int tln_fine_to_coarse_table(tln_lattice_t* c, const int32_t** d_tabl
 extern "C" int tln_lattice_prepare_levels(tln_lattice_t* l0, int nr_coarse_levels, void* stream_) {
   TLN_REQUIRE(l0 && nr_coarse_levels >= 0 && nr_coarse_levels <= 3, "bad prepare_levels arguments");
   hipStream_t s = (hipStream_t)stream_;
-  tln_lattice* lv = l0;
-  for (int i = 0; i < nr_coarse_levels; ++i) {
-    tln_lattice* c = nullptr;
-    int rc = tln_coarsen(lv, &c, stream_);
-    if (rc) return rc;
-    lv = c;
+  // every coarse level extended without a host round trip in between, then ONE fetch of all their counters
+  {
+    tln_lattice* lv = l0;
+    int64_t bound = l0->nr_vertices;                       // exact
+    int64_t growth = l0->nr_vertices - (l0->coarse ? l0->coarse->embedded_fine : 0);
+    for (int i = 0; i < nr_coarse_levels; ++i) {
+      int rc = coarsen_deferred(lv, bound, s);
+      if (rc) return rc;
+      tln_lattice* c = lv->coarse;
+      if (growth < 0) growth = 0;
+      growth *= 4;                                         // a fine vertex touches at most 4 coarse vertices
+      bound = c->nr_vertices + growth;                     // >= the coarse level's new count
+      lv = c;
+    }
+    for (tln_lattice* c = l0->coarse; c; c = c->coarse)
+      TLN_HIP(hipMemcpyAsync(c->h_ctr, c->d_ctr, CTR_COUNT * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    TLN_HIP(hipStreamSynchronize(s));
+    int lvl = 0;
+    for (tln_lattice* c = l0->coarse; c && lvl < nr_coarse_levels; c = c->coarse, ++lvl) {
+      c->nr_vertices = c->h_ctr[CTR_NV];
+      c->occupied = c->h_ctr[CTR_OCCUPIED];
+      c->embedded_fine = c->parent->nr_vertices;
+      if (c->h_ctr[CTR_PROBE_FAIL] != 0) {
+        tln_set_error("hash probing failed for %d rows at level %d (table too full)", c->h_ctr[CTR_PROBE_FAIL], c->level);
+        return TLN_E_CAPACITY;
+      }
+    }
   }
   TableJobs jobs{};
   int blocks = 0;
