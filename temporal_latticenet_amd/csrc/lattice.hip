@@ -1120,7 +1120,7 @@ extern "C" int tln_distribute(tln_lattice_t* l, const float* d_positions, const 
                               float* d_weights, void* stream_) {
   TLN_REQUIRE(l && d_positions && d_distributed && d_indices && d_weights, "null argument");
   TLN_REQUIRE(n > 0 && 4 * n < (1ll << 31), "nr of points %lld out of range", (long long)n);
-  TLN_REQUIRE(val_dim >= 0 && val_dim <= 16 && (val_dim == 0 || d_values), "bad val_dim %d", val_dim);
+  TLN_REQUIRE(val_dim >= 0 && val_dim <= 1024 && (val_dim == 0 || d_values), "bad val_dim %d", val_dim);
   hipStream_t s = (hipStream_t)stream_;
   const int64_t rows = 4 * n;
   int rc = ensure_rows(l, rows);
