@@ -265,7 +265,7 @@ enum {
                              f[1] beta, i[0] use_center, bias                                            */
   TLN_OP_SLICE_GATHER,    /* out [N, 4*(cols+1)] from s0.slot and the frame's indices / weights          */
   TLN_OP_SLICE,           /* out [N, cols] = blend of s0.slot rows, s1.slot = delta weights (or -1), bias */
-  TLN_OP_COPY,            /* out[:, out_col:out_col+cols(s0)] = s0.slot                                  */
+  TLN_OP_COPY,            /* out[:, out_col:out_col+cols(s0)] = s0.slot; i[0] != 0: row 0 of the copy zeroed   */
   TLN_OP_ZERO_ROW0,       /* out[0, :] = 0 (lm:569-570)                                                  */
   TLN_OP_STOP_IF_EARLY    /* early_return frames end here; s0.slot is what the frame returns            */
 };

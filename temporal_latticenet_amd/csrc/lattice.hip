@@ -150,13 +150,49 @@ static int lattice_alloc(tln_lattice** out, int pos_dim, const double* sigmas, i
   return TLN_OK;
 }
 
+// every level of a lattice emptied by ONE launch (slot tables to 0xFF.., counters to 0) instead of four memsets each
+struct ClearJobs {
+  struct {
+    uint64_t* key;
+    int32_t* val;
+    uint32_t* touch;
+    int32_t* ctr;
+    int64_t nslots;
+  } j[4];
+  int n;
+};
+__global__ void __launch_bounds__(256) k_clear_levels(ClearJobs jobs) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (int k = 0; k < jobs.n; ++k) {
+    // 16 bytes of keys + 8 of values + 8 of touches per step and thread
+    ulonglong2* key2 = reinterpret_cast<ulonglong2*>(jobs.j[k].key);
+    int2* val2 = reinterpret_cast<int2*>(jobs.j[k].val);
+    uint2* touch2 = reinterpret_cast<uint2*>(jobs.j[k].touch);
+    const int64_t pairs = jobs.j[k].nslots >> 1;  // slot counts are powers of two
+    for (int64_t i = id; i < pairs; i += stride) {
+      key2[i] = make_ulonglong2(~0ull, ~0ull);
+      val2[i] = make_int2(-1, -1);
+      touch2[i] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+    }
+    if (id < CTR_COUNT) jobs.j[k].ctr[id] = 0;
+  }
+}
+
 extern "C" int tln_lattice_clear(tln_lattice_t* l, void* stream_) {
   hipStream_t s = (hipStream_t)stream_;
+  ClearJobs jobs{};
   for (tln_lattice* p = l; p; p = p->coarse) {
-    TLN_HIP(hipMemsetAsync(p->slot_key, 0xFF, p->nslots * sizeof(uint64_t), s));
-    TLN_HIP(hipMemsetAsync(p->slot_val, 0xFF, p->nslots * sizeof(int32_t), s));
-    TLN_HIP(hipMemsetAsync(p->slot_touch, 0xFF, p->nslots * sizeof(uint32_t), s));
-    TLN_HIP(hipMemsetAsync(p->d_ctr, 0, CTR_COUNT * sizeof(int32_t), s));
+    if (jobs.n == 4) {  // deeper chains than the kernel takes at once
+      hipLaunchKernelGGL(k_clear_levels, dim3(2048), dim3(256), 0, s, jobs);
+      jobs.n = 0;
+    }
+    jobs.j[jobs.n].key = p->slot_key;
+    jobs.j[jobs.n].val = p->slot_val;
+    jobs.j[jobs.n].touch = p->slot_touch;
+    jobs.j[jobs.n].ctr = p->d_ctr;
+    jobs.j[jobs.n].nslots = p->nslots;
+    ++jobs.n;
     p->nr_vertices = 0;
     p->overflow_rows = 0;
     p->occupied = 0;
@@ -165,6 +201,8 @@ extern "C" int tln_lattice_clear(tln_lattice_t* l, void* stream_) {
     p->embedded_fine = 0;
     p->csr_rows = -1;
   }
+  if (jobs.n) hipLaunchKernelGGL(k_clear_levels, dim3(2048), dim3(256), 0, s, jobs);
+  TLN_LAUNCH_CHECK();
   return TLN_OK;
 }
 

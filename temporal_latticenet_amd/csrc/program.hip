@@ -14,6 +14,19 @@
 
 #include "common.h"
 
+// strided row copy (concat halves, the PointNet clone); zero_row0 folds the lm:569-570 row-0 reset into the clone
+__global__ void __launch_bounds__(256) k_copy_rows(const float* __restrict__ src, int64_t ld_src, float* __restrict__ dst,
+                                                   int64_t ld_dst, int64_t rows, int cols, int zero_row0) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c4 = cols >> 2;  // cols % 4 == 0 and 16-byte aligned rows (checked by the caller)
+  const int64_t r = gid / c4;
+  if (r >= rows) return;
+  const int c = (int)(gid - r * c4) * 4;
+  float4 v = *reinterpret_cast<const float4*>(src + r * ld_src + c);
+  if (zero_row0 && r == 0) v = make_float4(0.f, 0.f, 0.f, 0.f);
+  *reinterpret_cast<float4*>(dst + r * ld_dst + c) = v;
+}
+
 namespace {
 
 constexpr size_t kAlign = 256;
@@ -378,10 +391,22 @@ int walk(tln_program* p, bool dry, int early, float* d_out, int64_t out_rows, in
         const tln_slot& so = p->slots[o.out];
         const int64_t rows = p->rt[o.s0.slot].rows;
         TLN_REQUIRE(rows == p->rt[o.out].rows && o.out_col + ss.cols <= so.cols, "op %d: copy shapes", oi);
-        if (rows > 0)
-          TLN_HIP(hipMemcpy2DAsync(fptr(o.out) + o.out_col, (size_t)so.cols * sizeof(float), fptr(o.s0.slot),
-                                   (size_t)ss.cols * sizeof(float), (size_t)ss.cols * sizeof(float), (size_t)rows,
-                                   hipMemcpyDeviceToDevice, s));
+        if (rows > 0) {
+          const float* sp = fptr(o.s0.slot);
+          float* dp = fptr(o.out) + o.out_col;
+          const bool vec = ss.cols % 4 == 0 && so.cols % 4 == 0 && o.out_col % 4 == 0 &&
+                           (reinterpret_cast<uintptr_t>(sp) & 15) == 0 && (reinterpret_cast<uintptr_t>(dp) & 15) == 0;
+          if (vec) {
+            const int64_t total = rows * (ss.cols / 4);
+            hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)tln_cdiv(total, 256)), dim3(256), 0, s, sp, (int64_t)ss.cols, dp,
+                               (int64_t)so.cols, rows, ss.cols, o.i[0]);
+            TLN_LAUNCH_CHECK();
+          } else {
+            TLN_HIP(hipMemcpy2DAsync(dp, (size_t)so.cols * sizeof(float), sp, (size_t)ss.cols * sizeof(float),
+                                     (size_t)ss.cols * sizeof(float), (size_t)rows, hipMemcpyDeviceToDevice, s));
+            if (o.i[0]) TLN_HIP(hipMemsetAsync(dp, 0, (size_t)ss.cols * sizeof(float), s));
+          }
+        }
         break;
       }
       case TLN_OP_ZERO_ROW0: {

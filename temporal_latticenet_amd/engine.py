@@ -206,9 +206,10 @@ def _walk_model(model):
     x = b.fusion(fm, pooled, 0)
     if fm is not None:                                   # the stored state keeps its row 0 (lm:569-570 on a copy)
         q = Val(b.slot(0, x.cols), 0, x.cols)
-        b.op(OP_COPY, out=q.slot, s0=b.src(x))
+        b.op(OP_COPY, out=q.slot, s0=b.src(x), i=[1] + [0] * 7)      # clone with row 0 zeroed, one launch
         x = q
-    b.op(OP_ZERO_ROW0, out=x.slot)
+    else:
+        b.op(OP_ZERO_ROW0, out=x.slot)
     lv = b.tap_product(_need(getattr(pn, "last_conv", None), "last_conv"), x, 0, TABLE_NBR, 0)      # lm:573
 
     stopped = False
