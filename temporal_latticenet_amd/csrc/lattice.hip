@@ -459,33 +459,63 @@ static int ensure_slots(tln_lattice* l, int64_t rows, hipStream_t s) {
 // ---------------------------------------------------------------------------------------
 // phase A kernels: compute keys, claim slots
 // ---------------------------------------------------------------------------------------
+// one thread per ROW (point p = id>>2, simplex vertex r = id&3): the four lanes of a point repeat the cheap simplex
+// arithmetic, but every hash probe is its own thread — four times the waves to hide the dependent table reads behind
+// (one thread per point: 42 us per 120k-point frame; per row: see DESIGN 6)
 __global__ void __launch_bounds__(256) k_distribute_insert(const float* __restrict__ pos, const float* __restrict__ val,
                                                            int64_t n, int val_dim, float s0, float s1, float s2,
                                                            TableRef t, int32_t* __restrict__ row_slot,
                                                            float* __restrict__ weights, float* __restrict__ dist) {
-  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n) return;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live_row = (gid >> 2) < n;
+  const int64_t p = live_row ? (gid >> 2) : n - 1;   // lanes past the end shadow the last point and store nothing
+  const int r = (int)(gid & 3);
   const float x = pos[3 * p], y = pos[3 * p + 1], z = pos[3 * p + 2];
   int rem0[4], rank[4];
   float bary[4];
   point_simplex(x, y, z, s0, s1, s2, rem0, rank, bary);
+  const float b = r == 0 ? bary[0] : (r == 1 ? bary[1] : (r == 2 ? bary[2] : bary[3]));
   const int cols = 3 + val_dim + 1;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    int k0, k1, k2;
-    vertex_key(rem0, rank, r, k0, k1, k2);
-    const uint32_t id = (uint32_t)(4 * p + r);
+  int k0, k1, k2;
+  vertex_key(rem0, rank, r, k0, k1, k2);
+  const uint32_t id = (uint32_t)gid;
+  if (live_row) {
     int slot = -1;
     if (tln_key_in_range(k0, k1, k2)) slot = probe_insert(t, tln_pack_key(k0, k1, k2), id);
     row_slot[id] = slot;
-    weights[id] = bary[r];
-    float* row = dist + (int64_t)id * cols;
-    row[0] = x;
-    row[1] = y;
-    row[2] = z;
-    for (int c = 0; c < val_dim; ++c) row[3 + c] = val[p * val_dim + c];
-    row[3 + val_dim] = bary[r];
+    weights[id] = b;
   }
+  if (val_dim == 1) {
+    // the 64 rows of a wave are 64 x 20 contiguous bytes: staged through LDS and written as five fully coalesced
+    // 256-byte stores instead of five 20-byte-strided ones
+    __shared__ float stage[4][64 * 5];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    float* st = stage[wid];
+    st[lane * 5] = x;
+    st[lane * 5 + 1] = y;
+    st[lane * 5 + 2] = z;
+    st[lane * 5 + 3] = val[p];
+    st[lane * 5 + 4] = b;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int64_t wave_row0 = gid - lane;                      // first row of this wave
+    const int64_t live = 4 * n - wave_row0 < 64 ? 4 * n - wave_row0 : 64;   // <= 0 for a wave wholly past the end
+    float* base = dist + wave_row0 * 5;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int e = k * 64 + lane;
+      if (e < live * 5) base[e] = st[e];
+    }
+    return;
+  }
+  if (!live_row) return;
+  float* row = dist + (int64_t)id * cols;
+  row[0] = x;
+  row[1] = y;
+  row[2] = z;
+  for (int c = 0; c < val_dim; ++c) row[3 + c] = val[p * val_dim + c];
+  row[3 + val_dim] = b;
 }
 
 // coarse embedding of the fine vertices [first, first+count)
@@ -1166,7 +1196,7 @@ extern "C" int tln_distribute(tln_lattice_t* l, const float* d_positions, const 
   rc = ensure_slots(l, rows, s);
   if (rc) return rc;
   TableRef t = table_ref(l);
-  hipLaunchKernelGGL(k_distribute_insert, dim3((unsigned)tln_cdiv(n, 256)), dim3(256), 0, s, d_positions, d_values, n,
+  hipLaunchKernelGGL(k_distribute_insert, dim3((unsigned)tln_cdiv(4 * n, 256)), dim3(256), 0, s, d_positions, d_values, n,
                      val_dim, l->scale[0], l->scale[1], l->scale[2], t, l->row_slot, d_weights, d_distributed);
   TLN_LAUNCH_CHECK();
   rc = number_new(l, rows, s);
