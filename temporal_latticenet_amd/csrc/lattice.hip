@@ -93,6 +93,8 @@ static int bits_for(int64_t v) {
   return b;
 }
 
+#define RADIX_KPB 4096   // radix sort: keys per block (csr build below)
+
 static int ensure_rows(tln_lattice* l, int64_t rows) {
   if (rows <= l->rows_cap) return TLN_OK;
   int64_t cap = 1;
@@ -113,7 +115,7 @@ static int ensure_rows(tln_lattice* l, int64_t rows) {
   TLN_HIP(hipMalloc(&l->pieces, (cap / 256 + 2) * 6 * sizeof(double)));
   // radix-sort scratch: ping-pong keys + values and the [256][blocks] digit histogram
   // + the 256 digit bases and the arrival counter of the fused table scan (counter starts, and is left, at zero)
-  const size_t hist_ints = (size_t)256 * (cap / 4096 + 2);
+  const size_t hist_ints = (size_t)256 * (cap / RADIX_KPB + 2);
   const size_t bytes = (size_t)cap * 2 * sizeof(int32_t) + (hist_ints + 256 + 16 + 3 * 256) * sizeof(int32_t);
   TLN_HIP(hipMalloc(&l->sort_temp, bytes));
   TLN_HIP(hipMemset(l->sort_temp, 0, bytes));
@@ -776,7 +778,6 @@ __global__ void __launch_bounds__(256) k_seg_start(const int32_t* __restrict__ s
 //                   blocks ordered through the scanned table => stable
 // The keys are vertex indices (< V+1), so a 120k-point frame on a few thousand vertices needs two passes.
 // ---------------------------------------------------------------------------------------
-#define RADIX_KPB 4096   // keys per block
 #define RADIX_TPB 1024   // threads per block (16 waves)
 
 // Exclusive scan of the digit-major table hist[256][nblk] by one 1024-thread block: wave w owns digit rows
@@ -989,14 +990,14 @@ __global__ void __launch_bounds__(RADIX_TPB) k_radix_scatter(const int32_t* __re
 
 // scratch behind the ping-pong buffers: hist | dbase[256] | arrive[16] | totals[3][256]
 static int32_t* sort_hist(tln_lattice* l) { return reinterpret_cast<int32_t*>(l->sort_temp) + 2 * l->rows_cap; }
-static int32_t* sort_totals(tln_lattice* l) { return sort_hist(l) + (size_t)256 * (l->rows_cap / 4096 + 2) + 256 + 16; }
+static int32_t* sort_totals(tln_lattice* l) { return sort_hist(l) + (size_t)256 * (l->rows_cap / RADIX_KPB + 2) + 256 + 16; }
 
 static int radix_sort_pairs(tln_lattice* l, int64_t rows, int bits, hipStream_t s) {
   const int nblk = (int)tln_cdiv(rows, RADIX_KPB);
   int32_t* tmp_k = reinterpret_cast<int32_t*>(l->sort_temp);
   int32_t* tmp_v = tmp_k + l->rows_cap;
   int32_t* hist = tmp_v + l->rows_cap;
-  int32_t* dbase = hist + (size_t)256 * (l->rows_cap / 4096 + 2);
+  int32_t* dbase = hist + (size_t)256 * (l->rows_cap / RADIX_KPB + 2);
   unsigned* arrive = reinterpret_cast<unsigned*>(dbase + 256);
   int32_t* totals = sort_totals(l);
   const int passes = (bits + 7) / 8;
