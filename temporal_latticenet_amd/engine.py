@@ -392,16 +392,26 @@ class FrameProgram:
         return t
 
 
-def params_key(model):
+def params_key(model, refresh=False):
     """identity + in-place version of every parameter: a program is rebuilt when any of them was re-allocated or
-    written (optimizer step, load_state_dict) since it was compiled — AFlow's alpha / beta are baked in by value"""
-    return tuple((p.data_ptr(), p._version) for p in model.parameters())
+    written (optimizer step, load_state_dict, .to()) since it was compiled — AFlow's alpha / beta are baked in by
+    value.  The list of Parameter objects is walked once per compile (a module-tree walk per sequence costs more host
+    time than the sequence's native calls); assigning a NEW Parameter object to a module attribute afterwards needs
+    `model._program = None`."""
+    plist = None if refresh else getattr(model, "_program_params", None)
+    if plist is None:
+        plist = list(model.parameters())
+        object.__setattr__(model, "_program_params", plist)
+    return tuple([(p.data_ptr(), p._version) for p in plist])
 
 
 def compile_model(model):
     """FrameProgram for `model`, or None when the configuration / state needs the operator-level route"""
     try:
         b = _walk_model(model)
-    except (NotReady, Unsupported):
+    except NotReady:
+        return None
+    except Unsupported:
+        object.__setattr__(model, "_program_unsupported", True)     # the configuration will not change: stop trying
         return None
     return FrameProgram(model, b)

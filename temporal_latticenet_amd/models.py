@@ -178,12 +178,14 @@ class LNN_SEQ(torch.nn.Module):
         """decided at the first frame of a sequence; a frame that needs the operator-level route (gradients,
         visualisation hooks) takes the hidden states with it"""
         from . import engine
-        wanted = self.use_frame_program and not torch.is_grad_enabled() and not vis_aflow
+        wanted = self.use_frame_program and not torch.is_grad_enabled() and not vis_aflow and \
+            not getattr(self, "_program_unsupported", False)
         if self.first_sequence or not self.sequence_learning:
             self._program_active = False
             if wanted:
                 key = engine.params_key(self)
                 if getattr(self, "_program", None) is None or self._program_key != key:
+                    key = engine.params_key(self, refresh=True)     # lazily created parameters may have appeared
                     self._program, self._program_key = engine.compile_model(self), key
                 prog = self._program
                 if prog is not None and not (self.training and prog.uses_dropout):
