@@ -73,6 +73,28 @@ class OracleLNN:
     def _block(self, lv, table, p):
         return self._resnet(lv, table, p) if (p + ".conv1.conv.weight") in self.sd else self._bottleneck(lv, table, p)
 
+    def _attention_pool(self, dist, indices, v0):
+        """reference lm:449, 460-467, 486-510: the MLP runs on the FULL distributed rows (barycentric weight
+        included), the per-row features are softmax-weighted per vertex instead of max-pooled"""
+        sd, pfx = self.sd, "point_net_seq."
+        x = torch.as_tensor(dist)
+        nl = len(self.pointnet_layers)
+        for i in range(nl):                                                           # lm:460-467
+            x = F.linear(x, sd[pfx + "layers.%d.weight" % i], sd[pfx + "layers.%d.bias" % i])
+            if i < nl - 1:
+                x = torch.relu(x)
+        idx = torch.as_tensor(indices).long().clone()
+        idx[idx < 0] = 0                                                              # lm:480
+        max_reduced, _ = O.scatter_max(x, idx, v0)                                    # lm:488
+        x_max = x + sd[pfx + "gamma"] * max_reduced[idx]                              # lm:489-490
+        pre = F.linear(x_max, sd[pfx + "pre_conv.weight"])                            # lm:492
+        att = self._gnrelu1x1(pre, pfx + "att_activ")                                 # lm:493
+        att = torch.exp(self._gnrelu1x1(att, pfx + "att_scores"))                     # lm:494-495
+        att_sum = O.scatter_add(att, idx, v0)[idx]                                    # lm:496-497
+        reduced = O.scatter_add(x * (att / att_sum), idx, v0)                         # lm:498-501
+        nr_points = O.scatter_add(torch.ones(idx.shape[0], 1), idx, v0)               # lm:504-506
+        return reduced.masked_fill(nr_points < 4, 0)                                  # lm:507-509
+
     def _fusion(self, slot, kind, lv, table, p):
         h = self.h.get(slot)
         if kind == "gru":
@@ -148,7 +170,10 @@ class OracleLNN:
             ws = [sd["point_net_seq.layers.%d.weight" % i] for i in range(nl)]
             bs = [sd["point_net_seq.layers.%d.bias" % i] for i in range(nl)]
         early_maxpool = self.seq and self.rnn[0] == "maxpool"
-        lv = O.pointnet_pool(dist, indices, v0, ws, bs, 0 if early_maxpool else 4)
+        if self.experiment == "attention_pool":
+            lv = self._attention_pool(dist, indices, v0)
+        else:
+            lv = O.pointnet_pool(dist, indices, v0, ws, bs, 0 if early_maxpool else 4)
         if self.seq and self.rnn[0] == "maxpool":
             rowsum = lv[:, : lv.shape[1] // 2].abs().sum(1, keepdim=True)
             lv = lv.masked_fill(rowsum == 0, -9900)

@@ -145,3 +145,31 @@ def test_reference_import_names_drive_the_model(gpu, tmp_path):
     assert pred.shape == (6000, 26)
     mx, arg = ns["torch_scatter"].scatter_max(torch.rand(50, 3, device="cuda"), torch.randint(0, 7, (50,), device="cuda"), dim=0)
     assert mx.shape == (7, 3)
+
+
+@pytest.mark.parametrize("experiment,rnn", [
+    ("slice_no_deform", ("gru", "gru", "aflow", "gru")),
+    ("pointnet_no_local_mean", ("gru", "gru", "aflow", "gru")),
+    ("pointnet_no_elevate", ("none", "gru", "none", "gru")),
+    ("pointnet_no_elevate_no_local_mean", ("none", "gru", "none", "gru")),
+    ("splat", ("none", "gru", "none", "gru")),
+    ("attention_pool", ("none", "gru", "none", "gru")),
+])
+def test_experiments_match_oracle(gpu, experiment, rnn):
+    """the `experiment` switches of models.py:39 (PointNet without elevation / local mean, attention pooling
+    lm:486-510, slice without the deformation head); the second pass runs through the frame program where the
+    configuration supports it"""
+    contents = make_config(rnn_modules=rnn, frames=2, sigma=0.7, experiment=experiment)
+    seq = make_sequence(8000, 2, seed=41)
+    model = build_model(contents).eval()
+    _run(model, contents, seq, gpu)
+    randomize_parameters(model, seed=3)
+    outs = _run(model, contents, seq, gpu)
+    oracle = oracle_from_model(model, contents)
+    for t, (pos, val) in enumerate(seq):
+        want = oracle.forward(pos, val, early_return=(t != len(seq) - 1))
+        got = outs[t]
+        assert got.shape == want.shape
+        scale = max(1.0, float(want.abs().max()))
+        err = float((got - want).abs().max())
+        assert err <= LOGIT_TOL * scale, "%s frame %d: max abs err %.3e (scale %.2f)" % (experiment, t, err, scale)
