@@ -110,3 +110,21 @@ def test_program_is_rebuilt_after_a_parameter_update(gpu):
     c, _ = _run(model, contents, seq, gpu)
     assert torch.equal(b[-1][1], c[-1][1])
     assert not torch.equal(a[-1][1], b[-1][1])
+
+
+@pytest.mark.parametrize("n,sigma,capacity", [(777, 2.5, 100000), (3001, 0.4, 600), (64, 5.0, 100000)])
+def test_program_edge_cases_equal_operator_route(gpu, n, sigma, capacity):
+    """ragged sizes: a handful of vertices (fewer than one 32-row tile), a capacity that rejects most keys (rows with
+    index -1, models.py:479), a cloud of one wave"""
+    contents = make_config(rnn_modules=("gru", "gru", "aflow", "gru"), frames=3, sigma=sigma, capacity=capacity)
+    seq = make_sequence(n, 3, seed=23)
+    model = _prepared(contents, seq, gpu)
+    ref, _ = _run(model, contents, seq, gpu)
+    model.use_frame_program = True
+    got, used = _run(model, contents, seq, gpu)
+    assert all(used)
+    for t in range(3):
+        a, b = got[t][1], ref[t][1]
+        assert a.shape == b.shape
+        same = torch.equal(a, b) or bool(((a == b) | (a.isnan() & b.isnan())).all())   # AFlow's 0/0 is a NaN on both
+        assert same, "frame %d differs (max %.3e)" % (t, float((a - b).abs().nan_to_num().max()))
