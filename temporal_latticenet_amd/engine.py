@@ -7,9 +7,10 @@ tree is walked ONCE, after the lazily created parameters exist, and turned into 
 same C-ABI entry points with the same arguments in the same order as the modules do, so both routes produce
 identical tensors (tests/test_gpu_engine.py compares them bit for bit).
 
-Supported: experiment none / slice_no_deform / pointnet_no_local_mean, fusion modules none / gru / aflow in every
-slot (the BASELINE configurations).  Anything else, gradients, dropout in training mode and the AFlow
-visualisation hooks stay on the operator-level route (compile_model returns None).
+Supported: experiment none / slice_no_deform / pointnet_no_local_mean, fusion modules none / gru / aflow / linear in
+every slot (the BASELINE configurations and the simplest alternative).  Anything else (lstm, maxpool, cga, the
+no-elevation / attention-pool experiments), gradients, dropout in training mode and the AFlow visualisation hooks
+stay on the operator-level route (compile_model returns None).
 """
 import ctypes as C
 
@@ -18,7 +19,7 @@ import torch
 from . import _lib
 from .lattice import stream_ptr
 from .lattice_modules import BottleneckBlock, NO_MEAN_EXPERIMENTS, ResnetBlock
-from .seq_modules import CrossframeLocalInterpolationModule, GRUModule
+from .seq_modules import CrossframeLocalInterpolationModule, GRUModule, TemporalLinearModule
 
 ROWS_POINTS, ROWS_POINT_ROWS, ROWS_STATE = -1, -2, -16
 SLOT_F32, SLOT_STATS, SLOT_STATE_NEW, SLOT_STATE_PREV, SLOT_OUT = 0, 1, 2, 3, 4
@@ -172,6 +173,13 @@ class Builder:
                     f=[float(a.alpha), float(a.beta), -999999.0, 0.0], i=[1 if a.use_center else 0] + [0] * 7)
             self.gemm(level, x.cols, mod.linear.weight, True, self.src(Val(av, level, x.cols)), self.src(x),
                       bias=mod.linear.bias, relu=True, stats=False, cond=(sid, 1), out=new)  # lm:223-227
+        elif isinstance(mod, TemporalLinearModule):
+            if x.cols != mod.nr_output_channels:
+                raise Unsupported("TemporalLinearModule width")
+            h1 = self.gemm(ROWS_STATE - sid, x.cols, mod.hidden_linear.weight, True, self.src(prev_val),
+                           bias=mod.hidden_linear.bias, stats=False, cond=(sid, 1))        # lm:172
+            self.gemm(level, x.cols, mod.linear.weight, True, self.src(h1, pad_value=0.0), self.src(x),
+                      bias=mod.linear.bias, relu=True, stats=False, cond=(sid, 1), out=new)  # lm:174-179
         else:
             raise Unsupported(type(mod).__name__)
         return Val(new, level, x.cols)
@@ -184,7 +192,7 @@ def _walk_model(model):
     seq = model.sequence_learning
     rnn = model.rnn_modules if seq else ["none"] * 4
     for k in rnn:
-        if k not in ("none", "gru", "aflow"):
+        if k not in ("none", "gru", "aflow", "linear"):
             raise Unsupported("fusion module " + k)
     pn = model.point_net_seq
     if pn.experiment not in ("none", "slice_no_deform", "pointnet_no_local_mean"):
