@@ -199,6 +199,14 @@ int tln_slice_gather(const float* d_lv, int64_t V, int cb, const int32_t* d_indi
 int tln_slice(const float* d_lv, int64_t V, int C, const int32_t* d_indices, const float* d_weights,
               const float* d_delta, const float* d_bias, int64_t n, float* d_out, void* stream);
 
+/* the whole DeformSlice head of SliceFastCUDALatticeModule (models.py:465) per point in one kernel:
+ * g = [w_r * b[idx_r], w_r] x4 -> relu(W_pre g) -> dw = W_dw . + b_dw -> out = sum_r (w_r + dw_r) * scores[idx_r] + bias.
+ * b [V, cb] is the per-vertex bottleneck (cb = 8), scores [V, C] the per-vertex class scores,
+ * W_pre [4(cb+1), 4(cb+1)], W_dw [4, 4(cb+1)], b_dw [4] torch Linear layouts; d_bias [C] may be NULL. */
+int tln_slice_deform(const float* d_b, int cb, const float* d_scores, int64_t V, int C, const int32_t* d_indices,
+                     const float* d_weights, const float* d_w_pre, const float* d_w_dw, const float* d_b_dw,
+                     const float* d_bias, int64_t n, float* d_out, void* stream);
+
 /* ---- K11 plain splat (SplatLatticeModule) ---------------------------------------------- */
 /* out [V, val_dim+1] = sum over rows of w * [values, 1]  (uses the CSR of the last distribute) */
 int tln_splat(tln_lattice_t* l, const float* d_values, int val_dim, const float* d_weights, int64_t rows,
@@ -267,7 +275,9 @@ enum {
   TLN_OP_SLICE,           /* out [N, cols] = blend of s0.slot rows, s1.slot = delta weights (or -1), bias */
   TLN_OP_COPY,            /* out[:, out_col:out_col+cols(s0)] = s0.slot; i[0] != 0: row 0 of the copy zeroed   */
   TLN_OP_ZERO_ROW0,       /* out[0, :] = 0 (lm:569-570)                                                  */
-  TLN_OP_STOP_IF_EARLY    /* early_return frames end here; s0.slot is what the frame returns            */
+  TLN_OP_STOP_IF_EARLY,   /* early_return frames end here; s0.slot is what the frame returns            */
+  TLN_OP_SLICE_DEFORM     /* out [N, cols(s1)] = tln_slice_deform(b = s0.slot, scores = s1.slot; p[0..2] = W_pre, W_dw,
+                             b_dw; bias)                                                                */
 };
 typedef struct {
   int kind;

@@ -92,6 +92,7 @@ _PROTOS = {
     "tln_aflow": (_i, [_vp, _vp, _i64, _i64, _i, _vp, _f, _f, _f, _i, _vp, _vp, _vp, _vp, _vp]),
     "tln_slice_gather": (_i, [_vp, _i64, _i, _vp, _vp, _i64, _vp, _vp]),
     "tln_slice": (_i, [_vp, _i64, _i, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "tln_slice_deform": (_i, [_vp, _i, _vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "tln_splat": (_i, [_vp, _vp, _i, _vp, _i64, _vp, _vp]),
     "tln_scatter_max": (_i, [_vp, _vp, _i64, _i, _i64, _vp, _vp, _vp, _i64, _vp]),
     "tln_scatter_add": (_i, [_vp, _vp, _i64, _i, _i64, _vp, _vp]),

@@ -334,6 +334,127 @@ extern "C" int tln_slice(const float* d_lv, int64_t V, int C, const int32_t* d_i
   return TLN_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// DeformSlice head in ONE kernel (SliceFastCUDALatticeModule, models.py:465): per point
+//   g      = for r: [w_r * b[idx_r, :cb], w_r]                          (cb = 8: 36 features)
+//   hdn    = relu(W_pre g)                                              Linear(36, 36, no bias)
+//   dw     = W_dw hdn + b_dw                                            Linear(36, 4)
+//   out    = sum_r (w_r + dw_r) * scores[idx_r] + bias
+// instead of gather -> two per-point products over [N, 36] -> blend (three [N, 36] round trips through HBM and four
+// launches).  One thread per point, the 36 x 36 + 4 x 36 weights are wave-uniform (scalar loads).
+// ---------------------------------------------------------------------------------------
+template <int CB>
+__global__ void __launch_bounds__(256) k_slice_deform(const float* __restrict__ b, const float* __restrict__ scores,
+                                                      int64_t V, int C, const int32_t* __restrict__ indices,
+                                                      const float* __restrict__ weights,
+                                                      const float* __restrict__ w_pre, const float* __restrict__ w_dw,
+                                                      const float* __restrict__ b_dw, const float* __restrict__ bias,
+                                                      int64_t n, float* __restrict__ out) {
+  constexpr int G = 4 * (CB + 1);            // 36 gathered features
+  constexpr int GP = (G + 3) / 4 * 4;        // LDS rows padded to 16-byte multiples
+  constexpr int PPB = 64;                    // points per block: FOUR lanes per point, each owns G/4 hidden units
+  constexpr int JQ = G / 4;
+  static_assert(G % 4 == 0, "hidden units split over four lanes");
+  __shared__ __attribute__((aligned(16))) float wp_s[G * GP];
+  __shared__ float wd_s[4 * G];
+  __shared__ float wr_s[PPB][4];
+  __shared__ int idx_s[PPB][4];
+  for (int i = threadIdx.x; i < G * GP; i += blockDim.x) {
+    const int j = i / GP, k = i - j * GP;
+    wp_s[i] = k < G ? w_pre[j * G + k] : 0.0f;
+  }
+  for (int i = threadIdx.x; i < 4 * G; i += blockDim.x) wd_s[i] = w_dw[i];
+  __syncthreads();
+  const int pl = threadIdx.x >> 2, q = threadIdx.x & 3;     // point in block, quarter of the hidden layer
+  const int64_t p0 = (int64_t)blockIdx.x * PPB;
+  const int64_t p = p0 + pl;
+  if (p < n) {
+    int idx[4];
+    float w[4];
+    float g[GP];
+#pragma unroll
+    for (int k = 0; k < GP; ++k) g[k] = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      idx[r] = indices[4 * p + r];
+      w[r] = weights[4 * p + r];
+      const bool ok = idx[r] >= 0 && idx[r] < V;
+      if (ok) {
+        const float4* br = reinterpret_cast<const float4*>(b + (int64_t)idx[r] * CB);
+#pragma unroll
+        for (int c4 = 0; c4 < CB / 4; ++c4) {
+          const float4 v = br[c4];
+          g[r * (CB + 1) + 4 * c4] = w[r] * v.x;
+          g[r * (CB + 1) + 4 * c4 + 1] = w[r] * v.y;
+          g[r * (CB + 1) + 4 * c4 + 2] = w[r] * v.z;
+          g[r * (CB + 1) + 4 * c4 + 3] = w[r] * v.w;
+        }
+        g[r * (CB + 1) + CB] = w[r];
+      }
+    }
+    // this lane's hidden units j = q*JQ .. q*JQ+JQ-1 (each: 36 FMAs in input order) and their 4 contributions
+    float dw[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int jj = 0; jj < JQ; ++jj) {
+      const int j = q * JQ + jj;
+      float h = 0.0f;
+#pragma unroll
+      for (int k4 = 0; k4 < GP; k4 += 4) {
+        const float4 wv = *reinterpret_cast<const float4*>(wp_s + j * GP + k4);
+        h = fmaf(wv.x, g[k4], h);
+        h = fmaf(wv.y, g[k4 + 1], h);
+        h = fmaf(wv.z, g[k4 + 2], h);
+        h = fmaf(wv.w, g[k4 + 3], h);
+      }
+      h = fmaxf(h, 0.0f);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dw[r] = fmaf(wd_s[r * G + j], h, dw[r]);
+    }
+    // the four quarters of a point sit in neighbouring lanes: fixed-order sum (q = 0,1,2,3) + bias
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float d0 = __shfl(dw[r], (threadIdx.x & 60) + 0, 64), d1 = __shfl(dw[r], (threadIdx.x & 60) + 1, 64);
+      const float d2 = __shfl(dw[r], (threadIdx.x & 60) + 2, 64), d3 = __shfl(dw[r], (threadIdx.x & 60) + 3, 64);
+      dw[r] = b_dw[r] + ((d0 + d1) + (d2 + d3));
+    }
+    if (q == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        wr_s[pl][r] = w[r] + dw[r];
+        idx_s[pl][r] = (idx[r] >= 0 && idx[r] < V) ? idx[r] : -1;
+      }
+    }
+  }
+  __syncthreads();
+  // blend: the block's points x C classes are written by consecutive threads (coalesced rows of `out`, and each
+  // gathered scores row is read by C neighbouring threads)
+  const int64_t live = (n - p0) < (int64_t)PPB ? (n - p0) : (int64_t)PPB;
+  for (int64_t e = threadIdx.x; e < live * C; e += blockDim.x) {
+    const int pt = (int)(e / C), c = (int)(e - (int64_t)pt * C);
+    float acc = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ix = idx_s[pt][r];
+      if (ix >= 0) acc = fmaf(wr_s[pt][r], scores[(int64_t)ix * C + c], acc);
+    }
+    out[(p0 + pt) * C + c] = bias ? acc + bias[c] : acc;
+  }
+}
+
+extern "C" int tln_slice_deform(const float* d_b, int cb, const float* d_scores, int64_t V, int C,
+                                const int32_t* d_indices, const float* d_weights, const float* d_w_pre,
+                                const float* d_w_dw, const float* d_b_dw, const float* d_bias, int64_t n, float* d_out,
+                                void* stream_) {
+  TLN_REQUIRE(d_b && d_scores && d_indices && d_weights && d_w_pre && d_w_dw && d_b_dw && d_out && C > 0,
+              "null argument");
+  TLN_REQUIRE(cb == 8, "the deform head is built for the 8-channel bottleneck (got %d)", cb);
+  if (n <= 0) return TLN_OK;
+  hipLaunchKernelGGL(k_slice_deform<8>, dim3((unsigned)tln_cdiv(n, 64)), dim3(256), 0, (hipStream_t)stream_, d_b,
+                     d_scores, V, C, d_indices, d_weights, d_w_pre, d_w_dw, d_b_dw, d_bias, n, d_out);
+  TLN_LAUNCH_CHECK();
+  return TLN_OK;
+}
+
 // =======================================================================================
 // torch_scatter 2.0.4 equivalents (reference lm:485-520, models.py:454); dim=0 only
 // =======================================================================================

@@ -385,6 +385,14 @@ int walk(tln_program* p, bool dry, int early, float* d_out, int64_t out_rows, in
         if (rc) return rc;
         break;
       }
+      case TLN_OP_SLICE_DEFORM: {
+        if (dry) break;
+        rc = tln_slice_deform(fptr(o.s0.slot), p->slots[o.s0.slot].cols, fptr(o.s1.slot), p->rt[o.s1.slot].rows,
+                              p->slots[o.s1.slot].cols, p->d_idx, p->d_w, o.p[0], o.p[1], o.p[2], o.bias, p->N,
+                              fptr(o.out), s);
+        if (rc) return rc;
+        break;
+      }
       case TLN_OP_COPY: {
         if (dry) break;
         const tln_slot& ss = p->slots[o.s0.slot];

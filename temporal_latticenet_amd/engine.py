@@ -25,7 +25,7 @@ ROWS_POINTS, ROWS_POINT_ROWS, ROWS_STATE = -1, -2, -16
 SLOT_F32, SLOT_STATS, SLOT_STATE_NEW, SLOT_STATE_PREV, SLOT_OUT = 0, 1, 2, 3, 4
 TABLE_NONE, TABLE_NBR, TABLE_C2F, TABLE_F2C = 0, 1, 2, 3
 (OP_GEMM, OP_GN_PARTIALS, OP_POOL, OP_GRU, OP_AFLOW, OP_SLICE_GATHER, OP_SLICE, OP_COPY, OP_ZERO_ROW0,
- OP_STOP_IF_EARLY) = range(1, 11)
+ OP_STOP_IF_EARLY, OP_SLICE_DEFORM) = range(1, 12)
 
 
 class NotReady(Exception):
@@ -276,21 +276,20 @@ def _walk_model(model):
     clasify = _need(sl.linear_clasify, "slice parameters")
     if sl.dropout is not None and sl.dropout.prob > 0.0:
         b.uses_dropout = True
-    delta = None
+    t = None
     if sl.experiment != "slice_no_deform":
         t = lv
         for m in sl.stepdown:
             t = b.gn_relu_1x1(m, t)
         t = b.gn_relu_1x1(sl.bottleneck, t)
-        g = Val(b.slot(ROWS_POINTS, 4 * (t.cols + 1)), ROWS_POINTS, 4 * (t.cols + 1))
-        b.op(OP_SLICE_GATHER, out=g.slot, s0=b.src(t))
-        hdn = b.gemm(ROWS_POINTS, g.cols, sl.linear_pre_deltaW.weight, True, b.src(g), relu=True, stats=False)
-        delta = b.gemm(ROWS_POINTS, 4, sl.linear_deltaW.weight, True, b.src(hdn), bias=sl.linear_deltaW.bias,
-                       stats=False)
     scores = b.gemm(level, clasify.weight.shape[0], clasify.weight, True, b.src(lv), stats=False)
     out = b.slot(ROWS_POINTS, clasify.weight.shape[0], SLOT_OUT)
-    b.keep.append(clasify.bias)
-    b.op(OP_SLICE, out=out, s0=b.src(scores), s1=b.src(delta) if delta is not None else None, bias=_p(clasify.bias))
+    b.keep += [clasify.bias, sl.linear_pre_deltaW.weight, sl.linear_deltaW.weight, sl.linear_deltaW.bias]
+    if t is not None:
+        b.op(OP_SLICE_DEFORM, out=out, s0=b.src(t), s1=b.src(scores), bias=_p(clasify.bias),
+             p=[_p(sl.linear_pre_deltaW.weight), _p(sl.linear_deltaW.weight), _p(sl.linear_deltaW.bias)] + [None] * 5)
+    else:
+        b.op(OP_SLICE, out=out, s0=b.src(scores), s1=None, bias=_p(clasify.bias))
     b.out_shape = (ROWS_POINTS, clasify.weight.shape[0])
     if not stopped:
         b.stop_shape = None

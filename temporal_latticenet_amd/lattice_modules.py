@@ -407,18 +407,17 @@ class SliceFastCUDALatticeModule(torch.nn.Module):
             feat = AG.slice_blend(lv, indices, weights, delta)
             ls.set_values(lv)
             return torch.nn.functional.linear(feat, self.linear_clasify.weight, self.linear_clasify.bias)
-        delta = None
+        b = None
         if self.experiment != "slice_no_deform":
             b = lv
             for m in self.stepdown:
                 b, _ = m(b, ls)
             b, _ = self.bottleneck(b, ls)
-            g = ops.slice_gather(b, indices, weights)
-            n = g.shape[0]
-            hdn = ops.gather_gemm(n, self.linear_pre_deltaW.weight, ops.gemm_src(g), w_is_nk=True, relu=True)
-            delta = ops.gather_gemm(n, self.linear_deltaW.weight, ops.gemm_src(hdn), w_is_nk=True,
-                                    bias=self.linear_deltaW.bias)
         scores = ops.gather_gemm(lv.shape[0], self.linear_clasify.weight, ops.gemm_src(lv), w_is_nk=True)
-        out = ops.slice_blend(scores, indices, weights, delta, self.linear_clasify.bias)
+        if b is not None:   # gather -> Linear(36,36)+ReLU -> Linear(36,4) -> blend, per point, in one kernel
+            out = ops.slice_deform(b, scores, indices, weights, self.linear_pre_deltaW.weight,
+                                   self.linear_deltaW.weight, self.linear_deltaW.bias, self.linear_clasify.bias)
+        else:
+            out = ops.slice_blend(scores, indices, weights, None, self.linear_clasify.bias)
         ls.set_values(lv)
         return out

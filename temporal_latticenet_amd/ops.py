@@ -8,7 +8,7 @@ from . import _lib
 from .lattice import Lattice, stream_ptr, _ptr
 
 __all__ = ["gemm_src", "gather_gemm", "groupnorm_stats", "affine_act", "pointnet_pool", "gru_cell", "aflow",
-           "slice_gather", "slice_blend", "splat", "im2row", "scatter_max", "scatter_add"]
+           "slice_gather", "slice_blend", "slice_deform", "splat", "im2row", "scatter_max", "scatter_add"]
 
 # ---- optional per-call timing (bench.py roofline pass): HIP events on the launch stream ----------------
 _prof = None
@@ -232,6 +232,18 @@ def slice_blend(lv, indices, weights, delta=None, bias=None):
     _lib.check(_lib.lib().tln_slice(_ptr(lv), lv.shape[0], lv.shape[1], _ptr(indices.contiguous()),
                                     _ptr(_f32c(weights)), _ptr(_f32c(delta)), _ptr(_f32c(bias)), n, _ptr(out),
                                     stream_ptr()), "tln_slice")
+    return out
+
+
+def slice_deform(b, scores, indices, weights, w_pre, w_dw, b_dw, bias=None):
+    """the DeformSlice head per point in one kernel (tln_slice_deform): logits [n, C]"""
+    b, scores = _f32c(b), _f32c(scores)
+    n = indices.shape[0] // 4
+    out = torch.empty((n, scores.shape[1]), dtype=torch.float32, device="cuda")
+    _lib.check(_lib.lib().tln_slice_deform(_ptr(b), b.shape[1], _ptr(scores), scores.shape[0], scores.shape[1],
+                                           _ptr(indices.contiguous()), _ptr(_f32c(weights)), _ptr(_f32c(w_pre)),
+                                           _ptr(_f32c(w_dw)), _ptr(_f32c(b_dw)), _ptr(_f32c(bias)), n, _ptr(out),
+                                           stream_ptr()), "tln_slice_deform")
     return out
 
 
