@@ -184,6 +184,19 @@ int tln_gru_cell(const float* d_x, const float* d_h, int64_t V, int64_t Vh, int 
                  const float* d_w_hh, const float* d_b_ih, const float* d_b_hh, float* d_out,
                  float* d_ws /* [V,6C] */, int64_t ws_floats, void* stream);
 
+/* ---- element-wise steps of the alternative fusion modules (rnn_modules = lstm / maxpool / cga, lm:17-185) ---- */
+/* LSTMModule lm:36-38: gates [V,4C] in torch LSTMCell order i|f|g|o, zero cell state: out = sig(o)*tanh(sig(i)*tanh(g)) */
+int tln_lstm_gates(const float* d_gates, int64_t V, int C, float* d_out, void* stream);
+/* TemporalMaxPoolModule lm:138-141: out [V,C] = max(h padded to V rows with pad_value, x) */
+int tln_temporal_max(const float* d_x, const float* d_h, int64_t V, int64_t Vh, int C, float pad_value,
+                     float* d_out, void* stream);
+/* CrossframeGlobalAttentionModule lm:104-112: out = sigmoid(a * scale) * x for rows < Vh, x for the rows born in this
+ * frame (their gate is set to 1, lm:109-110) */
+int tln_cga_gate(const float* d_a, const float* d_x, int64_t V, int64_t Vh, int C, float scale, float* d_out,
+                 void* stream);
+/* PointNetSeqModule lm:555-562 (early max-pool fusion): rows whose first `half` channels are all zero -> `value` */
+int tln_fill_empty_rows(const float* d_x, int64_t V, int C, int half, float value, float* d_out, void* stream);
+
 /* ---- K10 AFlow correlation: CustomKernelConvLatticeIm2RowModule.forward lm:282-339 ------ */
 /* x [V,C] current features, h [Vh,C] previous hidden state (rows >= Vh = pad_value -999999),
  * table [V,9]; out [V,C] (+bias), weights [V,9], nbr_idx [V,9]. */
@@ -276,8 +289,12 @@ enum {
   TLN_OP_COPY,            /* out[:, out_col:out_col+cols(s0)] = s0.slot; i[0] != 0: row 0 of the copy zeroed   */
   TLN_OP_ZERO_ROW0,       /* out[0, :] = 0 (lm:569-570)                                                  */
   TLN_OP_STOP_IF_EARLY,   /* early_return frames end here; s0.slot is what the frame returns            */
-  TLN_OP_SLICE_DEFORM     /* out [N, cols(s1)] = tln_slice_deform(b = s0.slot, scores = s1.slot; p[0..2] = W_pre, W_dw,
+  TLN_OP_SLICE_DEFORM,    /* out [N, cols(s1)] = tln_slice_deform(b = s0.slot, scores = s1.slot; p[0..2] = W_pre, W_dw,
                              b_dw; bias)                                                                */
+  TLN_OP_LSTM_GATES,      /* out [V, C] = tln_lstm_gates(s0.slot [V, 4C])                                */
+  TLN_OP_TEMPORAL_MAX,    /* out = max(s1.slot padded with f[0], s0.slot)                                */
+  TLN_OP_CGA_GATE,        /* out = sigmoid(s0.slot / (V + C)) * s1.slot, rows past rows(state i[0]) pass unchanged */
+  TLN_OP_FILL_EMPTY       /* out = s0.slot with the rows whose first i[0] channels are zero set to f[0]  */
 };
 typedef struct {
   int kind;

@@ -89,6 +89,10 @@ _PROTOS = {
     "tln_groupnorm_stats": (_i, [_vp, _i64, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _i64, _vp]),
     "tln_affine_act": (_i, [_vp, _i64, _i, _vp, _vp, _i, _vp, _vp]),
     "tln_gru_cell": (_i, [_vp, _vp, _i64, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "tln_lstm_gates": (_i, [_vp, _i64, _i, _vp, _vp]),
+    "tln_temporal_max": (_i, [_vp, _vp, _i64, _i64, _i, _f, _vp, _vp]),
+    "tln_cga_gate": (_i, [_vp, _vp, _i64, _i64, _i, _f, _vp, _vp]),
+    "tln_fill_empty_rows": (_i, [_vp, _i64, _i, _i, _f, _vp, _vp]),
     "tln_aflow": (_i, [_vp, _vp, _i64, _i64, _i, _vp, _f, _f, _f, _i, _vp, _vp, _vp, _vp, _vp]),
     "tln_slice_gather": (_i, [_vp, _i64, _i, _vp, _vp, _i64, _vp, _vp]),
     "tln_slice": (_i, [_vp, _i64, _i, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),

@@ -193,6 +193,96 @@ extern "C" int tln_gru_cell(const float* d_x, const float* d_h, int64_t V, int64
 }
 
 // =======================================================================================
+// Element-wise steps of the alternative fusion modules (reference lm:17-185), so that every `rnn_modules` choice runs
+// on this library's kernels end to end:
+//   LSTMModule lm:36-38              h' = sig(o) * tanh(sig(i) * tanh(g))     (LSTMCell with a zero cell state)
+//   TemporalMaxPoolModule lm:138-141 out = max(pad(h, -9999), x)
+//   CrossframeGlobalAttentionModule lm:104-112   out = sig(a * s) * x, rows born in this frame pass unchanged
+//   PointNetSeqModule lm:555-562     rows whose first half is all zero are filled with -9900 (early max-pool fusion)
+// =======================================================================================
+__device__ __forceinline__ float tln_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ void __launch_bounds__(256) k_lstm_gates(const float* __restrict__ gates, int64_t V, int C,
+                                                    float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= V * C) return;
+  const int64_t v = i / C;
+  const int c = (int)(i - v * C);
+  const float* g = gates + v * 4 * C;   // i | f | g | o (torch.nn.LSTMCell order); f multiplies the zero cell state
+  const float cell = tln_sigmoid(g[c]) * tanhf(g[2 * C + c]);
+  out[i] = tln_sigmoid(g[3 * C + c]) * tanhf(cell);
+}
+
+extern "C" int tln_lstm_gates(const float* d_gates, int64_t V, int C, float* d_out, void* stream_) {
+  TLN_REQUIRE(d_gates && d_out && C > 0 && V >= 0, "bad LSTM gate arguments");
+  if (V == 0) return TLN_OK;
+  hipLaunchKernelGGL(k_lstm_gates, dim3((unsigned)tln_cdiv(V * C, 256)), dim3(256), 0, (hipStream_t)stream_, d_gates, V,
+                     C, d_out);
+  TLN_LAUNCH_CHECK();
+  return TLN_OK;
+}
+
+__global__ void __launch_bounds__(256) k_temporal_max(const float* __restrict__ x, const float* __restrict__ h,
+                                                      int64_t V, int64_t Vh, int C, float pad,
+                                                      float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= V * C) return;
+  const float hv = (i / C < Vh) ? h[i] : pad;
+  out[i] = fmaxf(hv, x[i]);
+}
+
+extern "C" int tln_temporal_max(const float* d_x, const float* d_h, int64_t V, int64_t Vh, int C, float pad_value,
+                                float* d_out, void* stream_) {
+  TLN_REQUIRE(d_x && d_h && d_out && C > 0 && V >= 0 && Vh >= 0 && Vh <= V, "bad temporal max arguments");
+  if (V == 0) return TLN_OK;
+  hipLaunchKernelGGL(k_temporal_max, dim3((unsigned)tln_cdiv(V * C, 256)), dim3(256), 0, (hipStream_t)stream_, d_x, d_h,
+                     V, Vh, C, pad_value, d_out);
+  TLN_LAUNCH_CHECK();
+  return TLN_OK;
+}
+
+__global__ void __launch_bounds__(256) k_cga_gate(const float* __restrict__ a, const float* __restrict__ x, int64_t V,
+                                                  int64_t Vh, int C, float scale, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= V * C) return;
+  const float gte = (i / C < Vh) ? tln_sigmoid(a[i] * scale) : 1.0f;
+  out[i] = gte * x[i];
+}
+
+extern "C" int tln_cga_gate(const float* d_a, const float* d_x, int64_t V, int64_t Vh, int C, float scale, float* d_out,
+                            void* stream_) {
+  TLN_REQUIRE(d_a && d_x && d_out && C > 0 && V >= 0 && Vh >= 0 && Vh <= V, "bad attention gate arguments");
+  if (V == 0) return TLN_OK;
+  hipLaunchKernelGGL(k_cga_gate, dim3((unsigned)tln_cdiv(V * C, 256)), dim3(256), 0, (hipStream_t)stream_, d_a, d_x, V,
+                     Vh, C, scale, d_out);
+  TLN_LAUNCH_CHECK();
+  return TLN_OK;
+}
+
+// one wave per row: |x[:, :half]| summed; an all-zero first half marks an empty vertex
+__global__ void __launch_bounds__(256) k_fill_empty_rows(const float* __restrict__ x, int64_t V, int C, int half,
+                                                         float value, float* __restrict__ out) {
+  const int64_t v = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (v >= V) return;
+  const int lane = threadIdx.x & 63;
+  float s = 0.0f;
+  for (int c = lane; c < half; c += 64) s += fabsf(x[v * C + c]);
+  s = tln_wave_sum(s);
+  const bool empty = s == 0.0f;
+  for (int c = lane; c < C; c += 64) out[v * C + c] = empty ? value : x[v * C + c];
+}
+
+extern "C" int tln_fill_empty_rows(const float* d_x, int64_t V, int C, int half, float value, float* d_out,
+                                   void* stream_) {
+  TLN_REQUIRE(d_x && d_out && C > 0 && half > 0 && half <= C && V >= 0, "bad fill arguments");
+  if (V == 0) return TLN_OK;
+  hipLaunchKernelGGL(k_fill_empty_rows, dim3((unsigned)tln_cdiv(V * 64, 256)), dim3(256), 0, (hipStream_t)stream_, d_x,
+                     V, C, half, value, d_out);
+  TLN_LAUNCH_CHECK();
+  return TLN_OK;
+}
+
+// =======================================================================================
 // K10 AFlow correlation (CustomKernelConvLatticeIm2RowModule.forward, reference lm:298-339).
 // One wave per vertex: distances of the 9 (padded) hidden-state rows to the current centre feature,
 // mask, row-normalise, w = (alpha - min(d, alpha)) * beta, mask, weighted sum of the rows, + bias.

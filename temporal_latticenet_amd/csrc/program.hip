@@ -393,6 +393,36 @@ int walk(tln_program* p, bool dry, int early, float* d_out, int64_t out_rows, in
         if (rc) return rc;
         break;
       }
+      case TLN_OP_LSTM_GATES: {
+        if (dry) break;
+        rc = tln_lstm_gates(fptr(o.s0.slot), p->rt[o.out].rows, p->slots[o.out].cols, fptr(o.out), s);
+        if (rc) return rc;
+        break;
+      }
+      case TLN_OP_TEMPORAL_MAX: {
+        if (dry) break;
+        rc = tln_temporal_max(fptr(o.s0.slot), fptr(o.s1.slot), p->rt[o.out].rows, p->rt[o.s1.slot].rows,
+                              p->slots[o.out].cols, o.f[0], fptr(o.out), s);
+        if (rc) return rc;
+        break;
+      }
+      case TLN_OP_CGA_GATE: {
+        if (dry) break;
+        const int64_t Vr = p->rt[o.out].rows;
+        const int Cn = p->slots[o.out].cols;
+        TLN_REQUIRE(o.i[0] >= 0 && o.i[0] < p->n_states, "op %d: bad state id", oi);
+        rc = tln_cga_gate(fptr(o.s0.slot), fptr(o.s1.slot), Vr, p->state_rows[o.i[0]], Cn, 1.0f / (float)(Vr + Cn),
+                          fptr(o.out), s);
+        if (rc) return rc;
+        break;
+      }
+      case TLN_OP_FILL_EMPTY: {
+        if (dry) break;
+        rc = tln_fill_empty_rows(fptr(o.s0.slot), p->rt[o.out].rows, p->slots[o.out].cols, o.i[0], o.f[0], fptr(o.out),
+                                 s);
+        if (rc) return rc;
+        break;
+      }
       case TLN_OP_COPY: {
         if (dry) break;
         const tln_slot& ss = p->slots[o.s0.slot];

@@ -7,10 +7,10 @@ tree is walked ONCE, after the lazily created parameters exist, and turned into 
 same C-ABI entry points with the same arguments in the same order as the modules do, so both routes produce
 identical tensors (tests/test_gpu_engine.py compares them bit for bit).
 
-Supported: experiment none / slice_no_deform / pointnet_no_local_mean, fusion modules none / gru / aflow / linear in
-every slot (the BASELINE configurations and the simplest alternative).  Anything else (lstm, maxpool, cga, the
-no-elevation / attention-pool experiments), gradients, dropout in training mode and the AFlow visualisation hooks
-stay on the operator-level route (compile_model returns None).
+Supported: experiment none / slice_no_deform / pointnet_no_local_mean and every fusion choice of `rnn_modules`
+(none / gru / aflow / linear / lstm / maxpool / cga) in every slot.  The no-elevation / attention-pool experiments,
+gradients, dropout in training mode and the AFlow visualisation hooks stay on the operator-level route
+(compile_model returns None).
 """
 import ctypes as C
 
@@ -19,13 +19,14 @@ import torch
 from . import _lib
 from .lattice import stream_ptr
 from .lattice_modules import BottleneckBlock, NO_MEAN_EXPERIMENTS, ResnetBlock
-from .seq_modules import CrossframeLocalInterpolationModule, GRUModule, TemporalLinearModule
+from .seq_modules import (CrossframeGlobalAttentionModule, CrossframeLocalInterpolationModule, GRUModule, LSTMModule,
+                          TemporalLinearModule, TemporalMaxPoolModule)
 
 ROWS_POINTS, ROWS_POINT_ROWS, ROWS_STATE = -1, -2, -16
 SLOT_F32, SLOT_STATS, SLOT_STATE_NEW, SLOT_STATE_PREV, SLOT_OUT = 0, 1, 2, 3, 4
 TABLE_NONE, TABLE_NBR, TABLE_C2F, TABLE_F2C = 0, 1, 2, 3
 (OP_GEMM, OP_GN_PARTIALS, OP_POOL, OP_GRU, OP_AFLOW, OP_SLICE_GATHER, OP_SLICE, OP_COPY, OP_ZERO_ROW0,
- OP_STOP_IF_EARLY, OP_SLICE_DEFORM) = range(1, 12)
+ OP_STOP_IF_EARLY, OP_SLICE_DEFORM, OP_LSTM_GATES, OP_TEMPORAL_MAX, OP_CGA_GATE, OP_FILL_EMPTY) = range(1, 16)
 
 
 class NotReady(Exception):
@@ -180,6 +181,28 @@ class Builder:
                            bias=mod.hidden_linear.bias, stats=False, cond=(sid, 1))        # lm:172
             self.gemm(level, x.cols, mod.linear.weight, True, self.src(h1, pad_value=0.0), self.src(x),
                       bias=mod.linear.bias, relu=True, stats=False, cond=(sid, 1), out=new)  # lm:174-179
+        elif isinstance(mod, LSTMModule):
+            cell = mod.lstm
+            h1 = self.gemm(ROWS_STATE - sid, x.cols, mod.hidden_linear.weight, True, self.src(prev_val),
+                           bias=mod.hidden_linear.bias, stats=False, cond=(sid, 1))        # lm:32
+            gi = self.gemm(level, 4 * x.cols, cell.weight_ih, True, self.src(x), bias=cell.bias_ih, stats=False,
+                           cond=(sid, 1))
+            gates = self.gemm(level, 4 * x.cols, cell.weight_hh, True, self.src(h1, pad_value=0.0), bias=cell.bias_hh,
+                              residual=gi, stats=False, cond=(sid, 1))                     # lm:33-36
+            self.op(OP_LSTM_GATES, out=new, s0=self.src(gates), cond_state=sid, cond_has=1)
+        elif isinstance(mod, TemporalMaxPoolModule):
+            self.op(OP_TEMPORAL_MAX, out=new, s0=self.src(x), s1=self.src(prev_val), cond_state=sid, cond_has=1,
+                    f=[-9999.0, 0.0, 0.0, 0.0])                                            # lm:138-141
+        elif isinstance(mod, CrossframeGlobalAttentionModule):
+            lin = _need(mod.conv.linear, "attention conv")
+            gn = _need(mod.groupnorm.norm, "attention GroupNorm")
+            h1 = self.gemm(ROWS_STATE - sid, x.cols, mod.hidden_linear.weight, True, self.src(prev_val),
+                           bias=mod.hidden_linear.bias, stats=False, cond=(sid, 1))        # lm:89
+            a = self.gemm(level, x.cols, lin.weight, True, self.src(h1, pad_value=0.0), relu=True, stats=True,
+                          cond=(sid, 1))                                                   # lm:90-98
+            a2 = self.gemm(level, x.cols, lin.weight, True, self.src(a, gn=gn), stats=False, cond=(sid, 1))  # lm:100-102
+            self.op(OP_CGA_GATE, out=new, s0=self.src(a2), s1=self.src(x), cond_state=sid, cond_has=1,
+                    i=[sid] + [0] * 7)                                                     # lm:104-112
         else:
             raise Unsupported(type(mod).__name__)
         return Val(new, level, x.cols)
@@ -192,7 +215,7 @@ def _walk_model(model):
     seq = model.sequence_learning
     rnn = model.rnn_modules if seq else ["none"] * 4
     for k in rnn:
-        if k not in ("none", "gru", "aflow", "linear"):
+        if k not in ("none", "gru", "aflow", "linear", "lstm", "maxpool", "cga"):
             raise Unsupported("fusion module " + k)
     pn = model.point_net_seq
     if pn.experiment not in ("none", "slice_no_deform", "pointnet_no_local_mean"):
@@ -208,8 +231,13 @@ def _walk_model(model):
     ws = [l.weight for l in pn.layers]
     bs = [l.bias for l in pn.layers]
     b.keep += ws + bs
+    early_maxpool = seq and rnn[0] == "maxpool"
     b.op(OP_POOL, out=pooled.slot, p=[_p(w) for w in ws] + [None] * (4 - len(ws)) + [_p(x) for x in bs] +
-         [None] * (4 - len(bs)), i=[len(ws)] + dims + [0] * (5 - len(dims)) + [4, 0])
+         [None] * (4 - len(bs)), i=[len(ws)] + dims + [0] * (5 - len(dims)) + [0 if early_maxpool else 4, 0])
+    if early_maxpool:                                    # lm:555-562: empty vertices must lose the max
+        filled = Val(b.slot(0, pooled.cols), 0, pooled.cols)
+        b.op(OP_FILL_EMPTY, out=filled.slot, s0=b.src(pooled), i=[pooled.cols // 2] + [0] * 7, f=[-9900.0, 0.0, 0.0, 0.0])
+        pooled = filled
     fm = pn.fusion_module if seq else None
     x = b.fusion(fm, pooled, 0)
     if fm is not None:                                   # the stored state keeps its row 0 (lm:569-570 on a copy)

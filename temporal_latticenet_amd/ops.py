@@ -203,6 +203,38 @@ def gru_cell(x, h, w_ih, w_hh, b_ih, b_hh):
     return out
 
 
+def lstm_gates(gates, C):
+    gates = _f32c(gates)
+    V = gates.shape[0]
+    out = torch.empty((V, C), dtype=torch.float32, device="cuda")
+    _lib.check(_lib.lib().tln_lstm_gates(_ptr(gates), V, C, _ptr(out), stream_ptr()), "tln_lstm_gates")
+    return out
+
+
+def temporal_max(x, h, pad_value=-9999.0):
+    x, h = _f32c(x), _f32c(h)
+    out = torch.empty_like(x)
+    _lib.check(_lib.lib().tln_temporal_max(_ptr(x), _ptr(h), x.shape[0], h.shape[0], x.shape[1], float(pad_value),
+                                           _ptr(out), stream_ptr()), "tln_temporal_max")
+    return out
+
+
+def cga_gate(a, x, Vh, scale):
+    a, x = _f32c(a), _f32c(x)
+    out = torch.empty_like(x)
+    _lib.check(_lib.lib().tln_cga_gate(_ptr(a), _ptr(x), x.shape[0], int(Vh), x.shape[1], float(scale), _ptr(out),
+                                       stream_ptr()), "tln_cga_gate")
+    return out
+
+
+def fill_empty_rows(x, half, value):
+    x = _f32c(x)
+    out = torch.empty_like(x)
+    _lib.check(_lib.lib().tln_fill_empty_rows(_ptr(x), x.shape[0], x.shape[1], int(half), float(value), _ptr(out),
+                                              stream_ptr()), "tln_fill_empty_rows")
+    return out
+
+
 def aflow(x, h, table_ptr, alpha, beta, bias=None, pad_value=-999999.0, use_center=True):
     x, h = _f32c(x), _f32c(h)
     V, Cn = x.shape

@@ -67,9 +67,7 @@ class LSTMModule(torch.nn.Module):
             gi = ops.gather_gemm(V, self.lstm.weight_ih, ops.gemm_src(lv), w_is_nk=True, bias=self.lstm.bias_ih)
             gates = ops.gather_gemm(V, self.lstm.weight_hh, ops.gemm_src(self.h_lv, src_rows=Vh, pad_value=0.0),
                                     w_is_nk=True, bias=self.lstm.bias_hh, residual=gi)
-            i, f, g, o = gates.chunk(4, 1)
-            c = torch.sigmoid(i) * torch.tanh(g)                                     # f * c0 with c0 = 0
-            lv = torch.sigmoid(o) * torch.tanh(c)
+            lv = ops.lstm_gates(gates, C)                 # sig(o) * tanh(sig(i) * tanh(g)): f * c0 with c0 = 0 (lm:36-38)
             self.h_lv = _keep(lv)
             ls.set_values(lv)
         return lv, ls
@@ -126,19 +124,28 @@ class CrossframeGlobalAttentionModule(torch.nn.Module):
             V = lv.shape[0]
             Vh = self.h_lv.shape[0]
             self.h_lv = _linear(self.hidden_linear, self.h_lv)                       # lm:89
-            h_lv = torch.nn.functional.pad(self.h_lv, (0, 0, 0, V - Vh), value=0.0)  # lm:90-91
-            h_lv, _ = self.conv(h_lv, ls)                                            # lm:95
-            h_lv = self.relu(h_lv)                                                   # lm:98
-            h_lv, _ = self.groupnorm(h_lv, ls)                                       # lm:100
-            h_lv, _ = self.conv(h_lv, ls)                                            # lm:102
-            h_lv = h_lv * (1.0 / (h_lv.shape[0] + h_lv.shape[1]))                    # lm:104
-            h_lv = self.sigmoid(h_lv)                                                # lm:106
-            if V > Vh:                                                               # lm:109-110
-                if AG.grad_mode():
+            if AG.grad_mode():
+                h_lv = torch.nn.functional.pad(self.h_lv, (0, 0, 0, V - Vh), value=0.0)  # lm:90-91
+                h_lv, _ = self.conv(h_lv, ls)                                        # lm:95
+                h_lv = self.relu(h_lv)                                               # lm:98
+                h_lv, _ = self.groupnorm(h_lv, ls)                                   # lm:100
+                h_lv, _ = self.conv(h_lv, ls)                                        # lm:102
+                h_lv = h_lv * (1.0 / (h_lv.shape[0] + h_lv.shape[1]))                # lm:104
+                h_lv = self.sigmoid(h_lv)                                            # lm:106
+                if V > Vh:                                                           # lm:109-110
                     h_lv = torch.cat([h_lv[:Vh], torch.ones_like(h_lv[Vh:])], 0)
-                else:
-                    h_lv[Vh:] = 1.0
-            lv = h_lv * lv                                                           # lm:112
+                lv = h_lv * lv                                                       # lm:112
+            else:
+                # the same chain on the library's kernels: conv1x1 of the zero-padded state with the ReLU in the
+                # epilogue (lm:90-98), GroupNorm folded into the second conv1x1 (lm:100-102), then scale, sigmoid,
+                # ones for the rows born in this frame and the gate in one element-wise pass (lm:104-112)
+                if self.conv.linear is None:
+                    self.conv._make(self.h_lv.shape[1])
+                w = self.conv.linear.weight
+                a = ops.gather_gemm(V, w, ops.gemm_src(self.h_lv, src_rows=Vh, pad_value=0.0), w_is_nk=True, relu=True,
+                                    stats=True)
+                a = ops.gather_gemm(V, w, ops.gemm_src(a), w_is_nk=True, gn=(a, self.groupnorm.ensure(a), False))
+                lv = ops.cga_gate(a, lv, Vh, 1.0 / (V + a.shape[1]))
             self.h_lv = _keep(lv)
             ls.set_values(lv)
         return lv, ls
@@ -159,10 +166,14 @@ class TemporalMaxPoolModule(torch.nn.Module):
         if self.h_lv is None:
             self.h_lv = _keep(lv)
         else:
-            pad = lv.shape[0] - self.h_lv.shape[0]
-            h_lv = torch.nn.functional.pad(self.h_lv, (0, 0, 0, pad), value=-9999.0)  # lm:138-139
-            lv = torch.maximum(h_lv, lv)                                             # lm:141
-            self.h_lv = _keep(lv) if alpha == 0.0 else alpha * h_lv + (1 - alpha) * lv   # lm:142
+            if AG.grad_mode() or alpha != 0.0:
+                pad = lv.shape[0] - self.h_lv.shape[0]
+                h_lv = torch.nn.functional.pad(self.h_lv, (0, 0, 0, pad), value=-9999.0)  # lm:138-139
+                lv = torch.maximum(h_lv, lv)                                         # lm:141
+                self.h_lv = _keep(lv) if alpha == 0.0 else alpha * h_lv + (1 - alpha) * lv   # lm:142
+            else:
+                lv = ops.temporal_max(lv, self.h_lv, -9999.0)                        # lm:138-141 in one kernel
+                self.h_lv = _keep(lv)
         ls.set_values(lv)
         return lv, ls
 
@@ -427,8 +438,11 @@ class PointNetSeqModule(torch.nn.Module):
 
         if self.sequence_learning and self.rnn_modules[0] == "maxpool":              # lm:555-563
             feat_size = distributed_reduced.shape[1]
-            rowsum = distributed_reduced[:, 0:int(feat_size / 2)].abs().sum(dim=1).unsqueeze(1)
-            distributed_reduced = distributed_reduced.masked_fill(rowsum == 0, -9900)
+            if AG.grad_mode():
+                rowsum = distributed_reduced[:, 0:int(feat_size / 2)].abs().sum(dim=1).unsqueeze(1)
+                distributed_reduced = distributed_reduced.masked_fill(rowsum == 0, -9900)
+            else:
+                distributed_reduced = ops.fill_empty_rows(distributed_reduced, int(feat_size / 2), -9900.0)
             distributed_reduced, lattice_py = self.fusion_module(distributed_reduced, lattice_py)
         elif self.sequence_learning and self.fusion_module is not None:              # lm:564-565
             distributed_reduced, lattice_py = self.fusion_module(distributed_reduced, lattice_py)

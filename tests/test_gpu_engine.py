@@ -40,6 +40,8 @@ def _prepared(contents, seq, gpu, nr_classes=26, seed=3):
     (("none", "gru", "none", "none"), True, 3),        # ... after the middle fusion (models.py:346)
     (("gru", "none", "none", "none"), False, 1),       # no sequence learning
     (("linear", "linear", "gru", "linear"), True, 3),  # TemporalLinearModule (lm:149-185)
+    (("maxpool", "linear", "lstm", "cga"), True, 3),   # early max-pool fusion (lm:555-563), LSTM, global attention
+    (("cga", "lstm", "maxpool", "lstm"), True, 3),
 ])
 def test_program_equals_operator_route(gpu, rnn, seq_learning, frames):
     contents = make_config(rnn_modules=rnn, sequence_learning=seq_learning, frames=frames, sigma=0.7)
@@ -88,7 +90,8 @@ def test_hidden_states_follow_a_frame_that_needs_the_operator_route(gpu):
 
 
 def test_unsupported_configuration_stays_on_the_operator_route(gpu):
-    contents = make_config(rnn_modules=("maxpool", "gru", "lstm", "cga"), frames=2, sigma=0.8)
+    contents = make_config(rnn_modules=("none", "gru", "none", "gru"), frames=2, sigma=0.8,
+                           experiment="pointnet_no_elevate")
     seq = make_sequence(6000, 2, seed=6)
     model = _prepared(contents, seq, gpu)
     model.use_frame_program = True
