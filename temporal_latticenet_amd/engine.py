@@ -172,15 +172,21 @@ class Builder:
             self.op(OP_AFLOW, out=av, s0=dict(self.src(x), level=level), s1=self.src(prev_val), cond_state=sid,
                     cond_has=1, bias=_p(a.bias) if a.use_bias else None,
                     f=[float(a.alpha), float(a.beta), -999999.0, 0.0], i=[1 if a.use_center else 0] + [0] * 7)
-            self.gemm(level, x.cols, mod.linear.weight, True, self.src(Val(av, level, x.cols)), self.src(x),
-                      bias=mod.linear.bias, relu=True, stats=False, cond=(sid, 1), out=new)  # lm:223-227
+            out = self.gemm(level, x.cols, mod.linear.weight, True, self.src(Val(av, level, x.cols)), self.src(x),
+                            bias=mod.linear.bias, relu=True, stats=True, cond=(sid, 1), out=new)  # lm:223-227
+            # the product leaves the GroupNorm partial sums of the new state; the first frame (a plain copy) gets
+            # them from one pass, into the same slot
+            self.op(OP_GN_PARTIALS, s0=self.src(Val(new, level, x.cols)), stats_out=out.stats, cond_state=sid, cond_has=0)
+            return Val(new, level, x.cols, out.stats)
         elif isinstance(mod, TemporalLinearModule):
             if x.cols != mod.nr_output_channels:
                 raise Unsupported("TemporalLinearModule width")
             h1 = self.gemm(ROWS_STATE - sid, x.cols, mod.hidden_linear.weight, True, self.src(prev_val),
                            bias=mod.hidden_linear.bias, stats=False, cond=(sid, 1))        # lm:172
-            self.gemm(level, x.cols, mod.linear.weight, True, self.src(h1, pad_value=0.0), self.src(x),
-                      bias=mod.linear.bias, relu=True, stats=False, cond=(sid, 1), out=new)  # lm:174-179
+            out = self.gemm(level, x.cols, mod.linear.weight, True, self.src(h1, pad_value=0.0), self.src(x),
+                            bias=mod.linear.bias, relu=True, stats=True, cond=(sid, 1), out=new)  # lm:174-179
+            self.op(OP_GN_PARTIALS, s0=self.src(Val(new, level, x.cols)), stats_out=out.stats, cond_state=sid, cond_has=0)
+            return Val(new, level, x.cols, out.stats)
         elif isinstance(mod, LSTMModule):
             cell = mod.lstm
             h1 = self.gemm(ROWS_STATE - sid, x.cols, mod.hidden_linear.weight, True, self.src(prev_val),

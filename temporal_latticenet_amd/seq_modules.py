@@ -208,7 +208,7 @@ class TemporalLinearModule(torch.nn.Module):
                                                            self.linear.weight, self.linear.bias))
             else:
               lv = ops.gather_gemm(V, self.linear.weight, ops.gemm_src(self.h_lv, src_rows=Vh, pad_value=0.0),
-                                 ops.gemm_src(lv), w_is_nk=True, bias=self.linear.bias, relu=True)
+                                 ops.gemm_src(lv), w_is_nk=True, bias=self.linear.bias, relu=True, stats=True)
             self.h_lv = _keep(lv)
         ls.set_values(lv)
         return lv, ls
@@ -326,7 +326,7 @@ class CrossframeLocalInterpolationModule(torch.nn.Module):
                                                            self.linear.bias))
             else:
               lv = ops.gather_gemm(V, self.linear.weight, ops.gemm_src(aflow_vec), ops.gemm_src(lv), w_is_nk=True,
-                                 bias=self.linear.bias, relu=True)
+                                 bias=self.linear.bias, relu=True, stats=True)      # + partial sums for the next Gn
             self.h_lv = _keep(lv)
         ls.set_values(lv)
         return lv, ls
