@@ -501,7 +501,8 @@ __global__ void __launch_bounds__(768) k_gather_gemm_direct(const GemmArgs g) {
   const int n = n0 + l31;
   const bool ncol = n < g.N;
 
-  // LDS: [region: max(K-group reduction, GroupNorm partial scratch)] [Gsc cin0] [Gsh cin0] [Gch cin0 double2]
+  // LDS: [region: max(parked accumulators + statistics partials, GroupNorm partial scratch)] [Gsc cin0] [Gsh cin0]
+  //      [tap indices 32 x 9]
   const int cin0 = g.s[0].cin;
   const bool gn_lds = g.s[0].gn_part != nullptr;
   const bool pro_lds = gn_lds || g.s[0].scale != nullptr;
@@ -516,7 +517,6 @@ __global__ void __launch_bounds__(768) k_gather_gemm_direct(const GemmArgs g) {
   }
   float* Gsc = smem + region;
   float* Gsh = Gsc + cin0;
-  double2* Gch = reinterpret_cast<double2*>(Gsh + cin0);
 
   const bool stamp = g.dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0;
   if (stamp) g.dbg[0] = __builtin_amdgcn_s_memtime();
@@ -532,7 +532,7 @@ __global__ void __launch_bounds__(768) k_gather_gemm_direct(const GemmArgs g) {
 
   // tap indices of the block's 32 rows (source 0): one contiguous 1152-byte span of the table -> LDS
   const int64_t mc = mrow ? m : g.M - 1;  // rows past M work on row M-1 (their outputs are never stored)
-  int* Is = reinterpret_cast<int*>(Gch + cin0);
+  int* Is = reinterpret_cast<int*>(Gsh + cin0);
   if (g.s[0].table != nullptr) {
     const int64_t lim = g.M * TLN_TAPS;
     for (int i = threadIdx.x; i < 32 * TLN_TAPS; i += T) {
@@ -900,7 +900,7 @@ static int launch_direct(GemmArgs& g, int nchunks, int groups, hipStream_t s) {
     const size_t need = (size_t)J * cin0 * 4;
     if (need > region) region = need;
   }
-  const size_t lds = (region + (size_t)6 * cin0 + 32 * TLN_TAPS + 4) * sizeof(float);
+  const size_t lds = (region + (size_t)2 * cin0 + 32 * TLN_TAPS + 4) * sizeof(float);
   TLN_REQUIRE(lds <= 96 * 1024, "direct gemm: LDS %zu B", lds);
   if (lds > 48 * 1024) {
     static size_t attr_bytes = 0;  // per instantiation
