@@ -481,11 +481,30 @@ __global__ void __launch_bounds__(256) k_distribute_insert(const float* __restri
   int k0, k1, k2;
   vertex_key(rem0, rank, r, k0, k1, k2);
   const uint32_t id = (uint32_t)gid;
-  if (live_row) {
+  {
+    // Rows of neighbouring points mostly share their lattice vertices: only the FIRST lane of every distinct key in
+    // the wave probes the table (it also carries the smallest row id of its group, which is what first touch needs),
+    // the others take its slot.  On the first frame of a sequence every key is new and the CAS / atomicMin traffic of
+    // 480k rows on ~2k slots made this kernel 4x slower than on the later frames.
+    const bool valid = live_row && tln_key_in_range(k0, k1, k2);
+    const uint64_t K = valid ? tln_pack_key(k0, k1, k2) : 0ull;
+    const int lane = threadIdx.x & 63;
+    int leader = lane;
+    unsigned long long todo = __ballot(valid);
+    while (todo) {                                        // one round per distinct key, no memory traffic
+      const int first = __builtin_ctzll(todo);
+      const uint64_t kf = __shfl(K, first, 64);
+      const unsigned long long same = __ballot(valid && K == kf);
+      if (valid && K == kf) leader = first;
+      todo &= ~same;
+    }
     int slot = -1;
-    if (tln_key_in_range(k0, k1, k2)) slot = probe_insert(t, tln_pack_key(k0, k1, k2), id);
-    row_slot[id] = slot;
-    weights[id] = b;
+    if (valid && leader == lane) slot = probe_insert(t, K, id);
+    slot = __shfl(slot, leader, 64);
+    if (live_row) {
+      row_slot[id] = valid ? slot : -1;
+      weights[id] = b;
+    }
   }
   if (val_dim == 1) {
     // the 64 rows of a wave are 64 x 20 contiguous bytes: staged through LDS and written as five fully coalesced
