@@ -606,61 +606,46 @@ __global__ void __launch_bounds__(TLN_SCAN_BLOCK) k_count_new(TableRef t, const 
   }
 }
 
-// single block: exclusive scan of block_cnt (in place), update the vertex counter
-__global__ void __launch_bounds__(1024) k_scan_blocks(int32_t* __restrict__ block_cnt, int nblocks,
-                                                      int32_t* __restrict__ ctr, int capacity) {
-  __shared__ int wave_tot[16];
-  __shared__ int carry_s;
-  if (threadIdx.x == 0) carry_s = 0;
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  for (int base = 0; base < nblocks; base += 1024) {
-    const int i = base + threadIdx.x;
-    const int v = (i < nblocks) ? block_cnt[i] : 0;
-    int incl = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int u = __shfl_up(incl, o, 64);
-      if (lane >= o) incl += u;
-    }
-    if (lane == 63) wave_tot[wid] = incl;
-    __syncthreads();
-    int woff = 0;
-    for (int w = 0; w < wid; ++w) woff += wave_tot[w];
-    const int carry = carry_s;
-    if (i < nblocks) block_cnt[i] = carry + woff + incl - v;
-    __syncthreads();
-    if (threadIdx.x == 1023) carry_s = carry + woff + incl;
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    const int total = carry_s;
-    const int vold = ctr[CTR_NV];
-    ctr[CTR_VOLD] = vold;
-    ctr[CTR_NEW] = total;
-    ctr[CTR_OVERFLOW] = 0;  // accumulated by k_row_indices, which runs after the numbering
-    long long vnew = (long long)vold + total;
-    ctr[CTR_NV] = (int)(vnew < capacity ? vnew : capacity);
-  }
-}
-
+// numbering of the new slots: rank of a first-touch row = first-touch rows before it.  Every block sums the counts of
+// the blocks before it itself (a few hundred integers) — no separate scan launch; the last block also publishes the
+// new vertex count.  `vold` is the vertex count before this insertion (exact on the host).
 __global__ void __launch_bounds__(TLN_SCAN_BLOCK) k_assign_new(TableRef t, const int32_t* __restrict__ row_slot,
-                                                               int64_t rows, const int32_t* __restrict__ block_off,
-                                                               const int32_t* __restrict__ ctr, int capacity,
+                                                               int64_t rows, const int32_t* __restrict__ block_cnt,
+                                                               int32_t* __restrict__ ctr, int vold, int capacity,
                                                                int32_t* __restrict__ vkeys) {
   __shared__ int wave_cnt[TLN_SCAN_BLOCK / 64];
+  __shared__ int wave_pre[TLN_SCAN_BLOCK / 64];
   const int64_t id = (int64_t)blockIdx.x * TLN_SCAN_BLOCK + threadIdx.x;
   int slot;
   const bool f = is_first_touch(t, row_slot, id, rows, slot);
   const unsigned long long m = __ballot(f);
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  if (lane == 0) wave_cnt[wid] = __popcll(m);
+  int pre = 0;
+  for (int bq = threadIdx.x; bq < (int)blockIdx.x; bq += TLN_SCAN_BLOCK) pre += block_cnt[bq];
+  pre = tln_wave_sum(pre);
+  if (lane == 0) {
+    wave_cnt[wid] = __popcll(m);
+    wave_pre[wid] = pre;
+  }
   __syncthreads();
+  int block_off = 0, block_total = 0;
+  for (int w = 0; w < TLN_SCAN_BLOCK / 64; ++w) {
+    block_off += wave_pre[w];
+    block_total += wave_cnt[w];
+  }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+    const int total = block_off + block_total;
+    ctr[CTR_VOLD] = vold;
+    ctr[CTR_NEW] = total;
+    ctr[CTR_OVERFLOW] = 0;  // accumulated by k_row_indices, which runs after the numbering
+    const long long vnew = (long long)vold + total;
+    ctr[CTR_NV] = (int)(vnew < capacity ? vnew : capacity);
+  }
   if (!f) return;
   int woff = 0;
   for (int w = 0; w < wid; ++w) woff += wave_cnt[w];
-  const int rank = block_off[blockIdx.x] + woff + __popcll(m & ((1ull << lane) - 1ull));
-  const long long v = (long long)ctr[CTR_VOLD] + rank;
+  const int rank = block_off + woff + __popcll(m & ((1ull << lane) - 1ull));
+  const long long v = (long long)vold + rank;
   if (v < capacity) {
     t.slot_val[slot] = (int)v;
     int k0, k1, k2;
@@ -751,9 +736,8 @@ static int number_new(tln_lattice* l, int64_t rows, hipStream_t s) {
     return TLN_OK;
   }
   hipLaunchKernelGGL(k_count_new, dim3(nblocks), dim3(TLN_SCAN_BLOCK), 0, s, t, l->row_slot, rows, l->block_cnt);
-  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, l->block_cnt, nblocks, l->d_ctr, (int)l->capacity);
   hipLaunchKernelGGL(k_assign_new, dim3(nblocks), dim3(TLN_SCAN_BLOCK), 0, s, t, l->row_slot, rows, l->block_cnt,
-                     l->d_ctr, (int)l->capacity, l->vkeys);
+                     l->d_ctr, (int)l->nr_vertices, (int)l->capacity, l->vkeys);
   TLN_LAUNCH_CHECK();
   return TLN_OK;
 }
