@@ -251,3 +251,47 @@ def test_torch_scatter_equivalents(gpu):
     assert torch.equal(out.cpu(), wo) and torch.equal(arg.cpu(), wa)
     add = ops.scatter_add(src.to(gpu), index.to(gpu), 320)
     np.testing.assert_allclose(add.cpu().numpy(), O.scatter_add(src, index, 320).numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_elementwise_fusion_kernels(gpu):
+    """the element-wise steps of the alternative fusion modules against their reference formulas (lm:36-38, 138-141,
+    104-112, 555-562)"""
+    from temporal_latticenet_amd import ops
+    g = torch.Generator().manual_seed(5)
+    V, Vh, C = 777, 601, 96
+    gates = torch.randn(V, 4 * C, generator=g)
+    i, f, gg, o = gates.chunk(4, 1)
+    want = torch.sigmoid(o) * torch.tanh(torch.sigmoid(i) * torch.tanh(gg))
+    np.testing.assert_allclose(ops.lstm_gates(gates.to(gpu), C).cpu().numpy(), want.numpy(), rtol=1e-5, atol=1e-6)
+
+    x, h = torch.randn(V, C, generator=g), torch.randn(Vh, C, generator=g)
+    want = torch.maximum(torch.nn.functional.pad(h, (0, 0, 0, V - Vh), value=-9999.0), x)
+    assert torch.equal(ops.temporal_max(x.to(gpu), h.to(gpu), -9999.0).cpu(), want)
+
+    a = torch.randn(V, C, generator=g) * 50
+    gate = torch.sigmoid(a * (1.0 / (V + C)))
+    gate[Vh:] = 1.0
+    np.testing.assert_allclose(ops.cga_gate(a.to(gpu), x.to(gpu), Vh, 1.0 / (V + C)).cpu().numpy(), (gate * x).numpy(),
+                               rtol=1e-5, atol=1e-6)
+
+    y = torch.randn(V, C, generator=g)
+    y[::7, : C // 2] = 0.0                      # "empty" vertices: first half all zero
+    rowsum = y[:, : C // 2].abs().sum(1, keepdim=True)
+    want = y.masked_fill(rowsum == 0, -9900)
+    assert torch.equal(ops.fill_empty_rows(y.to(gpu), C // 2, -9900.0).cpu(), want)
+
+
+def test_slice_deform_matches_the_unfused_chain(gpu):
+    """tln_slice_deform == gather -> Linear(36,36)+ReLU -> Linear(36,4) -> blend + bias (SliceFastCUDALatticeModule)"""
+    from temporal_latticenet_amd import ops
+    lat, tab, (d, i, w), (od, oi, ow) = _lattice(gpu, 9000, 0.7, frames=1)
+    V = lat.nr_lattice_vertices()
+    g = torch.Generator().manual_seed(7)
+    b, scores = torch.randn(V, 8, generator=g), torch.randn(V, 26, generator=g)
+    Wp, Wd, bd, bias = (torch.randn(36, 36, generator=g) * 0.3, torch.randn(4, 36, generator=g) * 0.1,
+                        torch.randn(4, generator=g) * 0.1, torch.randn(26, generator=g))
+    got = ops.slice_deform(b.to(gpu), scores.to(gpu), i, w, Wp.to(gpu), Wd.to(gpu), bd.to(gpu), bias.to(gpu)).cpu()
+    gth = O.slice_gather(b, oi, ow)
+    delta = torch.nn.functional.linear(torch.relu(torch.nn.functional.linear(gth, Wp)), Wd, bd)
+    want = O.slice_blend(scores, oi, ow, delta) + bias
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-4, atol=1e-4)
