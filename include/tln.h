@@ -87,6 +87,15 @@ int tln_coarsen(tln_lattice_t* fine, tln_lattice_t** coarse_out, void* stream);
 /* once per frame, after tln_distribute: extends the coarse levels and (re)builds every stale neighbour / cross-level
  * table of the stack in one launch; afterwards the table getters return cached pointers */
 int tln_lattice_prepare_levels(tln_lattice_t* level0, int nr_coarse_levels, void* stream);
+/* the same in two halves, so that work that only needs level 0 can be launched while the coarse levels' vertex
+ * counts are still on their way to the host: _begin extends every coarse level, starts ONE asynchronous fetch of
+ * their counters and builds the level-0 neighbour table; v_bound_out[0] = V0 (exact), v_bound_out[i] >= the new vertex
+ * count of level i (may be NULL).  _finish waits for that fetch only (an event, not the stream), publishes the exact
+ * counts and builds the coarse tables.  Every entry point that looks at a coarse level finishes a pending fetch. */
+int tln_lattice_prepare_levels_begin(tln_lattice_t* l, int nr_coarse_levels, int64_t* v_bound_out, void* stream);
+int tln_lattice_prepare_levels_finish(tln_lattice_t* l, void* stream);
+/* the coarse level of `l` as it stands (NULL if none yet); no side effects */
+tln_lattice_t* tln_lattice_coarse_level(tln_lattice_t* l);
 /* [V_coarse,9] rows into the fine level (coarsen conv) / [V_fine,9] rows into the coarse level (finefy) */
 int tln_coarse_to_fine_table(tln_lattice_t* coarse, const int32_t** d_table_out, void* stream);
 int tln_fine_to_coarse_table(tln_lattice_t* coarse, const int32_t** d_table_out, void* stream);

@@ -72,6 +72,9 @@ _PROTOS = {
     "tln_neighbour_table": (_i, [_vp, C.POINTER(_vp), _vp]),
     "tln_coarsen": (_i, [_vp, C.POINTER(_vp), _vp]),
     "tln_lattice_prepare_levels": (_i, [_vp, _i, _vp]),
+    "tln_lattice_prepare_levels_begin": (_i, [_vp, _i, C.POINTER(_i64), _vp]),
+    "tln_lattice_prepare_levels_finish": (_i, [_vp, _vp]),
+    "tln_lattice_coarse_level": (_vp, [_vp]),
     "tln_coarse_to_fine_table": (_i, [_vp, C.POINTER(_vp), _vp]),
     "tln_fine_to_coarse_table": (_i, [_vp, C.POINTER(_vp), _vp]),
     "tln_gather_gemm": (_i, [_i64, _i, C.POINTER(GemmSrc), C.POINTER(GemmSrc), _vp, _i, _vp, _vp, _i64, _i, _vp, _i64, _vp]),

@@ -54,6 +54,9 @@ struct tln_lattice {
   int32_t* f2c = nullptr;
   int64_t f2c_vc = -1, f2c_vf = -1;
   int64_t embedded_fine = 0;
+  // tln_lattice_prepare_levels_begin without its _finish yet: coarse counters are in flight (root level only)
+  int levels_pending = 0;
+  hipEvent_t levels_event = nullptr;
   // per-call row workspace
   int64_t rows_cap = 0;
   int32_t* row_slot = nullptr;
@@ -1356,8 +1359,18 @@ extern "C" int tln_neighbour_table(tln_lattice_t* l, const int32_t** d_table_out
   return TLN_OK;
 }
 
+static int finish_pending(tln_lattice* l, void* stream_) {
+  tln_lattice* root = l;
+  while (root->parent) root = root->parent;
+  return root->levels_pending ? tln_lattice_prepare_levels_finish(root, stream_) : TLN_OK;
+}
+
 extern "C" int tln_coarsen(tln_lattice_t* fine, tln_lattice_t** coarse_out, void* stream_) {
   TLN_REQUIRE(fine && coarse_out, "null argument");
+  {
+    int rc = finish_pending(fine, stream_);
+    if (rc) return rc;
+  }
   hipStream_t s = (hipStream_t)stream_;
   if (!fine->coarse) {
     double sg[3] = {fine->sigmas[0] * 2, fine->sigmas[1] * 2, fine->sigmas[2] * 2};
@@ -1425,6 +1438,10 @@ static int coarsen_deferred(tln_lattice* fine, int64_t fine_bound, hipStream_t s
 
 extern "C" int tln_coarse_to_fine_table(tln_lattice_t* c, const int32_t** d_table_out, void* stream_) {
   TLN_REQUIRE(c && c->parent && d_table_out, "not a coarse level");
+  {
+    int rc = finish_pending(c, stream_);
+    if (rc) return rc;
+  }
   tln_lattice* f = c->parent;
   int rc = ensure_table(&c->c2f, c->capacity);
   if (rc) return rc;
@@ -1442,6 +1459,10 @@ extern "C" int tln_coarse_to_fine_table(tln_lattice_t* c, const int32_t** d_tabl
 
 extern "C" int tln_fine_to_coarse_table(tln_lattice_t* c, const int32_t** d_table_out, void* stream_) {
   TLN_REQUIRE(c && c->parent && d_table_out, "not a coarse level");
+  {
+    int rc = finish_pending(c, stream_);
+    if (rc) return rc;
+  }
   tln_lattice* f = c->parent;
   int rc = ensure_table(&c->f2c, f->capacity);
   if (rc) return rc;
@@ -1460,26 +1481,57 @@ extern "C" int tln_fine_to_coarse_table(tln_lattice_t* c, const int32_t** d_tabl
 // Build the coarse levels and every stale table of the stack in as few launches as possible: per coarse level one
 // insertion + one numbering launch and one counter read-back, then ONE launch for all neighbour / cross-level
 // tables.  Called once per frame right after tln_distribute; the per-table getters then only return pointers.
-extern "C" int tln_lattice_prepare_levels(tln_lattice_t* l0, int nr_coarse_levels, void* stream_) {
+// prepare_levels in two halves so that a caller can launch work that only needs level 0 while the coarse levels'
+// vertex counts are still on their way to the host:
+//   _begin   extends every coarse level (no host round trip in between), starts ONE asynchronous fetch of all their
+//            counters, records an event, builds the level-0 neighbour table; v_bound_out[0] = V0 (exact),
+//            v_bound_out[i] >= the new vertex count of level i
+//   _finish  waits for that event (not for the stream), publishes the exact counts, builds the coarse tables
+extern "C" int tln_lattice_prepare_levels_begin(tln_lattice_t* l0, int nr_coarse_levels, int64_t* v_bound_out,
+                                                void* stream_) {
   TLN_REQUIRE(l0 && nr_coarse_levels >= 0 && nr_coarse_levels <= 3, "bad prepare_levels arguments");
+  TLN_REQUIRE(!l0->parent, "prepare_levels wants the finest level");
   hipStream_t s = (hipStream_t)stream_;
-  // every coarse level extended without a host round trip in between, then ONE fetch of all their counters
-  {
-    tln_lattice* lv = l0;
-    int64_t bound = l0->nr_vertices;                       // exact
-    int64_t growth = l0->nr_vertices - (l0->coarse ? l0->coarse->embedded_fine : 0);
-    for (int i = 0; i < nr_coarse_levels; ++i) {
-      int rc = coarsen_deferred(lv, bound, s);
-      if (rc) return rc;
-      tln_lattice* c = lv->coarse;
-      if (growth < 0) growth = 0;
-      growth *= 4;                                         // a fine vertex touches at most 4 coarse vertices
-      bound = c->nr_vertices + growth;                     // >= the coarse level's new count
-      lv = c;
-    }
-    for (tln_lattice* c = l0->coarse; c; c = c->coarse)
-      TLN_HIP(hipMemcpyAsync(c->h_ctr, c->d_ctr, CTR_COUNT * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    TLN_HIP(hipStreamSynchronize(s));
+  if (l0->levels_pending) {
+    int rc = tln_lattice_prepare_levels_finish(l0, stream_);
+    if (rc) return rc;
+  }
+  if (v_bound_out) v_bound_out[0] = l0->nr_vertices;
+  tln_lattice* lv = l0;
+  int64_t bound = l0->nr_vertices;                       // exact
+  int64_t growth = l0->nr_vertices - (l0->coarse ? l0->coarse->embedded_fine : 0);
+  for (int i = 0; i < nr_coarse_levels; ++i) {
+    int rc = coarsen_deferred(lv, bound, s);
+    if (rc) return rc;
+    tln_lattice* c = lv->coarse;
+    if (growth < 0) growth = 0;
+    growth *= 4;                                         // a fine vertex touches at most 4 coarse vertices
+    bound = c->nr_vertices + growth;                     // >= the coarse level's new count
+    if (bound > c->capacity) bound = c->capacity;
+    if (v_bound_out) v_bound_out[i + 1] = bound;
+    lv = c;
+  }
+  for (tln_lattice* c = l0->coarse; c; c = c->coarse)
+    TLN_HIP(hipMemcpyAsync(c->h_ctr, c->d_ctr, CTR_COUNT * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  if (!l0->levels_event) TLN_HIP(hipEventCreateWithFlags(&l0->levels_event, hipEventDisableTiming));
+  TLN_HIP(hipEventRecord(l0->levels_event, s));
+  l0->levels_pending = nr_coarse_levels > 0 ? nr_coarse_levels : -1;   // -1: nothing to wait for, tables only
+  if (l0->nr_vertices > 0) {
+    const int32_t* unused = nullptr;
+    int rc = tln_neighbour_table(l0, &unused, stream_);
+    if (rc) return rc;
+  }
+  return TLN_OK;
+}
+
+extern "C" int tln_lattice_prepare_levels_finish(tln_lattice_t* l0, void* stream_) {
+  TLN_REQUIRE(l0 && !l0->parent, "prepare_levels wants the finest level");
+  if (!l0->levels_pending) return TLN_OK;
+  hipStream_t s = (hipStream_t)stream_;
+  const int nr_coarse_levels = l0->levels_pending > 0 ? l0->levels_pending : 0;
+  l0->levels_pending = 0;
+  if (nr_coarse_levels > 0) {
+    TLN_HIP(hipEventSynchronize(l0->levels_event));
     int lvl = 0;
     for (tln_lattice* c = l0->coarse; c && lvl < nr_coarse_levels; c = c->coarse, ++lvl) {
       c->nr_vertices = c->h_ctr[CTR_NV];
@@ -1536,3 +1588,12 @@ extern "C" int tln_lattice_prepare_levels(tln_lattice_t* l0, int nr_coarse_level
   }
   return TLN_OK;
 }
+
+extern "C" int tln_lattice_prepare_levels(tln_lattice_t* l0, int nr_coarse_levels, void* stream_) {
+  int rc = tln_lattice_prepare_levels_begin(l0, nr_coarse_levels, nullptr, stream_);
+  if (rc) return rc;
+  return tln_lattice_prepare_levels_finish(l0, stream_);
+}
+
+// the coarse level of `l` as it stands (NULL if none yet); no side effects
+extern "C" tln_lattice_t* tln_lattice_coarse_level(tln_lattice_t* l) { return l ? l->coarse : nullptr; }

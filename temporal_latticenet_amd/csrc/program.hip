@@ -111,8 +111,10 @@ struct GemmCall {
 
 struct SlotRt {
   bool live = false;
-  size_t off = 0, bytes = 0;
-  int64_t rows = 0;
+  size_t off = 0, bytes = 0;   // bytes: reserved from the UPPER BOUND of the row count (same in the sizing and the
+                               // launching pass, so both passes place every slot identically)
+  int64_t rows = 0;            // exact row count in the launching pass
+  int64_t rows_b = 0;          // upper bound
   char* ptr = nullptr;  // resolved device pointer (real pass)
 };
 
@@ -132,7 +134,10 @@ struct tln_program {
   // frame state
   tln_lattice_t* lat = nullptr;
   tln_lattice_t* levels[TLN_MAX_LEVELS] = {nullptr};
-  int64_t V[TLN_MAX_LEVELS] = {0};
+  int64_t V[TLN_MAX_LEVELS] = {0};   // exact vertex counts (coarse levels: valid once the pending fetch is finished)
+  int64_t Vb[TLN_MAX_LEVELS] = {0};  // upper bounds, known right after tln_program_begin_frame
+  bool exact_known = false;          // V[1..] hold the exact counts
+  int split = 0;                     // ops [0, split) only touch level 0: launched before the coarse counts arrive
   int64_t N = 0;
   int dist_cols = 0;
   bool frame_open = false;
@@ -145,13 +150,17 @@ struct tln_program {
   std::vector<SlotRt> rt;
   bool capture = false;
   std::vector<GemmCall> calls;
+  // state of a walk that is split in two (prefix, rest)
+  bool w_wrote[TLN_MAX_STATES] = {false};
+  int64_t w_new_rows[TLN_MAX_STATES] = {0};
+  bool w_finished = false;
 };
 
 namespace {
 
-int64_t slot_rows(const tln_program* p, const tln_slot& s) {
+int64_t slot_rows(const tln_program* p, const tln_slot& s, bool bound) {
   if (s.kind == TLN_SLOT_STATE_PREV) return p->state_rows[s.state];
-  if (s.rows >= 0) return p->V[s.rows];
+  if (s.rows >= 0) return (bound || (s.rows > 0 && !p->exact_known)) ? p->Vb[s.rows] : p->V[s.rows];
   if (s.rows == TLN_ROWS_POINTS) return p->N;
   if (s.rows == TLN_ROWS_POINT_ROWS) return 4 * p->N;
   return p->state_rows[TLN_ROWS_STATE - s.rows];
@@ -183,14 +192,21 @@ void for_outputs(const tln_op& o, F f) {
 }
 
 // One walk over the op list.  dry: only the arena bookkeeping (to size the arena); else launch.
-int walk(tln_program* p, bool dry, int early, float* d_out, int64_t out_rows, int out_cols, hipStream_t s) {
-  const int n_ops = (int)p->ops.size();
-  p->alloc.reset();
-  for (auto& r : p->rt) r = SlotRt();
-  bool wrote[TLN_MAX_STATES] = {false};
-  int64_t new_rows[TLN_MAX_STATES] = {0};
+int walk(tln_program* p, bool dry, int early, float* d_out, int64_t out_rows, int out_cols, hipStream_t s,
+         int op_begin, int op_end, bool fresh) {
+  if (fresh) {
+    p->alloc.reset();
+    for (auto& r : p->rt) r = SlotRt();
+    for (int st = 0; st < TLN_MAX_STATES; ++st) {
+      p->w_wrote[st] = false;
+      p->w_new_rows[st] = 0;
+    }
+    p->w_finished = false;
+  }
+  bool* wrote = p->w_wrote;
+  int64_t* new_rows = p->w_new_rows;
   char* base = reinterpret_cast<char*>(p->arena.p);
-  bool finished = false;
+  bool& finished = p->w_finished;
 
   auto tmp_alloc = [&](size_t bytes, size_t* off) {
     *off = p->alloc.alloc(bytes);
@@ -202,8 +218,9 @@ int walk(tln_program* p, bool dry, int early, float* d_out, int64_t out_rows, in
     const tln_slot& sl = p->slots[id];
     SlotRt& r = p->rt[id];
     if (r.live) return TLN_OK;
-    r.rows = slot_rows(p, sl);
-    r.bytes = slot_bytes(sl, r.rows);
+    r.rows_b = slot_rows(p, sl, true);
+    r.rows = dry ? r.rows_b : slot_rows(p, sl, false);
+    r.bytes = slot_bytes(sl, r.rows_b);
     if (sl.kind == TLN_SLOT_STATE_NEW) {
       const int st = sl.state;
       if (!dry) {
@@ -236,7 +253,7 @@ int walk(tln_program* p, bool dry, int early, float* d_out, int64_t out_rows, in
     SlotRt& r = p->rt[id];
     if (sl.kind == TLN_SLOT_STATE_PREV) {
       TLN_REQUIRE(p->state_has[sl.state], "op reads hidden state %d before it exists", sl.state);
-      r.rows = p->state_rows[sl.state];
+      r.rows = r.rows_b = p->state_rows[sl.state];
       r.bytes = slot_bytes(sl, r.rows);
       r.ptr = reinterpret_cast<char*>(p->state_buf[sl.state][p->state_cur[sl.state]].p);
       r.live = true;
@@ -248,7 +265,7 @@ int walk(tln_program* p, bool dry, int early, float* d_out, int64_t out_rows, in
 
   auto fptr = [&](int id) { return reinterpret_cast<float*>(p->rt[id].ptr); };
 
-  for (int oi = 0; oi < n_ops && !finished; ++oi) {
+  for (int oi = op_begin; oi < op_end && !finished; ++oi) {
     const tln_op& o = p->ops[oi];
     if (!cond_ok(p, o)) continue;
     int rc = TLN_OK;
@@ -348,7 +365,7 @@ int walk(tln_program* p, bool dry, int early, float* d_out, int64_t out_rows, in
       case TLN_OP_GRU: {
         const int64_t Vr = p->rt[o.out].rows;
         const int Cn = p->slots[o.out].cols;
-        want_scratch(0, (size_t)Vr * 6 * Cn * sizeof(float));
+        want_scratch(0, (size_t)p->rt[o.out].rows_b * 6 * Cn * sizeof(float));
         if (dry) break;
         rc = tln_gru_cell(fptr(o.s0.slot), fptr(o.s1.slot), Vr, p->rt[o.s1.slot].rows, Cn, o.p[0], o.p[1], o.p[2], o.p[3],
                           fptr(o.out), reinterpret_cast<float*>(scratch[0]), Vr * 6 * Cn, s);
@@ -358,8 +375,8 @@ int walk(tln_program* p, bool dry, int early, float* d_out, int64_t out_rows, in
       case TLN_OP_AFLOW: {
         const int64_t Vr = p->rt[o.out].rows;
         const int Cn = p->slots[o.out].cols;
-        want_scratch(0, (size_t)Vr * TLN_TAPS * sizeof(float));
-        want_scratch(1, (size_t)Vr * TLN_TAPS * sizeof(int32_t));
+        want_scratch(0, (size_t)p->rt[o.out].rows_b * TLN_TAPS * sizeof(float));
+        want_scratch(1, (size_t)p->rt[o.out].rows_b * TLN_TAPS * sizeof(int32_t));
         if (dry) break;
         const int32_t* tp = nullptr;
         TLN_REQUIRE(p->levels[o.s0.level], "op %d: level %d does not exist", oi, o.s0.level);
@@ -485,15 +502,17 @@ int walk(tln_program* p, bool dry, int early, float* d_out, int64_t out_rows, in
     for_inputs(o, drop);
     for_outputs(o, drop);
   }
-  if (!dry) {
-    for (int st = 0; st < p->n_states; ++st)
-      if (wrote[st]) {
-        p->state_cur[st] = 1 - p->state_cur[st];
-        p->state_rows[st] = new_rows[st];
-        p->state_has[st] = true;
-      }
-  }
   return TLN_OK;
+}
+
+// the frame that wrote a hidden state is over: the new buffer becomes the stored one
+void commit_states(tln_program* p) {
+  for (int st = 0; st < p->n_states; ++st)
+    if (p->w_wrote[st]) {
+      p->state_cur[st] = 1 - p->state_cur[st];
+      p->state_rows[st] = p->w_new_rows[st];
+      p->state_has[st] = true;
+    }
 }
 
 }  // namespace
@@ -535,6 +554,36 @@ extern "C" int tln_program_create(tln_program_t** out, const tln_slot* slots, in
     if (!ok) return fail("slot id out of range", oi);
     if (o.cond_state >= n_states) return fail("bad condition state", oi);
     if (o.kind == TLN_OP_GEMM && (!o.w || o.n <= 0 || o.s0.slot < 0)) return fail("incomplete GEMM", oi);
+  }
+  // ops [0, split) touch level 0 only (slots, hidden states and tables): they can be launched before the coarse levels'
+  // vertex counts are known on the host
+  {
+    int state_level[TLN_MAX_STATES];
+    for (int st = 0; st < TLN_MAX_STATES; ++st) state_level[st] = 0;
+    for (const tln_slot& sl : p->slots)
+      if (sl.kind == TLN_SLOT_STATE_NEW && sl.rows >= 0) state_level[sl.state] = sl.rows;
+    auto slot_coarse = [&](int id) {
+      if (id < 0) return false;
+      const tln_slot& sl = p->slots[id];
+      if (sl.kind == TLN_SLOT_STATE_PREV || sl.kind == TLN_SLOT_STATE_NEW) return state_level[sl.state] > 0;
+      if (sl.rows > 0) return true;
+      if (sl.rows <= TLN_ROWS_STATE) return state_level[TLN_ROWS_STATE - sl.rows] > 0;
+      return false;
+    };
+    p->split = n_ops;
+    for (int oi = 0; oi < n_ops; ++oi) {
+      const tln_op& o = p->ops[oi];
+      bool coarse = slot_coarse(o.out) || slot_coarse(o.stats_out) || slot_coarse(o.s0.slot) || slot_coarse(o.s1.slot) ||
+                    slot_coarse(o.s0.gn_stats) || slot_coarse(o.residual);
+      if (o.s0.slot >= 0 && o.s0.table != TLN_TABLE_NONE && o.s0.level > 0) coarse = true;
+      if (o.s1.slot >= 0 && o.s1.table != TLN_TABLE_NONE && o.s1.level > 0) coarse = true;
+      if (o.kind == TLN_OP_AFLOW && o.s0.level > 0) coarse = true;
+      if (o.kind == TLN_OP_CGA_GATE && state_level[o.i[0]] > 0) coarse = true;
+      if (coarse) {
+        p->split = oi;
+        break;
+      }
+    }
   }
   *out = p;
   return TLN_OK;
@@ -581,22 +630,21 @@ extern "C" int tln_program_begin_frame(tln_program_t* p, tln_lattice_t* l, const
   }
   rc = tln_distribute(l, d_positions, d_values, n, val_dim, subtract_mean, p->d_dist, p->d_idx, p->d_w, s);
   if (rc) return rc;
-  rc = tln_lattice_prepare_levels(l, p->n_coarse, s);
+  int64_t vb[TLN_MAX_LEVELS] = {0};
+  rc = tln_lattice_prepare_levels_begin(l, p->n_coarse, vb, s);   // coarse counts stay in flight until tln_program_run
   if (rc) return rc;
   p->lat = l;
   p->N = n;
   p->dist_cols = cols;
+  p->exact_known = p->n_coarse == 0;
   tln_lattice_t* lv = l;
   for (int i = 0; i <= p->n_coarse; ++i) {
+    TLN_REQUIRE(lv, "level %d does not exist", i);
     p->levels[i] = lv;
-    p->V[i] = tln_lattice_nr_vertices(lv);
-    v_out[i] = p->V[i];
-    if (i < p->n_coarse) {
-      tln_lattice_t* c = nullptr;
-      rc = tln_coarsen(lv, &c, s);
-      if (rc) return rc;
-      lv = c;
-    }
+    p->Vb[i] = vb[i];
+    p->V[i] = i == 0 ? vb[0] : -1;
+    v_out[i] = vb[i];   // level 0 exact; coarse levels: upper bounds (the exact counts follow in tln_program_run)
+    lv = tln_lattice_coarse_level(lv);
   }
   p->frame_open = true;
   return TLN_OK;
@@ -606,12 +654,28 @@ extern "C" int tln_program_run(tln_program_t* p, int early, float* d_out, int64_
                                void* stream_) {
   TLN_REQUIRE(p && p->frame_open, "tln_program_run without tln_program_begin_frame");
   hipStream_t s = (hipStream_t)stream_;
-  int rc = walk(p, true, early, nullptr, out_rows, out_cols, s);
+  const int n_ops = (int)p->ops.size();
+  // sizing pass over the whole op list with the upper bounds of the coarse vertex counts
+  int rc = walk(p, true, early, nullptr, out_rows, out_cols, s, 0, n_ops, true);
   if (rc) return rc;
   rc = ensure_buf(p->arena, p->alloc.high + kAlign, s);
   if (rc) return rc;
   p->calls.clear();
-  rc = walk(p, false, early, d_out, out_rows, out_cols, s);
+  // level-0 prefix: on the GPU while the coarse counts are still travelling to the host
+  rc = walk(p, false, early, d_out, out_rows, out_cols, s, 0, p->split, true);
+  // the exact coarse counts (waits for the fetch only) and the coarse tables
+  int rc2 = tln_lattice_prepare_levels_finish(p->lat, s);
+  if (rc == TLN_OK) rc = rc2;
+  if (rc == TLN_OK) {
+    for (int i = 1; i <= p->n_coarse; ++i) {
+      p->V[i] = tln_lattice_nr_vertices(p->levels[i]);
+      TLN_REQUIRE(p->V[i] <= p->Vb[i], "level %d has %lld vertices, more than the bound %lld", i, (long long)p->V[i],
+                  (long long)p->Vb[i]);
+    }
+    p->exact_known = true;
+    if (!p->w_finished) rc = walk(p, false, early, d_out, out_rows, out_cols, s, p->split, n_ops, false);
+  }
+  if (rc == TLN_OK) commit_states(p);
   p->frame_open = false;
   return rc;
 }
