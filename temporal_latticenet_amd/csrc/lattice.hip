@@ -186,6 +186,10 @@ __global__ void __launch_bounds__(256) k_clear_levels(ClearJobs jobs) {
 
 extern "C" int tln_lattice_clear(tln_lattice_t* l, void* stream_) {
   hipStream_t s = (hipStream_t)stream_;
+  if (l->levels_pending) {  // a fetch of coarse counters is in flight: let it land before the counters are reset
+    if (l->levels_pending > 0 && l->levels_event) TLN_HIP(hipEventSynchronize(l->levels_event));
+    l->levels_pending = 0;
+  }
   ClearJobs jobs{};
   for (tln_lattice* p = l; p; p = p->coarse) {
     if (jobs.n == 4) {  // deeper chains than the kernel takes at once
@@ -222,6 +226,10 @@ extern "C" int tln_lattice_create(tln_lattice_t** out, int pos_dim, const double
 }
 
 extern "C" int tln_lattice_destroy(tln_lattice_t* l) {
+  if (l && l->levels_event) {
+    (void)hipEventDestroy(l->levels_event);
+    l->levels_event = nullptr;
+  }
   if (!l) return TLN_OK;
   if (l->coarse) tln_lattice_destroy(l->coarse);
   void* ptrs[] = {l->slot_key, l->slot_val, l->slot_touch, l->vkeys, l->d_ctr, l->nbr, l->c2f, l->f2c,
