@@ -104,9 +104,9 @@ def gather_gemm(M, weight, s0, s1=None, w_is_nk=False, bias=None, residual=None,
         V, Cn = x.shape
         d = _lib.GnDesc()
         part = getattr(x, "_tln_stats", None)
-        # scale/shift scratch is only needed when the partial sums are too large for the in-kernel finalise
-        keep = torch.empty((2, Cn), dtype=torch.float32, device=weight.device) \
-            if (((V + 31) // 32) * Cn * 16 > (512 << 10) or Cn % 4) else None
+        # scale/shift scratch for the cases the in-kernel finalise does not take (partial sums too large to be re-read
+        # by every block, or a shape without 16-byte rows: the library decides)
+        keep = torch.empty((2, Cn), dtype=torch.float32, device=weight.device)
         if part is not None and tuple(part.shape) == ((V + 31) // 32, Cn, 2):
             d.d_partials = part.data_ptr()
         else:

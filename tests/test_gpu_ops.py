@@ -295,3 +295,61 @@ def test_slice_deform_matches_the_unfused_chain(gpu):
     delta = torch.nn.functional.linear(torch.relu(torch.nn.functional.linear(gth, Wp)), Wd, bd)
     want = O.slice_blend(scores, oi, ow, delta) + bias
     np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_direct_and_tiled_gemm_agree_on_random_shapes(gpu):
+    """the small-M direct kernel (one wave per 32x32 tile and K subset) against the LDS-tiled kernel on the same
+    calls: ragged M and N, one and two sources, both weight layouts, every number of waves per tile, GroupNorm
+    prologue from partial sums, bias / residual / ReLU, statistics output, padded hidden-state rows"""
+    from temporal_latticenet_amd import _lib, ops
+    lib = _lib.lib()
+    lat, tab, _, _ = _lattice(gpu, 15000, 0.45)
+    V = lat.nr_lattice_vertices()
+    rng = np.random.default_rng(12)
+    g = torch.Generator().manual_seed(12)
+    for case in range(24):
+        cin = int(rng.choice([32, 64, 96, 128, 192, 256]))
+        N = int(rng.choice([4, 8, 26, 32, 48, 64, 100, 192, 256]))
+        taps = 9 if rng.random() < 0.6 else 1
+        M = V if taps == 9 else int(rng.integers(1, V + 1))
+        two = taps == 1 and rng.random() < 0.4
+        nk = taps == 1 and rng.random() < 0.6
+        relu, use_bias, use_res, use_gn = (rng.random() < 0.5 for _ in range(4))
+        groups = int(rng.choice([0, 1, 2, 3, 5, 8, 12]))
+        x = torch.randn(V, cin, generator=g).to(gpu)
+        src_rows = int(rng.integers(M // 2 + 1, M + 1)) if taps == 1 else V
+        K = taps * cin + (cin if two else 0)
+        W = (torch.randn((N, K) if nk else (K, N), generator=g) / np.sqrt(K)).to(gpu)
+        bias = torch.randn(N, generator=g).to(gpu) if use_bias else None
+        res = torch.randn(M, N, generator=g).to(gpu) if use_res else None
+        norm = torch.nn.GroupNorm(32, cin).to(gpu)
+        with torch.no_grad():
+            norm.weight.uniform_(0.5, 1.5)
+            norm.bias.normal_(0, 0.2)
+        xs = ops.gather_gemm(V, torch.eye(cin, device=gpu), ops.gemm_src(x), stats=True)      # x with partial sums
+        y = torch.randn(M, cin, generator=g).to(gpu) if two else None
+
+        def call():
+            s0 = ops.gemm_src(xs, lat.neighbour_table_ptr() if taps == 9 else None, taps,
+                              src_rows=src_rows if not use_gn else None, pad_value=-3.0)
+            s1 = ops.gemm_src(y) if two else None
+            return ops.gather_gemm(M, W, s0, s1, w_is_nk=nk, bias=bias, residual=res, relu=relu, stats=True,
+                                   gn=(xs, norm, True) if use_gn else None)
+
+        lib.tln_gemm_force_direct(1)
+        lib.tln_gemm_force_groups(groups)
+        try:
+            a = call()
+        finally:
+            lib.tln_gemm_force_groups(0)
+        lib.tln_gemm_force_direct(-1)
+        try:
+            b = call()
+        finally:
+            lib.tln_gemm_force_direct(0)
+        scale = max(1.0, float(b.abs().max()))
+        err = float((a - b).abs().max())
+        assert err <= 2e-5 * scale, "case %d (cin %d, N %d, taps %d, M %d, two %s, nk %s, groups %d): %.3e" % (
+            case, cin, N, taps, M, two, nk, groups, err)
+        sa, sb = a._tln_stats.cpu().numpy(), b._tln_stats.cpu().numpy()
+        np.testing.assert_allclose(sa, sb, rtol=1e-4, atol=1e-3 * scale * scale)
