@@ -142,3 +142,28 @@ def test_insert_keys_matches_distribute_numbering(gpu):
     idx = lat2.insert_keys(keys)
     assert np.array_equal(idx.cpu().numpy(), np.arange(keys.shape[0], dtype=np.int32))
     assert np.array_equal(lat2.keys().cpu().numpy(), keys.cpu().numpy())
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 63, 64, 65, 257, 1000])
+def test_distribute_fuzz_ragged_sizes_and_scales(gpu, n):
+    """clouds of a few points up to a few waves, coordinates from centimetres to hundreds of metres (both signs),
+    coarse and fine lattices, duplicated points, two frames (the second one appends): indices, weights and the CSR
+    bit-exact, the mean-subtracted rows within float rounding"""
+    from temporal_latticenet_amd.lattice import Lattice
+    rng = np.random.default_rng(1000 + n)
+    for spread, sigma in [(0.05, 0.05), (1.0, 0.5), (30.0, 0.5), (300.0, 3.0), (2.0, 50.0)]:
+        lat = Lattice.from_params([sigma] * 3, 1 << 16)
+        tab = P.VertexTable(3, 1 << 16)
+        for t in range(2):
+            pos = (rng.standard_normal((n, 3)) * spread + rng.standard_normal(3) * spread).astype(np.float32)
+            if n > 4:
+                pos[n // 2] = pos[0]                       # an exact duplicate
+            val = rng.random((n, 1)).astype(np.float32)
+            d, i, w = lat.distribute(torch.from_numpy(pos).to(gpu), torch.from_numpy(val).to(gpu), reset_hashmap=(t == 0))
+            od, oi, ow = O.distribute(tab, pos, val, [sigma] * 3, True)
+            assert np.array_equal(i.cpu().numpy(), oi), (n, spread, sigma, t)
+            assert np.array_equal(w.cpu().numpy(), ow), (n, spread, sigma, t)
+            np.testing.assert_allclose(d.cpu().numpy(), od, rtol=0, atol=1e-5 * max(1.0, spread))
+            assert lat.nr_lattice_vertices() == tab.nr_vertices
+            _check_csr(lat, oi)
+        assert np.array_equal(lat.keys().cpu().numpy(), tab.keys)
