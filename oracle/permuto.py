@@ -108,7 +108,7 @@ KEY_BIAS = 1 << 20
 def pack_keys(keys):
     """[...,3] i32 -> [...] i64 (21 bits per coordinate, biased). d=3 only."""
     k = keys.astype(np.int64) + KEY_BIAS
-    assert k.min() >= 0 and k.max() < (1 << 21), "key out of the 21-bit range"
+    assert k.size == 0 or (k.min() >= 0 and k.max() < (1 << 21)), "key out of the 21-bit range"
     return (k[..., 0] << 42) | (k[..., 1] << 21) | k[..., 2]
 
 

@@ -167,3 +167,33 @@ def test_distribute_fuzz_ragged_sizes_and_scales(gpu, n):
             assert lat.nr_lattice_vertices() == tab.nr_vertices
             _check_csr(lat, oi)
         assert np.array_equal(lat.keys().cpu().numpy(), tab.keys)
+
+
+@pytest.mark.parametrize("n,spread,sigma", [(1, 1.0, 0.5), (7, 3.0, 0.3), (65, 40.0, 0.5), (900, 200.0, 1.0),
+                                            (3000, 5.0, 0.1), (3000, 0.5, 2.0)])
+def test_coarse_levels_and_tables_fuzz(gpu, n, spread, sigma):
+    """three levels over two frames of random clouds whose keys span both signs: keys, the 9-tap tables of every
+    level and both cross-level tables bit-exact"""
+    from temporal_latticenet_amd.lattice import Lattice
+    rng = np.random.default_rng(7 * n + 1)
+    lat = Lattice.from_params([sigma] * 3, 1 << 16)
+    tabs = [P.VertexTable(3, 1 << 16) for _ in range(3)]
+    seen = [0, 0, 0]
+    for t in range(2):
+        pos = (rng.standard_normal((n, 3)) * spread - spread * t).astype(np.float32)
+        val = rng.random((n, 1)).astype(np.float32)
+        lat.distribute(torch.from_numpy(pos).to(gpu), torch.from_numpy(val).to(gpu), reset_hashmap=(t == 0))
+        O.distribute(tabs[0], pos, val, [sigma] * 3)
+        for l in (1, 2):
+            P.coarsen_insert(tabs[l], tabs[l - 1].keys[seen[l - 1]:])
+        seen = [tb.nr_vertices for tb in tabs]
+        g = [lat, lat.coarsen()]
+        g.append(g[1].coarsen())
+        for l in range(3):
+            assert np.array_equal(g[l].keys().cpu().numpy(), tabs[l].keys), (t, l)
+            assert np.array_equal(g[l].neighbour_table().cpu().numpy(), P.neighbour_table(tabs[l])), (t, l)
+        for l in (1, 2):
+            want = tabs[l - 1].lookup(P.neighbour_keys(tabs[l].keys * 2))
+            assert np.array_equal(g[l].coarse_to_fine_table().cpu().numpy(), want), (t, l)
+            want = tabs[l].lookup(P.neighbour_keys(P.finefy_centres(tabs[l - 1].keys)))
+            assert np.array_equal(g[l].fine_to_coarse_table(tabs[l - 1].nr_vertices).cpu().numpy(), want), (t, l)
