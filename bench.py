@@ -41,8 +41,8 @@ FP32_MFMA_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: dense fp32 matrix peak
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--points", type=int, default=120000)
     ap.add_argument("--frames", type=int, default=4)
     ap.add_argument("--sigma", type=float, default=0.6)

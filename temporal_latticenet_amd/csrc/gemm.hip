@@ -1040,15 +1040,30 @@ extern "C" int tln_gather_gemm_ex(int64_t M, int N, const tln_gemm_src* s0, cons
     // enough waves to cover the SIMDs a few times over, 2..8 chunks per wave
     const int64_t tiles = tln_cdiv(M, 32) * tln_cdiv(N, 32);
     int G = g_force_groups ? g_force_groups : 1;
-    if (!g_force_groups) {
-      // waves per tile: the fewest chunks per wave (down to 2: both in flight before the first MFMA) that still keeps
-      // ALL blocks resident at once: 256 CUs x floor(12 / G) blocks (3 waves per SIMD at this kernel's VGPR count)
+    if (!g_force_groups && tiles <= 256) {
+      // at most one block per CU: the fewest chunks per wave (down to 2: both in flight before the first MFMA)
       int best_iters = nchunks;
       for (int cand = 2; cand <= 12; ++cand) {
         const int it = (nchunks + cand - 1) / cand;
-        if (it < 2 || tiles > (int64_t)256 * (12 / cand)) continue;
+        if (it < 2) continue;
         if (it < best_iters) {
           best_iters = it;
+          G = cand;
+        }
+      }
+    } else if (!g_force_groups) {
+      // several blocks per CU: the busiest SIMD decides.  A block's waves go round the 4 SIMDs, so it puts
+      // ceil(G/4) waves of `iters` chunks each on the busiest one; measured over G = 1..12 on the K-heavy level-0
+      // products (TLN_GEMM_DUMP=2) the launch time follows ceil(G/4) * blocks-per-CU * iters closely (G = 5..7 are
+      // the worst choices), ties go to the smaller block
+      const int64_t bpc = tln_cdiv(tiles, 256);
+      int64_t best = -1;
+      for (int cand = 1; cand <= 12; ++cand) {
+        const int it = (nchunks + cand - 1) / cand;
+        if (it < 2 && cand > 1) continue;
+        const int64_t cost = (int64_t)((cand + 3) / 4) * bpc * it;
+        if (best < 0 || cost < best) {
+          best = cost;
           G = cand;
         }
       }

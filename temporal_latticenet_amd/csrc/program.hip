@@ -718,6 +718,39 @@ extern "C" int tln_program_replay_gemms(tln_program_t* p, int reps, double* ms_t
     TLN_HIP(hipEventElapsedTime(&ms, e0, e1));
     *ms_total = ms;
   }
+  if (!rc && getenv("TLN_GEMM_DUMP")) {  // per-launch table for tools/: 20 back-to-back launches of each call
+    int idx = 0;
+    for (const GemmCall& c : p->calls) {
+      TLN_HIP(hipEventRecord(e0, s));
+      for (int r = 0; r < 20; ++r)
+        tln_gather_gemm_ex(c.M, c.N, &c.a[0], c.two ? &c.a[1] : nullptr, c.w, c.w_is_nk, c.bias, c.res, c.ld_res, c.relu,
+                           c.out, c.ld_out, c.stats, s);
+      TLN_HIP(hipEventRecord(e1, s));
+      TLN_HIP(hipEventSynchronize(e1));
+      float ms = 0.f;
+      TLN_HIP(hipEventElapsedTime(&ms, e0, e1));
+      const double K = (double)c.a[0].taps * c.a[0].cin + (c.two ? (double)c.a[1].taps * c.a[1].cin : 0.0);
+      fprintf(stderr, "gemm %2d M=%7ld N=%4d K=%5.0f taps=%d cin=%d two=%d gn=%d res=%d stats=%d  %.2f us  %.1f TF", idx++,
+              (long)c.M, c.N, K, c.a[0].taps, c.a[0].cin, (int)c.two, c.a[0].d_gn_partials ? 1 : 0, c.res ? 1 : 0,
+              c.stats ? 1 : 0, ms * 50.0, 2.0 * c.M * K * c.N / (ms * 50.0e-6) * 1e-12);
+      if (atoi(getenv("TLN_GEMM_DUMP")) >= 2) {  // the direct kernel over its waves-per-tile choices
+        fprintf(stderr, " | G:");
+        for (int G = 1; G <= 12; ++G) {
+          tln_gemm_force_groups(G);
+          TLN_HIP(hipEventRecord(e0, s));
+          for (int r = 0; r < 20; ++r)
+            tln_gather_gemm_ex(c.M, c.N, &c.a[0], c.two ? &c.a[1] : nullptr, c.w, c.w_is_nk, c.bias, c.res, c.ld_res,
+                               c.relu, c.out, c.ld_out, c.stats, s);
+          TLN_HIP(hipEventRecord(e1, s));
+          TLN_HIP(hipEventSynchronize(e1));
+          TLN_HIP(hipEventElapsedTime(&ms, e0, e1));
+          fprintf(stderr, " %d:%.1f", G, ms * 50.0);
+        }
+        tln_gemm_force_groups(0);
+      }
+      fprintf(stderr, "\n");
+    }
+  }
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   if (rc) return rc;

@@ -29,8 +29,8 @@ def test_concurrent_streams_equal_the_single_stream_results(gpu, frame_program):
     _alone(model, contents, seqs[0])
     randomize_parameters(model, seed=9)
     model.use_frame_program = frame_program
-    want = [_alone(model, contents, s) for s in seqs]
     pool = SequenceStreams(model, lambda: build_model(contents).eval(), lambda: make_lattice(contents), seqs[0], S)
+    want = [_alone(model, contents, s) for s in seqs]       # after the pool: same process-wide kernel choices
     for m in pool.models:
         m.use_frame_program = frame_program
     assert pool.models[1].point_net_seq.layers[0].weight is model.point_net_seq.layers[0].weight
@@ -41,3 +41,4 @@ def test_concurrent_streams_equal_the_single_stream_results(gpu, frame_program):
             assert torch.equal(got[i][1], want[S + i]), "stream %d, second sequence" % i
     if frame_program:
         assert all(getattr(m, "_program", None) is not None for m in pool.models)
+    pool.close()
