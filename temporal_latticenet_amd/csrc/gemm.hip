@@ -91,7 +91,7 @@ __global__ void __launch_bounds__(128 * WM * G) k_gather_gemm(const GemmArgs g) 
   const int tid = threadIdx.x % GT, grp = threadIdx.x / GT;
   float* As0 = smem + grp * GROUP_FLOATS;
   float* Bs0 = As0 + A_TILE;
-  int* Is = reinterpret_cast<int*>(smem + REGION);  // [BM][TLN_TAPS] tap indices of source 0, then 1 flag word
+  int* Is = reinterpret_cast<int*>(smem + REGION);  // [2][BM][TLN_TAPS] tap indices of both sources, then 1 flag word
 
   const int lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
@@ -121,16 +121,20 @@ __global__ void __launch_bounds__(128 * WM * G) k_gather_gemm(const GemmArgs g) 
 
   const bool stamp = g.dbg && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0;
   if (stamp) g.dbg[0] = __builtin_amdgcn_s_memtime();
-  if (g.s[0].table != nullptr) {
-    const int taps = g.s[0].taps;
+  // both tables go through LDS: a tap index fetched from global memory inside the K loop makes the compiler merge the
+  // LDS and the global alternative into one FLAT load with s_waitcnt vmcnt(0), draining the operand loads in flight
+  for (int si = 0; si < g.nsrc; ++si) {
+    const SrcDev& sd = si ? g.s[1] : g.s[0];
+    if (sd.table == nullptr) continue;
+    const int taps = sd.taps;
     for (int i = threadIdx.x; i < BM * taps; i += GT * G) {
       const int64_t m = m0 + i / taps;
-      Is[i] = (m < g.M) ? g.s[0].table[m * taps + (i % taps)] : -1;
+      Is[si * (BM * TLN_TAPS) + i] = (m < g.M) ? sd.table[m * taps + (i % taps)] : -1;
     }
   }
   // GroupNorm of source 0, finalised here: every block reduces the producer's per-32-row (sum, sumsq) partials in a
   // fixed order (deterministic) into per-channel scale/shift kept in LDS.  No separate statistics kernel.
-  float* Gsc = reinterpret_cast<float*>(Is + BM * TLN_TAPS + 4);
+  float* Gsc = reinterpret_cast<float*>(Is + 2 * BM * TLN_TAPS + 4);
   float* Gsh = Gsc + g.s[0].cin;
   const bool gn_lds = g.s[0].gn_part != nullptr;
   if (gn_lds) {
@@ -208,7 +212,7 @@ __global__ void __launch_bounds__(128 * WM * G) k_gather_gemm(const GemmArgs g) 
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (m < g.M && 4 * a_kq < kvalid) {
         int64_t srow = m;
-        if (s.table) srow = (si == 0) ? (int64_t)Is[rloc * s.taps + tap] : (int64_t)s.table[m * s.taps + tap];
+        if (s.table) srow = (int64_t)Is[si * (BM * TLN_TAPS) + rloc * s.taps + tap];
         if (srow >= 0) {
           if (srow >= s.src_rows) {
             v = make_float4(s.pad, s.pad, s.pad, s.pad);
@@ -408,7 +412,7 @@ __global__ void __launch_bounds__(128 * WM * G) k_gather_gemm(const GemmArgs g) 
         for (int r = 0; r < 16; ++r) mine[((i * TN + j) * 16 + r) * GT + tid] = acc[i][j][r];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    int* flag = Is + BM * TLN_TAPS;
+    int* flag = Is + 2 * BM * TLN_TAPS;
     if (tid == 0) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -492,7 +496,10 @@ template <bool W_NK>
 __global__ void __launch_bounds__(768) k_gather_gemm_direct(const GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int T = blockDim.x, G = T >> 6;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  // the wave index as a SCALAR: everything derived from it (chunk, tap, channel offset, K row, source selection) then
+  // lives in SGPRs, and the K loop is bound by the instructions a wave issues per chunk beside its 16 MFMAs (a knock-out
+  // of loads AND MFMAs left 3/4 of the loop time): operand addresses are scalar base + one per-lane offset
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int l31 = lane & 31, half = lane >> 5;
   const int64_t m0 = (int64_t)blockIdx.x * 32;
   const int n0 = blockIdx.y * 32;
@@ -532,12 +539,16 @@ __global__ void __launch_bounds__(768) k_gather_gemm_direct(const GemmArgs g) {
 
   // tap indices of the block's 32 rows (source 0): one contiguous 1152-byte span of the table -> LDS
   const int64_t mc = mrow ? m : g.M - 1;  // rows past M work on row M-1 (their outputs are never stored)
-  int* Is = reinterpret_cast<int*>(Gsh + cin0);
-  if (g.s[0].table != nullptr) {
+  // (both sources: a tap index fetched from global memory inside the K loop would make the compiler merge the two
+  // alternatives into one FLAT load followed by s_waitcnt vmcnt(0), which drains the prefetched operand loads)
+  int* Is = reinterpret_cast<int*>(Gsh + cin0);  // [2][32][TLN_TAPS]
+  const bool tab0 = g.s[0].table != nullptr, tab1 = g.nsrc > 1 && g.s[1].table != nullptr;
+  if (tab0 || tab1) {
     const int64_t lim = g.M * TLN_TAPS;
     for (int i = threadIdx.x; i < 32 * TLN_TAPS; i += T) {
       const int64_t at = m0 * TLN_TAPS + i;
-      Is[i] = at < lim ? g.s[0].table[at] : -1;
+      if (tab0) Is[i] = at < lim ? g.s[0].table[at] : -1;
+      if (tab1) Is[32 * TLN_TAPS + i] = at < lim ? g.s[1].table[at] : -1;
     }
     __syncthreads();
   }
@@ -551,47 +562,68 @@ __global__ void __launch_bounds__(768) k_gather_gemm_direct(const GemmArgs g) {
                                             // clamped and its A operand zeroed (adds exact zeros)
   const unsigned nc = (unsigned)(ncol ? n : g.N - 1);  // columns past N are computed on column N-1, never stored
 
+  const unsigned b_loff = 4u * ((unsigned)(16 * half) * (unsigned)g.ldw + nc);  // [K,N] weights: the lane's fixed byte offset
   f32x4 a[TLN_DIRECT_DEPTH][4];
   float b[TLN_DIRECT_DEPTH][16];
-  int meta[TLN_DIRECT_DEPTH];  // mode (0 zero row, 1 data, 2 pad) | source << 2 | c0 << 3
+  int mode_r[TLN_DIRECT_DEPTH];   // per lane: 0 zero row, 1 data, 2 pad
+  int smeta[TLN_DIRECT_DEPTH];    // wave-uniform: source | c0 << 1
 
-  // branch-free: every address is clamped into range, the mode decides afterwards what the values mean
-  auto load = [&](int t_raw, f32x4 (&av)[4], float (&bv)[16], int& mt) {
+  // rows as 32-bit numbers (the host checks src_rows, M < 2^31), the row offset as one 32 x 32 -> 64 multiply
+  const unsigned inv0 = (65536u + cpt0 - 1) / cpt0, inv1 = (65536u + cpt1 - 1) / cpt1;  // chunk -> tap without a division
+  const int mc32 = (int)mc;
+  const int rows0 = (int)g.s[0].src_rows, rows1 = g.nsrc > 1 ? (int)g.s[1].src_rows : 0;
+  const unsigned ld0 = (unsigned)g.s[0].ld, ld1 = g.nsrc > 1 ? (unsigned)g.s[1].ld : 0u;
+
+  // where chunk t lives: branch-free, every address is clamped into range, the mode decides afterwards what the
+  // values mean
+  struct Chunk {
+    const f32x4* ap;   // the lane's 16 channels of its gathered row
+    const char* wq;    // [K,N] weights: wave-uniform pointer to the chunk's first K row
+    const f32x4* wp;   // [N,K] weights: the lane's 16 K values of its column
+    int mode, sm;
+  };
+  auto locate = [&](int t_raw) {
+    Chunk c;
     const bool live = t_raw < nchunks;
     const int t = live ? t_raw : nchunks - 1;
     const int si = (t < nch0) ? 0 : 1;
     const float* src = si ? g.s[1].src : g.s[0].src;
-    const int32_t* table = si ? g.s[1].table : g.s[0].table;
-    const int64_t src_rows = si ? g.s[1].src_rows : g.s[0].src_rows;
-    const int64_t ld = si ? g.s[1].ld : g.s[0].ld;
+    const bool has_table = si ? tab1 : tab0;
+    const int src_rows = si ? rows1 : rows0;
+    const unsigned ld = si ? ld1 : ld0;
     const int cin = si ? g.s[1].cin : cin0;
     const int tt = si ? t - nch0 : t;
     const int cpt = si ? cpt1 : cpt0;
-    const int tap = tt / cpt;
+    const int tap = (int)(((unsigned)tt * (si ? inv1 : inv0)) >> 16);  // tt / cpt (exact for cpt <= 32, tt < 2048)
     const int c0 = (tt - tap * cpt) << 5;
     const int kb = (si ? g.K0 : 0) + tap * cin + c0;  // first K row of the chunk (wave-uniform)
-    int64_t srow = mc;
-    if (table != nullptr) {
-      srow = (si == 0) ? Is[l31 * TLN_TAPS + tap] : table[mc * TLN_TAPS + tap];
-    }
-    const int mode = (!live || srow < 0) ? 0 : (srow >= src_rows ? 2 : 1);
-    mt = mode | (si << 2) | (c0 << 3);
-    const int64_t sr = mode == 1 ? srow : 0;
-    const f32x4* ap = reinterpret_cast<const f32x4*>(src + sr * ld + c0 + 16 * half);
+    int srow = mc32;
+    if (has_table) srow = Is[si * (32 * TLN_TAPS) + l31 * TLN_TAPS + tap];
+    c.mode = (!live || srow < 0) ? 0 : (srow >= src_rows ? 2 : 1);
+    c.sm = si | (c0 << 1);
+    const unsigned sr = c.mode == 1 ? (unsigned)srow : 0u;
+    c.ap = reinterpret_cast<const f32x4*>(src + (uint64_t)sr * ld + (unsigned)(c0 + 16 * half));
+    c.wq = reinterpret_cast<const char*>(g.W + (int64_t)kb * g.ldw);
+    c.wp = reinterpret_cast<const f32x4*>(g.W + (int64_t)nc * g.ldw + kb + 16 * half);
+    return c;
+  };
+  // [K,N] weights: K row q of the chunk; the lane's part is a fixed 32-bit byte offset on a wave-uniform row pointer
+  auto load_b_kn = [&](const Chunk& c, int q) {
+    return *reinterpret_cast<const float*>(c.wq + (int64_t)q * g.ldw * 4 + b_loff);
+  };
+  auto load = [&](int t_raw, f32x4 (&av)[4], float (&bv)[16], int& md, int& sm) {
+    const Chunk c = locate(t_raw);
+    md = c.mode;
+    sm = c.sm;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) av[q] = ap[q];
+    for (int q = 0; q < 4; ++q) av[q] = c.ap[q];
     if (!W_NK) {
-      const unsigned loff = (unsigned)(16 * half) * (unsigned)g.ldw + nc;
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const float* wq = g.W + (int64_t)(kb + q) * g.ldw;
-        bv[q] = wq[loff];
-      }
+      for (int q = 0; q < 16; ++q) bv[q] = load_b_kn(c, q);
     } else {
-      const f32x4* wp = reinterpret_cast<const f32x4*>(g.W + (int64_t)nc * g.ldw + kb + 16 * half);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const f32x4 v = wp[q];
+        const f32x4 v = c.wp[q];
         bv[4 * q] = v[0];
         bv[4 * q + 1] = v[1];
         bv[4 * q + 2] = v[2];
@@ -606,10 +638,10 @@ __global__ void __launch_bounds__(768) k_gather_gemm_direct(const GemmArgs g) {
 
   const int relu0 = g.s[0].relu, relu1 = g.nsrc > 1 ? g.s[1].relu : 0;
   const float pad0 = g.s[0].pad, pad1 = g.nsrc > 1 ? g.s[1].pad : 0.f;
-  auto compute = [&](const f32x4 (&av)[4], const float (&bv)[16], int mt) {
-    const int mode = mt & 3, si = (mt >> 2) & 1, c0 = mt >> 3;
+  // the chunk's A operands: prologue (GroupNorm affine, ReLU) and the zero / pad rows
+  auto prepare = [&](const f32x4 (&av)[4], int mode, int sm, float (&x)[16]) {
+    const int si = sm & 1, c0 = sm >> 1;
     const int cb = c0 + 16 * half;
-    float x[16];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       x[4 * q] = av[q][0];
@@ -626,14 +658,48 @@ __global__ void __launch_bounds__(768) k_gather_gemm_direct(const GemmArgs g) {
         for (int e = 0; e < 4; ++e) x[4 * q + e] = fmaf(x[4 * q + e], sc[e], sh[e]);
       }
     }
-    // ReLU as max(x, floor): floor = 0 with the activation, -inf without (wave-uniform)
-    const float floor_v = (si ? relu1 : relu0) ? 0.f : -__builtin_inff();
+    // ReLU as ONE integer max on the bit pattern (sign bit set <=> negative as an integer; fmaxf costs a NaN
+    // canonicalisation in front of the max), wave-uniform
+    if (si ? relu1 : relu0) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) x[q] = __int_as_float(max(__float_as_int(x[q]), 0));
+    }
     // a missing neighbour stays an exact zero row, a row past the source is the pad value (no activation)
     const float other = (mode == 2) ? (si ? pad1 : pad0) : 0.f;
+    const bool data = mode == 1;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) x[q] = (mode == 1) ? fmaxf(x[q], floor_v) : other;
+    for (int q = 0; q < 16; ++q) x[q] = data ? x[q] : other;
+  };
+  auto compute = [&](const f32x4 (&av)[4], const float (&bv)[16], int mode, int sm) {
+    float x[16];
+    prepare(av, mode, sm, x);
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x[q], bv[q], acc, 0, 0, 0);
+  };
+  // compute the slot's chunk and refill the slot with chunk t_next on the way: the A registers are free once the
+  // operands are prepared, each B register once its MFMA has been issued, so the next loads go out BETWEEN the MFMAs
+  // of the chain instead of in an issue phase of their own (a lone wave spent as long there as in the chain)
+  auto step = [&](f32x4 (&av)[4], float (&bv)[16], int& md, int& sm, int t_next) {
+    float x[16];
+    prepare(av, md, sm, x);
+    const Chunk c = locate(t_next);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) av[q] = c.ap[q];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x[q], bv[q], acc, 0, 0, 0);
+      if (!W_NK) {
+        bv[q] = load_b_kn(c, q);
+      } else if ((q & 3) == 3) {
+        const f32x4 v = c.wp[q >> 2];
+        bv[q - 3] = v[0];
+        bv[q - 2] = v[1];
+        bv[q - 1] = v[2];
+        bv[q] = v[3];
+      }
+    }
+    md = c.mode;
+    sm = c.sm;
   };
 
   if (stamp) {
@@ -642,7 +708,7 @@ __global__ void __launch_bounds__(768) k_gather_gemm_direct(const GemmArgs g) {
   }
   // first chunks in flight before the GroupNorm finalise
 #pragma unroll
-  for (int d = 0; d < TLN_DIRECT_DEPTH; ++d) load(wv + d * G, a[d], b[d], meta[d]);
+  for (int d = 0; d < TLN_DIRECT_DEPTH; ++d) load(wv + d * G, a[d], b[d], mode_r[d], smeta[d]);
   if (stamp) g.dbg[6] = __builtin_amdgcn_s_memtime();
 
   if (gn_lds) {
@@ -670,6 +736,7 @@ __global__ void __launch_bounds__(768) k_gather_gemm_direct(const GemmArgs g) {
       Gp[idx] = make_double2(sx, sq);
     }
     __syncthreads();
+    if (stamp) g.dbg[7] = __builtin_amdgcn_s_memtime();
     // group statistics straight from the J x cin0 partials (every thread of a group repeats the group's sum: no
     // second LDS round, no second barrier), fixed order => deterministic
     const int cpg = cin0 / s.gn_groups;
@@ -703,18 +770,17 @@ __global__ void __launch_bounds__(768) k_gather_gemm_direct(const GemmArgs g) {
   }
   if (stamp) g.dbg[1] = __builtin_amdgcn_s_memtime();
 
-  // main loop: compute slot d, refill it DEPTH chunks ahead; then drain without loads
+  // main loop: compute slot d while refilling it DEPTH chunks ahead; then drain without loads
   int it = 0;
   for (; it + TLN_DIRECT_DEPTH < iters; it += TLN_DIRECT_DEPTH) {
 #pragma unroll
     for (int d = 0; d < TLN_DIRECT_DEPTH; ++d) {
-      compute(a[d], b[d], meta[d]);
-      load(wv + (it + d + TLN_DIRECT_DEPTH) * G, a[d], b[d], meta[d]);
+      step(a[d], b[d], mode_r[d], smeta[d], wv + (it + d + TLN_DIRECT_DEPTH) * G);
     }
   }
 #pragma unroll
   for (int d = 0; d < TLN_DIRECT_DEPTH; ++d)
-    if (it + d < iters) compute(a[d], b[d], meta[d]);
+    if (it + d < iters) compute(a[d], b[d], mode_r[d], smeta[d]);
   if (stamp) g.dbg[2] = __builtin_amdgcn_s_memtime();
 
   // ---- all waves park their accumulators in LDS (the GroupNorm scratch is dead: every wave passed the barrier
@@ -846,7 +912,7 @@ static int launch_gemm(GemmArgs& g, int splits, hipStream_t s) {
   constexpr int REGION = (G * GROUP_FLOATS > RED_FLOATS) ? G * GROUP_FLOATS : RED_FLOATS;
   // + scale/shift [2][cin] floats and the per-channel (sum, sumsq) doubles of the in-kernel GroupNorm finalise
   const size_t gn_floats = g.s[0].gn_part ? (size_t)6 * g.s[0].cin : (g.s[0].scale ? (size_t)2 * g.s[0].cin : 0);
-  const size_t lds = (size_t)(REGION + BM * TLN_TAPS + 4 + gn_floats) * sizeof(float);
+  const size_t lds = (size_t)(REGION + 2 * BM * TLN_TAPS + 4 + gn_floats) * sizeof(float);
   auto kern = k_gather_gemm<WM, TM, TN, BK, G, W_NK, VEC>;
   if (lds > 48 * 1024) {
     static size_t attr_bytes = 0;  // per instantiation
@@ -900,7 +966,7 @@ static int launch_direct(GemmArgs& g, int nchunks, int groups, hipStream_t s) {
     const size_t need = (size_t)J * cin0 * 4;
     if (need > region) region = need;
   }
-  const size_t lds = (region + (size_t)2 * cin0 + 32 * TLN_TAPS + 4) * sizeof(float);
+  const size_t lds = (region + (size_t)2 * cin0 + 2 * 32 * TLN_TAPS + 4) * sizeof(float);
   TLN_REQUIRE(lds <= 96 * 1024, "direct gemm: LDS %zu B", lds);
   if (lds > 48 * 1024) {
     static size_t attr_bytes = 0;  // per instantiation
@@ -1029,10 +1095,12 @@ extern "C" int tln_gather_gemm_ex(int64_t M, int N, const tln_gemm_src* s0, cons
   for (int i = 0; i < g.nsrc; ++i) nchunks += g.s[i].taps * ((g.s[i].cin + bk - 1) / bk);
   const Plan p = make_plan(M, N, nchunks);
   // small M: one wave per 32x32 tile and K subset, operands straight from global memory
-  bool direct_ok = bk32 && g.s[0].cin <= 1024 && tln_cdiv(N, 32) <= 65535;
+  bool direct_ok = bk32 && g.s[0].cin <= 1024 && tln_cdiv(N, 32) <= 65535 && M < (1ll << 31) &&
+                   (int64_t)g.ldw * 17 + N < (1ll << 29);  // 32-bit rows and byte offsets in that kernel
   for (int i = 0; i < g.nsrc; ++i) {
     const SrcDev& d = g.s[i];
-    direct_ok = direct_ok && d.src_rows >= 1 && (d.table == nullptr || d.taps == TLN_TAPS);
+    direct_ok = direct_ok && d.src_rows >= 1 && d.src_rows < (1ll << 31) && d.ld < (1ll << 31) &&
+                (d.table == nullptr || d.taps == TLN_TAPS);
     if (i > 0) direct_ok = direct_ok && d.scale == nullptr;  // only source 0 carries a prologue there
   }
   const bool direct_small = p.wm == 1;

@@ -35,5 +35,5 @@ for name, L, cin, cout, taps, use_gn in [("conv 64->64 V0", lat, 64, 64, 9, True
     print("%-22s V=%5d | prologue %6d  K-loop %6d  reduce %6d  epilogue %6d  cycles (total %.1f us @2.4GHz... x? clock 100MHz ticks=%d)"
           % (name, V, d[0], d[1], d[2], d[3], (s[4] - s[0]) / 2400.0, s[4] - s[0]))
     if s[5]:
-        print("    direct kernel: tap indices arrived +%d, first chunk loads issued +%d (cycles after start)" % (s[5] - s[0], s[6] - s[0]))
+        print("    direct kernel: tap indices arrived +%d, first chunk loads issued +%d, GroupNorm partials summed +%d (cycles after start)" % (s[5] - s[0], s[6] - s[0], (s[7] - s[0]) if s[7] else 0))
     buf.zero_()
