@@ -550,8 +550,39 @@ __global__ void __launch_bounds__(768) k_gather_gemm_direct(const GemmArgs g) {
       if (tab0) Is[i] = at < lim ? g.s[0].table[at] : -1;
       if (tab1) Is[32 * TLN_TAPS + i] = at < lim ? g.s[1].table[at] : -1;
     }
-    __syncthreads();
   }
+  // GroupNorm, first half: the producer's per-32-row partial sums -> J x cin0 sums in LDS.  BEFORE the operand loads:
+  // the barrier below would otherwise wait until every wave has pushed its 40 first loads through the texture
+  // addresser (~3k cycles), with the group statistics still to come after it
+  if (gn_lds) {
+    const SrcDev& s = g.s[0];
+    double2* Gp = reinterpret_cast<double2*>(smem);  // [J][cin0]
+    for (int idx = threadIdx.x; idx < J * cin0; idx += T) {
+      const int c = idx % cin0, j = idx / cin0;
+      // partial blocks j, j+J, j+2J, ...: eight loads in flight per batch, added in block order (deterministic).
+      // (Deeper batches do not pay: with many channels the stage is bound by the bytes a block pulls through its L1,
+      // 75 x 192 x 16 B for a 192-channel source, with few channels one batch covers everything.)
+      double sx = 0.0, sq = 0.0;
+      for (int bb = j; bb < s.gn_nblk; bb += 8 * J) {
+        double2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int b = bb + u * J;
+          const int bc = b < s.gn_nblk ? b : j;  // clamped address, masked below
+          v[u] = s.gn_part[(int64_t)bc * cin0 + c];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (bb + u * J < s.gn_nblk) {
+            sx += v[u].x;
+            sq += v[u].y;
+          }
+      }
+      Gp[idx] = make_double2(sx, sq);
+    }
+  }
+  if (tab0 || tab1 || gn_lds) __syncthreads();
+  if (stamp) g.dbg[7] = __builtin_amdgcn_s_memtime();
 
   const int cpt0 = cin0 >> 5;
   const int nch0 = g.s[0].taps * cpt0;
@@ -706,7 +737,7 @@ __global__ void __launch_bounds__(768) k_gather_gemm_direct(const GemmArgs g) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     g.dbg[5] = __builtin_amdgcn_s_memtime();
   }
-  // first chunks in flight before the GroupNorm finalise
+  // first chunks in flight before the group statistics (double-precision mean / rstd of a few threads)
 #pragma unroll
   for (int d = 0; d < TLN_DIRECT_DEPTH; ++d) load(wv + d * G, a[d], b[d], mode_r[d], smeta[d]);
   if (stamp) g.dbg[6] = __builtin_amdgcn_s_memtime();
@@ -714,29 +745,6 @@ __global__ void __launch_bounds__(768) k_gather_gemm_direct(const GemmArgs g) {
   if (gn_lds) {
     const SrcDev& s = g.s[0];
     double2* Gp = reinterpret_cast<double2*>(smem);  // [J][cin0]
-    for (int idx = threadIdx.x; idx < J * cin0; idx += T) {
-      const int c = idx % cin0, j = idx / cin0;
-      // partial blocks j, j+J, j+2J, ...: eight loads in flight per batch, added in block order (deterministic)
-      double sx = 0.0, sq = 0.0;
-      for (int bb = j; bb < s.gn_nblk; bb += 8 * J) {
-        double2 v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int b = bb + u * J;
-          const int bc = b < s.gn_nblk ? b : j;  // clamped address, masked below
-          v[u] = s.gn_part[(int64_t)bc * cin0 + c];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-          if (bb + u * J < s.gn_nblk) {
-            sx += v[u].x;
-            sq += v[u].y;
-          }
-      }
-      Gp[idx] = make_double2(sx, sq);
-    }
-    __syncthreads();
-    if (stamp) g.dbg[7] = __builtin_amdgcn_s_memtime();
     // group statistics straight from the J x cin0 partials (every thread of a group repeats the group's sum: no
     // second LDS round, no second barrier), fixed order => deterministic
     const int cpg = cin0 / s.gn_groups;
