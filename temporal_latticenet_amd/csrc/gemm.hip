@@ -134,7 +134,8 @@ __global__ void __launch_bounds__(128 * WM * G) k_gather_gemm(const GemmArgs g) 
   }
   // GroupNorm of source 0, finalised here: every block reduces the producer's per-32-row (sum, sumsq) partials in a
   // fixed order (deterministic) into per-channel scale/shift kept in LDS.  No separate statistics kernel.
-  float* Gsc = reinterpret_cast<float*>(Is + 2 * BM * TLN_TAPS + 4);
+  const int ntab = (g.nsrc > 1 && g.s[1].table != nullptr) ? 2 : 1;  // the second table's LDS only when there is one
+  float* Gsc = reinterpret_cast<float*>(Is + ntab * BM * TLN_TAPS + 4);
   float* Gsh = Gsc + g.s[0].cin;
   const bool gn_lds = g.s[0].gn_part != nullptr;
   if (gn_lds) {
@@ -412,7 +413,7 @@ __global__ void __launch_bounds__(128 * WM * G) k_gather_gemm(const GemmArgs g) 
         for (int r = 0; r < 16; ++r) mine[((i * TN + j) * 16 + r) * GT + tid] = acc[i][j][r];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    int* flag = Is + 2 * BM * TLN_TAPS;
+    int* flag = Is + ((g.nsrc > 1 && g.s[1].table != nullptr) ? 2 : 1) * BM * TLN_TAPS;
     if (tid == 0) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -920,7 +921,8 @@ static int launch_gemm(GemmArgs& g, int splits, hipStream_t s) {
   constexpr int REGION = (G * GROUP_FLOATS > RED_FLOATS) ? G * GROUP_FLOATS : RED_FLOATS;
   // + scale/shift [2][cin] floats and the per-channel (sum, sumsq) doubles of the in-kernel GroupNorm finalise
   const size_t gn_floats = g.s[0].gn_part ? (size_t)6 * g.s[0].cin : (g.s[0].scale ? (size_t)2 * g.s[0].cin : 0);
-  const size_t lds = (size_t)(REGION + 2 * BM * TLN_TAPS + 4 + gn_floats) * sizeof(float);
+  const int ntab = (g.nsrc > 1 && g.s[1].table != nullptr) ? 2 : 1;
+  const size_t lds = (size_t)(REGION + ntab * BM * TLN_TAPS + 4 + gn_floats) * sizeof(float);
   auto kern = k_gather_gemm<WM, TM, TN, BK, G, W_NK, VEC>;
   if (lds > 48 * 1024) {
     static size_t attr_bytes = 0;  // per instantiation
