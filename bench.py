@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--streams", type=int, default=4,
                     help="independent sequences in flight per GPU (one HIP stream + host thread + model replica each); "
                          "one step = one sequence on every stream")
+    ap.add_argument("--pairs", type=int, default=1,
+                    help="1: every stream steps two sequences in lock-step with shared gather-GEMM launches; "
+                         "one step = two sequences on every stream")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) on the GPU node; gloo for rehearsals")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: all ranks use cuda:0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -151,13 +154,14 @@ def main():
             S = max(1, args.streams)
             with quiet:
                 pool = SequenceStreams(model, lambda: build_model(contents).eval(), lambda: make_lattice(contents),
-                                       frames, S)
+                                       frames, S, pairs=bool(args.pairs))
+            per = 2 if args.pairs else 1
             per_stream = [frames] + [
                 [(torch.from_numpy(p).cuda(), torch.from_numpy(v).cuda())
-                 for p, v in make_sequence(args.points, args.frames, seed=seed + 1000 * i)] for i in range(1, S)]
+                 for p, v in make_sequence(args.points, args.frames, seed=seed + 1000 * i)] for i in range(1, S * per)]
 
             def run_steps(n):
-                pool.run([[per_stream[i]] * n for i in range(S)])
+                pool.run([per_stream[per * i:per * i + per] * n for i in range(S)])
 
         run_steps(args.warmup)
         barrier()
@@ -243,7 +247,7 @@ def main():
                 for k, (cnt, ms, fl) in sorted(shapes.items(), key=lambda kv: -kv[1][1])[:24]:
                     print("    %-22s %4.1f %8.1f %7.2f" % (k, cnt / 3, ms * 1e3 / cnt, fl / ms / 1e9), file=sys.stderr)
 
-    groups = plan.nr_groups if frames_mode else args.gpus * max(1, args.streams)
+    groups = plan.nr_groups if frames_mode else args.gpus * max(1, args.streams) * (2 if args.pairs else 1)
     clouds = groups * args.steps * args.frames
     value = clouds / elapsed
 
@@ -254,8 +258,9 @@ def main():
     if rank == 0:
         par = ("frames of a sequence sharded over %d ranks (key all-gather + hidden-state hand-off), %d group(s)"
                % (plan.group_size, plan.nr_groups)) if frames_mode else \
-            "%d independent sequence stream(s) per GPU, each on its own HIP stream; one step = one %d-frame sequence on " \
-            "every stream (no data-path collective)" % (max(1, args.streams), args.frames)
+            "%d independent sequence stream(s) per GPU, each on its own HIP stream; one step = %s %d-frame sequence%s on " \
+            "every stream (no data-path collective)" % (max(1, args.streams), "two lock-stepped" if args.pairs else "one",
+                                                        args.frames, "s" if args.pairs else "")
         line = {
             "metric": "point-clouds/sec (120k pts, sigma=0.6, 4-frame seq)",
             "value": round(value, 3), "unit": "clouds/s", "n_gpus": args.gpus, "steps": args.steps,

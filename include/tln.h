@@ -139,6 +139,29 @@ int tln_gather_gemm_ex(int64_t M, int N, const tln_gemm_src* s0, const tln_gemm_
 
 /* tuning hook: force the block tile (TM,TN in {1,2}; 0 = heuristic) */
 void tln_gemm_force_tiles(int tm, int tn);
+/* Two independent products in one launch: for a host that steps two sequences in lock-step on one stream (the
+ * frame program's pair mode, tln_program_run_pair).  Each call is what tln_gather_gemm_ex would take.  When both
+ * are products of the same shape class (same N, K layout, channel counts, weight layout; M may differ) that take the
+ * small-M kernel, they run as ONE launch (blockIdx.z = problem) and each result is what its own launch would give up
+ * to the order of the K summation (the waves per tile are chosen for the pair); otherwise as two launches. */
+typedef struct {
+  int64_t M;
+  int N;
+  const tln_gemm_src* s0;
+  const tln_gemm_src* s1;   /* NULL: one source */
+  const float* d_w;
+  int w_is_nk;
+  const float* d_bias;
+  const float* d_residual;
+  int64_t ld_res;
+  int relu;
+  float* d_out;
+  int64_t ld_out;
+  void* d_stats;
+} tln_gemm_call;
+int tln_gather_gemm_pair(const tln_gemm_call* a, const tln_gemm_call* b, void* stream);
+/* test hook: run tln_gather_gemm_pair as two separate launches (1) or as designed (0) */
+void tln_gemm_pair_disable(int off);
 /* tuning hook: force the number of K-groups per block (1, 2, 4; 0 = heuristic) for 64x64 tiles */
 void tln_gemm_force_groups(int groups);
 /* tuning hook: force the split-K slices over the grid and the tile height (wm: 1 = 32 rows, 2 = 64 rows) */
@@ -341,6 +364,12 @@ int tln_program_run(tln_program_t* p, int early, float* d_out, int64_t out_rows,
 int tln_program_capture_gemms(tln_program_t* p, int enable);
 int tln_program_replay_gemms(tln_program_t* p, int reps, double* ms_total, int64_t* launches, double* flops,
                              double* bytes, void* stream);
+/* Pair mode: two programs compiled from the same model (same weights), each with its own open frame
+ * (tln_program_begin_frame on its own lattice), stepped in lock-step on ONE stream: every op runs per program, except
+ * that the gather-GEMM ops of the two are issued pairwise through tln_gather_gemm_pair.  Results per program as from
+ * tln_program_run up to the K-summation order of the paired products.  Both outputs have out_cols columns. */
+int tln_program_run_pair(tln_program_t* a, tln_program_t* b, int early, float* d_out_a, int64_t out_rows_a,
+                         float* d_out_b, int64_t out_rows_b, int out_cols, void* stream);
 /* device pointers of the current frame's K1 outputs ([4N, 3+val_dim+1], [4N], [4N]); valid until the next frame */
 int tln_program_frame_rows(tln_program_t* p, const float** d_distributed, const int32_t** d_indices,
                            const float** d_weights, int64_t* rows, int* cols);

@@ -23,6 +23,15 @@ class GemmSrc(C.Structure):
     ]
 
 
+class GemmCall(C.Structure):
+    """tln_gemm_call"""
+    _fields_ = [
+        ("M", C.c_int64), ("N", C.c_int), ("s0", C.POINTER(GemmSrc)), ("s1", C.POINTER(GemmSrc)), ("d_w", C.c_void_p),
+        ("w_is_nk", C.c_int), ("d_bias", C.c_void_p), ("d_residual", C.c_void_p), ("ld_res", C.c_int64),
+        ("relu", C.c_int), ("d_out", C.c_void_p), ("ld_out", C.c_int64), ("d_stats", C.c_void_p),
+    ]
+
+
 class GnDesc(C.Structure):
     _fields_ = [
         ("d_partials", C.c_void_p), ("d_x", C.c_void_p), ("V", C.c_int64), ("C", C.c_int), ("groups", C.c_int),
@@ -82,6 +91,8 @@ _PROTOS = {
     "tln_gemm_force_groups": (None, [_i]),
     "tln_gemm_force_splits": (None, [_i, _i]),
     "tln_gemm_force_direct": (None, [_i]),
+    "tln_gather_gemm_pair": (_i, [C.POINTER(GemmCall), C.POINTER(GemmCall), _vp]),
+    "tln_gemm_pair_disable": (None, [_i]),
     "tln_gemm_debug_stamps": (None, [_vp]),
     "tln_gather_gemm_ex": (_i, [_i64, _i, C.POINTER(GemmSrc), C.POINTER(GemmSrc), _vp, _i, _vp, _vp, _i64, _i, _vp, _i64, _vp, _vp]),
     "tln_gn_gather_gemm": (_i, [C.POINTER(GnDesc), _i64, _i, C.POINTER(GemmSrc), C.POINTER(GemmSrc), _vp, _i, _vp, _vp, _i64, _i, _vp, _i64, _vp, _vp]),
@@ -108,6 +119,7 @@ _PROTOS = {
     "tln_program_reset": (_i, [_vp]),
     "tln_program_begin_frame": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, C.POINTER(_i64), _vp]),
     "tln_program_run": (_i, [_vp, _i, _vp, _i64, _i, _vp]),
+    "tln_program_run_pair": (_i, [_vp, _vp, _i, _vp, _i64, _vp, _i64, _i, _vp]),
     "tln_program_capture_gemms": (_i, [_vp, _i]),
     "tln_program_replay_gemms": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(C.c_double),
                                       C.POINTER(C.c_double), _vp]),

@@ -494,7 +494,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define TLN_DIRECT_DEPTH 2
 
 template <bool W_NK>
-__global__ void __launch_bounds__(768) k_gather_gemm_direct(const GemmArgs g) {
+__device__ __forceinline__ void direct_body(const GemmArgs& g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int T = blockDim.x, G = T >> 6;
   // the wave index as a SCALAR: everything derived from it (chunk, tap, channel offset, K row, source selection) then
@@ -838,6 +838,24 @@ __global__ void __launch_bounds__(768) k_gather_gemm_direct(const GemmArgs g) {
   if (stamp) g.dbg[4] = __builtin_amdgcn_s_memtime();
 }
 
+template <bool W_NK>
+__global__ void __launch_bounds__(768) k_gather_gemm_direct(const GemmArgs g) {
+  direct_body<W_NK>(g);
+}
+
+// Two independent products of the same shape class in ONE launch (two sequences stepped in lock-step by one stream,
+// tln_gather_gemm_pair): blockIdx.z selects the problem -- its own operands, tables, row counts, outputs and
+// statistics; weights, N, K and the waves per tile are common.  A block past its problem's rows leaves at once.
+struct GemmArgs2 {
+  GemmArgs a[2];
+};
+template <bool W_NK>
+__global__ void __launch_bounds__(768) k_gather_gemm_direct_pair(const GemmArgs2 gg) {
+  const GemmArgs& g = gg.a[blockIdx.z];
+  if ((int64_t)blockIdx.x * 32 >= g.M) return;
+  direct_body<W_NK>(g);
+}
+
 // ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
@@ -960,12 +978,8 @@ static int dispatch(GemmArgs& g, const Plan& p, hipStream_t s) {
   return launch_gemm<2, 1, 1, BK, 1, W_NK, true>(g, p.splits, s);
 }
 
-template <bool W_NK>
-static int launch_direct(GemmArgs& g, int nchunks, int groups, hipStream_t s) {
-  int G = groups;
-  if (G < 1) G = 1;
-  if (G > 12) G = 12;
-  if (G > nchunks) G = nchunks;
+// dynamic LDS of the direct kernel for a block of G waves (mirrors the carve-up at the top of direct_body)
+static size_t direct_lds_bytes(const GemmArgs& g, int G) {
   const int T = 64 * G;
   const int cin0 = g.s[0].cin;
   size_t region = (size_t)G * 16 * 64 + (size_t)4 * T;
@@ -976,7 +990,17 @@ static int launch_direct(GemmArgs& g, int nchunks, int groups, hipStream_t s) {
     const size_t need = (size_t)J * cin0 * 4;
     if (need > region) region = need;
   }
-  const size_t lds = (region + (size_t)2 * cin0 + 2 * 32 * TLN_TAPS + 4) * sizeof(float);
+  return (region + (size_t)2 * cin0 + 2 * 32 * TLN_TAPS + 4) * sizeof(float);
+}
+
+template <bool W_NK>
+static int launch_direct(GemmArgs& g, int nchunks, int groups, hipStream_t s) {
+  int G = groups;
+  if (G < 1) G = 1;
+  if (G > 12) G = 12;
+  if (G > nchunks) G = nchunks;
+  const int T = 64 * G;
+  const size_t lds = direct_lds_bytes(g, G);
   TLN_REQUIRE(lds <= 96 * 1024, "direct gemm: LDS %zu B", lds);
   if (lds > 48 * 1024) {
     static size_t attr_bytes = 0;  // per instantiation
@@ -994,6 +1018,8 @@ static int launch_direct(GemmArgs& g, int nchunks, int groups, hipStream_t s) {
 
 // optional overrides for tuning / tests (0 = heuristic)
 static int g_force_direct = 0;  // 0 heuristic, 1 always when eligible, -1 never
+static int g_pair_off = 0;      // tests: tln_gather_gemm_pair as two separate launches
+extern "C" void tln_gemm_pair_disable(int off) { g_pair_off = off; }
 extern "C" void tln_gemm_force_direct(int mode) { g_force_direct = mode; }
 static int g_force_tm = 0, g_force_tn = 0, g_force_groups = 0, g_force_splits = 0, g_force_wm = 0;
 static unsigned long long* g_dbg = nullptr;
@@ -1042,14 +1068,22 @@ static Plan make_plan(int64_t M, int N, int nchunks) {
   return p;
 }
 
-extern "C" int tln_gather_gemm_ex(int64_t M, int N, const tln_gemm_src* s0, const tln_gemm_src* s1, const float* d_w,
-                                  int w_is_nk, const float* d_bias, const float* d_residual, int64_t ld_res, int relu,
-                                  float* d_out, int64_t ld_out, void* d_stats, void* stream_) {
+// everything tln_gather_gemm_ex decides before it launches anything
+struct Prep {
+  GemmArgs g;
+  bool vec = false, bk32 = false, gn_fallback = false, direct = false;
+  int nchunks = 0, K = 0;
+  Plan p{2, 1, 1, 1, 1};
+};
+
+static int prepare_gemm(int64_t M, int N, const tln_gemm_src* s0, const tln_gemm_src* s1, const float* d_w, int w_is_nk,
+                        const float* d_bias, const float* d_residual, int64_t ld_res, int relu, float* d_out,
+                        int64_t ld_out, void* d_stats, Prep& q) {
   TLN_REQUIRE(s0 && d_w && d_out, "null argument");
-  TLN_REQUIRE(M >= 0 && N > 0 && ld_out >= N, "bad gemm shape M=%lld N=%d", (long long)M, N);
-  if (M == 0) return TLN_OK;
+  TLN_REQUIRE(M > 0 && N > 0 && ld_out >= N, "bad gemm shape M=%lld N=%d", (long long)M, N);
   TLN_REQUIRE(tln_cdiv(M, 32) < (1ll << 31), "M too large");
-  GemmArgs g{};
+  GemmArgs& g = q.g;
+  g = GemmArgs{};
   g.M = M;
   g.N = N;
   int rc = fill_src(g.s[0], s0);
@@ -1063,6 +1097,7 @@ extern "C" int tln_gather_gemm_ex(int64_t M, int N, const tln_gemm_src* s0, cons
     g.nsrc = 2;
     K += s1->taps * s1->cin;
   }
+  q.K = K;
   g.W = d_w;
   g.ldw = w_is_nk ? K : N;
   g.bias = d_bias;
@@ -1074,7 +1109,6 @@ extern "C" int tln_gather_gemm_ex(int64_t M, int N, const tln_gemm_src* s0, cons
   g.stats = reinterpret_cast<double2*>(d_stats);
   g.splits = 1;
   g.dbg = g_dbg;
-  hipStream_t s = (hipStream_t)stream_;
 
   bool vec = aligned16(d_w);
   for (int i = 0; i < g.nsrc; ++i) {
@@ -1082,30 +1116,16 @@ extern "C" int tln_gather_gemm_ex(int64_t M, int N, const tln_gemm_src* s0, cons
     vec = vec && aligned16(d.src) && (d.ld % 4 == 0) && (d.cin % 4 == 0);
   }
   vec = vec && (w_is_nk ? (K % 4 == 0) : (N % 4 == 0));
-  const bool bk32 = (g.s[0].cin % 32 == 0) && (g.nsrc == 1 || g.s[1].cin % 32 == 0);
-
+  q.vec = vec;
+  q.bk32 = (g.s[0].cin % 32 == 0) && (g.nsrc == 1 || g.s[1].cin % 32 == 0);
   // in-kernel GroupNorm finalise only while the partial sums are small enough to be re-read by every block
-  if (g.s[0].gn_part && (!vec || (size_t)g.s[0].gn_nblk * g.s[0].cin * sizeof(double2) > (512u << 10))) {
-    TLN_REQUIRE(s0->d_scale && s0->d_shift, "GroupNorm fallback needs the d_scale/d_shift scratch of source 0");
-    rc = tln_groupnorm_from_partials(g.s[0].gn_part, g.s[0].gn_rows, g.s[0].cin, g.s[0].gn_groups, g.s[0].gn_gamma,
-                                     g.s[0].gn_beta, g.s[0].gn_eps, const_cast<float*>(s0->d_scale),
-                                     const_cast<float*>(s0->d_shift), stream_);
-    if (rc) return rc;
-    g.s[0].gn_part = nullptr;
-  }
-
-  if (!vec) {
-    rc = w_is_nk ? launch_gemm<2, 1, 1, 16, 1, true, false>(g, 1, s) : launch_gemm<2, 1, 1, 16, 1, false, false>(g, 1, s);
-    if (rc) return rc;
-    TLN_LAUNCH_CHECK();
-    return TLN_OK;
-  }
-  const int bk = bk32 ? 32 : 16;
-  int nchunks = 0;
-  for (int i = 0; i < g.nsrc; ++i) nchunks += g.s[i].taps * ((g.s[i].cin + bk - 1) / bk);
-  const Plan p = make_plan(M, N, nchunks);
+  q.gn_fallback = g.s[0].gn_part && (!vec || (size_t)g.s[0].gn_nblk * g.s[0].cin * sizeof(double2) > (512u << 10));
+  const int bk = q.bk32 ? 32 : 16;
+  q.nchunks = 0;
+  for (int i = 0; i < g.nsrc; ++i) q.nchunks += g.s[i].taps * ((g.s[i].cin + bk - 1) / bk);
+  q.p = make_plan(M, N, q.nchunks);
   // small M: one wave per 32x32 tile and K subset, operands straight from global memory
-  bool direct_ok = bk32 && g.s[0].cin <= 1024 && tln_cdiv(N, 32) <= 65535 && M < (1ll << 31) &&
+  bool direct_ok = vec && q.bk32 && g.s[0].cin <= 1024 && tln_cdiv(N, 32) <= 65535 && M < (1ll << 31) &&
                    (int64_t)g.ldw * 17 + N < (1ll << 29);  // 32-bit rows and byte offsets in that kernel
   for (int i = 0; i < g.nsrc; ++i) {
     const SrcDev& d = g.s[i];
@@ -1113,47 +1133,153 @@ extern "C" int tln_gather_gemm_ex(int64_t M, int N, const tln_gemm_src* s0, cons
                 (d.table == nullptr || d.taps == TLN_TAPS);
     if (i > 0) direct_ok = direct_ok && d.scale == nullptr;  // only source 0 carries a prologue there
   }
-  const bool direct_small = p.wm == 1;
-  if (direct_ok && g_force_direct >= 0 && (direct_small || g_force_direct > 0)) {
-    // enough waves to cover the SIMDs a few times over, 2..8 chunks per wave
-    const int64_t tiles = tln_cdiv(M, 32) * tln_cdiv(N, 32);
-    int G = g_force_groups ? g_force_groups : 1;
-    if (!g_force_groups && tiles <= 256) {
-      // at most one block per CU: the fewest chunks per wave (down to 2: both in flight before the first MFMA)
-      int best_iters = nchunks;
-      for (int cand = 2; cand <= 12; ++cand) {
-        const int it = (nchunks + cand - 1) / cand;
-        if (it < 2) continue;
-        if (it < best_iters) {
-          best_iters = it;
-          G = cand;
-        }
-      }
-    } else if (!g_force_groups) {
-      // several blocks per CU: the busiest SIMD decides.  A block's waves go round the 4 SIMDs, so it puts
-      // ceil(G/4) waves of `iters` chunks each on the busiest one; measured over G = 1..12 on the K-heavy level-0
-      // products (TLN_GEMM_DUMP=2) the launch time follows ceil(G/4) * blocks-per-CU * iters closely (G = 5..7 are
-      // the worst choices), ties go to the smaller block
-      const int64_t bpc = tln_cdiv(tiles, 256);
-      int64_t best = -1;
-      for (int cand = 1; cand <= 12; ++cand) {
-        const int it = (nchunks + cand - 1) / cand;
-        if (it < 2 && cand > 1) continue;
-        const int64_t cost = (int64_t)((cand + 3) / 4) * bpc * it;
-        if (best < 0 || cost < best) {
-          best = cost;
-          G = cand;
-        }
+  const bool direct_small = q.p.wm == 1;
+  q.direct = direct_ok && g_force_direct >= 0 && (direct_small || g_force_direct > 0);
+  return TLN_OK;
+}
+
+// waves per 32x32 tile of the direct kernel
+static int choose_groups(int64_t tiles, int nchunks) {
+  if (g_force_groups) return g_force_groups;
+  int G = 1;
+  if (tiles <= 256) {
+    // at most one block per CU: the fewest chunks per wave (down to 2: both in flight before the first MFMA)
+    int best_iters = nchunks;
+    for (int cand = 2; cand <= 12; ++cand) {
+      const int it = (nchunks + cand - 1) / cand;
+      if (it < 2) continue;
+      if (it < best_iters) {
+        best_iters = it;
+        G = cand;
       }
     }
-    rc = w_is_nk ? launch_direct<true>(g, nchunks, G, s) : launch_direct<false>(g, nchunks, G, s);
+  } else {
+    // several blocks per CU: the busiest SIMD decides.  A block's waves go round the 4 SIMDs, so it puts
+    // ceil(G/4) waves of `iters` chunks each on the busiest one; measured over G = 1..12 on the K-heavy level-0
+    // products (TLN_GEMM_DUMP=2) the launch time follows ceil(G/4) * blocks-per-CU * iters closely (G = 5..7 are
+    // the worst choices), ties go to the smaller block
+    const int64_t bpc = tln_cdiv(tiles, 256);
+    int64_t best = -1;
+    for (int cand = 1; cand <= 12; ++cand) {
+      const int it = (nchunks + cand - 1) / cand;
+      if (it < 2 && cand > 1) continue;
+      const int64_t cost = (int64_t)((cand + 3) / 4) * bpc * it;
+      if (best < 0 || cost < best) {
+        best = cost;
+        G = cand;
+      }
+    }
+  }
+  return G;
+}
+
+extern "C" int tln_gather_gemm_ex(int64_t M, int N, const tln_gemm_src* s0, const tln_gemm_src* s1, const float* d_w,
+                                  int w_is_nk, const float* d_bias, const float* d_residual, int64_t ld_res, int relu,
+                                  float* d_out, int64_t ld_out, void* d_stats, void* stream_) {
+  TLN_REQUIRE(M >= 0, "bad gemm shape M=%lld", (long long)M);
+  if (M == 0) {
+    TLN_REQUIRE(s0 && d_w && d_out && N > 0 && ld_out >= N, "bad gemm arguments");
+    return TLN_OK;
+  }
+  Prep q;
+  int rc = prepare_gemm(M, N, s0, s1, d_w, w_is_nk, d_bias, d_residual, ld_res, relu, d_out, ld_out, d_stats, q);
+  if (rc) return rc;
+  GemmArgs& g = q.g;
+  hipStream_t s = (hipStream_t)stream_;
+  if (q.gn_fallback) {
+    TLN_REQUIRE(s0->d_scale && s0->d_shift, "GroupNorm fallback needs the d_scale/d_shift scratch of source 0");
+    rc = tln_groupnorm_from_partials(g.s[0].gn_part, g.s[0].gn_rows, g.s[0].cin, g.s[0].gn_groups, g.s[0].gn_gamma,
+                                     g.s[0].gn_beta, g.s[0].gn_eps, const_cast<float*>(s0->d_scale),
+                                     const_cast<float*>(s0->d_shift), stream_);
+    if (rc) return rc;
+    g.s[0].gn_part = nullptr;
+  }
+  if (!q.vec) {
+    rc = w_is_nk ? launch_gemm<2, 1, 1, 16, 1, true, false>(g, 1, s) : launch_gemm<2, 1, 1, 16, 1, false, false>(g, 1, s);
     if (rc) return rc;
     TLN_LAUNCH_CHECK();
     return TLN_OK;
   }
-  if (bk32) rc = w_is_nk ? dispatch<32, true>(g, p, s) : dispatch<32, false>(g, p, s);
-  else rc = w_is_nk ? dispatch<16, true>(g, p, s) : dispatch<16, false>(g, p, s);
+  if (q.direct) {
+    const int64_t tiles = tln_cdiv(M, 32) * tln_cdiv(N, 32);
+    const int G = choose_groups(tiles, q.nchunks);
+    rc = w_is_nk ? launch_direct<true>(g, q.nchunks, G, s) : launch_direct<false>(g, q.nchunks, G, s);
+    if (rc) return rc;
+    TLN_LAUNCH_CHECK();
+    return TLN_OK;
+  }
+  if (q.bk32) rc = w_is_nk ? dispatch<32, true>(g, q.p, s) : dispatch<32, false>(g, q.p, s);
+  else rc = w_is_nk ? dispatch<16, true>(g, q.p, s) : dispatch<16, false>(g, q.p, s);
   if (rc) return rc;
+  TLN_LAUNCH_CHECK();
+  return TLN_OK;
+}
+
+static int run_call(const tln_gemm_call* c, void* stream_) {
+  return tln_gather_gemm_ex(c->M, c->N, c->s0, c->s1, c->d_w, c->w_is_nk, c->d_bias, c->d_residual, c->ld_res, c->relu,
+                            c->d_out, c->ld_out, c->d_stats, stream_);
+}
+
+extern "C" int tln_gather_gemm_pair(const tln_gemm_call* a, const tln_gemm_call* b, void* stream_) {
+  TLN_REQUIRE(a && b, "null call");
+  if (a->M <= 0 || b->M <= 0 || g_pair_off) {
+    int rc = run_call(a, stream_);
+    return rc ? rc : run_call(b, stream_);
+  }
+  Prep qa, qb;
+  int rc = prepare_gemm(a->M, a->N, a->s0, a->s1, a->d_w, a->w_is_nk, a->d_bias, a->d_residual, a->ld_res, a->relu,
+                        a->d_out, a->ld_out, a->d_stats, qa);
+  if (rc) return rc;
+  rc = prepare_gemm(b->M, b->N, b->s0, b->s1, b->d_w, b->w_is_nk, b->d_bias, b->d_residual, b->ld_res, b->relu,
+                    b->d_out, b->ld_out, b->d_stats, qb);
+  if (rc) return rc;
+  const GemmArgs &ga = qa.g, &gb = qb.g;
+  // one launch only for two products of the same shape class that both take the direct kernel as it is
+  bool same = qa.direct && qb.direct && !qa.gn_fallback && !qb.gn_fallback && a->w_is_nk == b->w_is_nk && a->N == b->N &&
+              ga.nsrc == gb.nsrc && qa.nchunks == qb.nchunks && (ga.s[0].gn_part != nullptr) == (gb.s[0].gn_part != nullptr);
+  for (int i = 0; same && i < ga.nsrc; ++i)
+    same = ga.s[i].cin == gb.s[i].cin && ga.s[i].taps == gb.s[i].taps;
+  if (!same) {
+    rc = run_call(a, stream_);
+    return rc ? rc : run_call(b, stream_);
+  }
+  hipStream_t s = (hipStream_t)stream_;
+  const int64_t mt = tln_cdiv(a->M > b->M ? a->M : b->M, 32);
+  // waves per tile from the work of BOTH problems (they share the CUs)
+  const int64_t tiles = (tln_cdiv(a->M, 32) + tln_cdiv(b->M, 32)) * tln_cdiv(a->N, 32);
+  int G = choose_groups(tiles, qa.nchunks);
+  if (G < 1) G = 1;
+  if (G > 12) G = 12;
+  if (G > qa.nchunks) G = qa.nchunks;
+  size_t lds = direct_lds_bytes(ga, G);
+  const size_t ldb = direct_lds_bytes(gb, G);
+  if (ldb > lds) lds = ldb;
+  TLN_REQUIRE(lds <= 96 * 1024, "direct gemm: LDS %zu B", lds);
+  GemmArgs2 gg;
+  gg.a[0] = ga;
+  gg.a[1] = gb;
+  dim3 grid((unsigned)mt, (unsigned)tln_cdiv(a->N, 32), 2);
+  if (a->w_is_nk) {
+    if (lds > 48 * 1024) {
+      static bool attr = false;
+      if (!attr) {
+        TLN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gather_gemm_direct_pair<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        attr = true;
+      }
+    }
+    hipLaunchKernelGGL(k_gather_gemm_direct_pair<true>, grid, dim3(64 * G), lds, s, gg);
+  } else {
+    if (lds > 48 * 1024) {
+      static bool attr = false;
+      if (!attr) {
+        TLN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gather_gemm_direct_pair<false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        attr = true;
+      }
+    }
+    hipLaunchKernelGGL(k_gather_gemm_direct_pair<false>, grid, dim3(64 * G), lds, s, gg);
+  }
   TLN_LAUNCH_CHECK();
   return TLN_OK;
 }

@@ -154,6 +154,10 @@ struct tln_program {
   bool w_wrote[TLN_MAX_STATES] = {false};
   int64_t w_new_rows[TLN_MAX_STATES] = {0};
   bool w_finished = false;
+  // pair mode (tln_program_run_pair): the walk stops at every gather-GEMM with its resolved call left here
+  bool defer = false, has_pending = false;
+  GemmCall pending{};
+  int w_next = 0;  // where the next walk continues
 };
 
 namespace {
@@ -279,6 +283,7 @@ int walk(tln_program* p, bool dry, int early, float* d_out, int64_t out_rows, in
       });
       if (rc) return rc;
     }
+    bool stop_here = false;
     // op-local scratch (released right after the op)
     size_t scratch_off[3] = {0, 0, 0}, scratch_bytes[3] = {0, 0, 0};
     char* scratch[3] = {nullptr, nullptr, nullptr};
@@ -331,6 +336,14 @@ int walk(tln_program* p, bool dry, int early, float* d_out, int64_t out_rows, in
         }
         const float* res = o.residual >= 0 ? fptr(o.residual) : nullptr;
         const int64_t ld_res = o.residual >= 0 ? p->slots[o.residual].cols : 0;
+        if (p->defer) {  // the caller launches it together with the other sequence's product
+          p->pending = GemmCall{M, o.n, {a[0], a[1]}, o.s1.slot >= 0, o.w, o.w_is_nk, o.bias, res, ld_res, o.relu,
+                                fptr(o.out) + o.out_col, so.cols, o.stats_out >= 0 ? p->rt[o.stats_out].ptr : nullptr};
+          if (!p->pending.two) p->pending.a[1] = tln_gemm_src{};
+          p->has_pending = true;
+          stop_here = true;
+          break;
+        }
         rc = tln_gather_gemm_ex(M, o.n, &a[0], o.s1.slot >= 0 ? &a[1] : nullptr, o.w, o.w_is_nk, o.bias, res, ld_res,
                                 o.relu, fptr(o.out) + o.out_col, so.cols,
                                 o.stats_out >= 0 ? p->rt[o.stats_out].ptr : nullptr, s);
@@ -501,7 +514,12 @@ int walk(tln_program* p, bool dry, int early, float* d_out, int64_t out_rows, in
     };
     for_inputs(o, drop);
     for_outputs(o, drop);
+    if (stop_here) {
+      p->w_next = oi + 1;
+      return TLN_OK;
+    }
   }
+  p->w_next = op_end;
   return TLN_OK;
 }
 
@@ -677,6 +695,104 @@ extern "C" int tln_program_run(tln_program_t* p, int early, float* d_out, int64_
   }
   if (rc == TLN_OK) commit_states(p);
   p->frame_open = false;
+  return rc;
+}
+
+// ---- pair mode: two sequences stepped in lock-step on one stream, their gather-GEMM ops sharing launches -----------
+namespace {
+int launch_pending(tln_program* a, tln_program* b, hipStream_t s) {
+  auto as_call = [](const GemmCall& c) {
+    return tln_gemm_call{c.M, c.N, &c.a[0], c.two ? &c.a[1] : nullptr, c.w, c.w_is_nk, c.bias, c.res, c.ld_res,
+                         c.relu, c.out, c.ld_out, c.stats};
+  };
+  int rc = TLN_OK;
+  if (a->has_pending && b->has_pending) {
+    const tln_gemm_call ca = as_call(a->pending), cb = as_call(b->pending);
+    rc = tln_gather_gemm_pair(&ca, &cb, s);
+  } else {
+    for (tln_program* p : {a, b})
+      if (p->has_pending && !rc) {
+        const GemmCall& c = p->pending;
+        rc = tln_gather_gemm_ex(c.M, c.N, &c.a[0], c.two ? &c.a[1] : nullptr, c.w, c.w_is_nk, c.bias, c.res, c.ld_res,
+                                c.relu, c.out, c.ld_out, c.stats, s);
+      }
+  }
+  for (tln_program* p : {a, b}) {
+    if (p->has_pending && p->capture && p->pending.M > 0) p->calls.push_back(p->pending);
+    p->has_pending = false;
+  }
+  return rc;
+}
+
+// ops [begin, end) of both programs: everything but the products per program, the products pairwise
+int walk_pair(tln_program* pa, tln_program* pb, int early, float* const d_out[2], const int64_t out_rows[2],
+              const int out_cols[2], hipStream_t s, int begin, int end, bool fresh) {
+  tln_program* pp[2] = {pa, pb};
+  int at[2] = {begin, begin};
+  bool first = true;
+  int rc = TLN_OK;
+  for (;;) {
+    bool any = false;
+    for (int k = 0; k < 2 && !rc; ++k) {
+      tln_program* p = pp[k];
+      p->has_pending = false;
+      if (at[k] >= end || (p->w_finished && !(fresh && first))) continue;
+      p->defer = true;
+      rc = walk(p, false, early, d_out[k], out_rows[k], out_cols[k], s, at[k], end, fresh && first);
+      p->defer = false;
+      at[k] = p->w_next;
+      any = any || p->has_pending;
+    }
+    first = false;
+    if (rc) break;
+    if (!any) break;
+    rc = launch_pending(pa, pb, s);
+    if (rc) break;
+  }
+  for (tln_program* p : pp) {
+    p->defer = false;
+    p->has_pending = false;
+  }
+  return rc;
+}
+}  // namespace
+
+extern "C" int tln_program_run_pair(tln_program_t* pa, tln_program_t* pb, int early, float* d_out_a, int64_t out_rows_a,
+                                    float* d_out_b, int64_t out_rows_b, int out_cols, void* stream_) {
+  TLN_REQUIRE(pa && pb && pa != pb && pa->frame_open && pb->frame_open, "tln_program_run_pair without two open frames");
+  TLN_REQUIRE(pa->ops.size() == pb->ops.size() && pa->split == pb->split, "the two programs differ");
+  hipStream_t s = (hipStream_t)stream_;
+  const int n_ops = (int)pa->ops.size();
+  tln_program* pp[2] = {pa, pb};
+  float* const d_out[2] = {d_out_a, d_out_b};
+  const int64_t out_rows[2] = {out_rows_a, out_rows_b};
+  const int out_cols2[2] = {out_cols, out_cols};
+  int rc = TLN_OK;
+  for (int k = 0; k < 2 && !rc; ++k) {
+    rc = walk(pp[k], true, early, nullptr, out_rows[k], out_cols, s, 0, n_ops, true);
+    if (!rc) rc = ensure_buf(pp[k]->arena, pp[k]->alloc.high + kAlign, s);
+    pp[k]->calls.clear();
+  }
+  if (rc) return rc;
+  rc = walk_pair(pa, pb, early, d_out, out_rows, out_cols2, s, 0, pa->split, true);
+  for (int k = 0; k < 2; ++k) {
+    tln_program* p = pp[k];
+    int rc2 = tln_lattice_prepare_levels_finish(p->lat, s);
+    if (rc == TLN_OK) rc = rc2;
+    if (rc == TLN_OK) {
+      for (int i = 1; i <= p->n_coarse; ++i) {
+        p->V[i] = tln_lattice_nr_vertices(p->levels[i]);
+        TLN_REQUIRE(p->V[i] <= p->Vb[i], "level %d has %lld vertices, more than the bound %lld", i, (long long)p->V[i],
+                    (long long)p->Vb[i]);
+      }
+      p->exact_known = true;
+    }
+  }
+  if (rc == TLN_OK) rc = walk_pair(pa, pb, early, d_out, out_rows, out_cols2, s, pa->split, n_ops, false);
+  for (int k = 0; k < 2; ++k) {
+    if (rc == TLN_OK) commit_states(pp[k]);
+    pp[k]->frame_open = false;
+  }
   return rc;
 }
 

@@ -410,6 +410,39 @@ class FrameProgram:
         ls.set_values(out)
         return out, ls
 
+    def _begin(self, ls, positions, values, reset_hashmap, early_return):
+        positions = positions.contiguous().float()
+        n = positions.shape[0]
+        if values is None or values.numel() == 0:
+            values, val_dim = None, 0
+        else:
+            values = values.contiguous().float()
+            val_dim = values.shape[1]
+        _lib.check(_lib.lib().tln_program_begin_frame(self._h, ls._h, positions.data_ptr(),
+                                                      values.data_ptr() if values is not None else None, n, val_dim,
+                                                      1 if reset_hashmap else 0, 1 if self.subtract_mean else 0,
+                                                      self._v, stream_ptr()), "tln_program_begin_frame")
+        ls._csr_key = None
+        early = bool(early_return) and self.stop_shape is not None
+        rows_code, cols = self.stop_shape if early else self.out_shape
+        out = torch.empty((self._rows(rows_code, n), cols), dtype=torch.float32, device="cuda")
+        return early, out, (positions, values)        # the inputs stay alive until the frame has been enqueued
+
+    @staticmethod
+    def run_frame_pair(progs, lattices, positions, values, reset_hashmap, early_return):
+        """two sequences in lock-step on the current stream (tln_program_run_pair): -> [(tensor, ls), (tensor, ls)]"""
+        a, b = progs
+        ea, out_a, keep_a = a._begin(lattices[0], positions[0], values[0], reset_hashmap, early_return)
+        eb, out_b, keep_b = b._begin(lattices[1], positions[1], values[1], reset_hashmap, early_return)
+        assert ea == eb and out_a.shape[1] == out_b.shape[1]
+        _lib.check(_lib.lib().tln_program_run_pair(a._h, b._h, 1 if ea else 0, out_a.data_ptr(), out_a.shape[0],
+                                                   out_b.data_ptr(), out_b.shape[0], out_a.shape[1], stream_ptr()),
+                   "tln_program_run_pair")
+        del keep_a, keep_b
+        lattices[0].set_values(out_a)
+        lattices[1].set_values(out_b)
+        return [(out_a, lattices[0]), (out_b, lattices[1])]
+
     def capture_gemms(self, enable=True):
         _lib.check(_lib.lib().tln_program_capture_gemms(self._h, 1 if enable else 0), "tln_program_capture_gemms")
 

@@ -346,3 +346,24 @@ class LNN_SEQ(torch.nn.Module):
         class_weights = 1.0 / torch.log(1.05 + class_frequencies_tensor)
         class_weights[background_idx] = 0.00000001
         return class_weights
+
+
+def forward_pair(models, lattices, positions, values, early_return=False):
+    """One frame of TWO independent sequences in lock-step on the current stream (inference): every gather-GEMM op of
+    the two frame programs is issued as one launch (engine.FrameProgram.run_frame_pair, tln_program_run_pair).  Same
+    return value per model as LNN_SEQ.forward; falls back to two forward calls when a model cannot take the frame
+    program for this frame."""
+    from . import engine
+    resets = [not (mod.sequence_learning and not mod.first_sequence) for mod in models]
+    progs = [mod._program_for_this_frame(False) for mod in models]
+    if progs[0] is None or progs[1] is None or resets[0] != resets[1] or progs[0] is progs[1]:
+        return [mod(ls, p, v, early_return, False) for mod, ls, p, v in zip(models, lattices, positions, values)]
+    res = engine.FrameProgram.run_frame_pair(progs, lattices, positions, values, resets[0], early_return)
+    out = []
+    for mod, prog, (o, ls) in zip(models, progs, res):
+        mod.first_sequence = False
+        if early_return and prog.stop_shape is not None:
+            out.append((o, o, ls))
+        else:
+            out.append((mod.logsoftmax(o), o, ls))
+    return out

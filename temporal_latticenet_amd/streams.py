@@ -45,11 +45,16 @@ class SequenceStreams:
     (positions, values) frames resident on the device) through replica i in its own thread and returns, per stream,
     the per-sequence outputs of the last frame."""
 
-    def __init__(self, base_model, make_model, make_lattice, warm_sequence, n_streams):
+    def __init__(self, base_model, make_model, make_lattice, warm_sequence, n_streams, pairs=False):
+        """pairs: every stream steps TWO sequences in lock-step (models.forward_pair: their gather-GEMM launches are
+        shared), i.e. 2 * n_streams sequences in flight -- the GPU runs at most four streams of a process at full rate"""
+        self.pairs = bool(pairs)
+        self.n_streams = n_streams
+        n_models = n_streams * (2 if self.pairs else 1)
         self.models = [base_model]
         self.make_lattice = make_lattice
         quiet = contextlib.redirect_stdout(io.StringIO())
-        for _ in range(n_streams - 1):
+        for _ in range(n_models - 1):
             with quiet, torch.no_grad():
                 m = make_model()
                 m.train(base_model.training)
@@ -59,7 +64,7 @@ class SequenceStreams:
                 m.reset_sequence()
             self.models.append(share_parameters(m, base_model))
         self.streams = [torch.cuda.Stream() for _ in range(n_streams)]
-        self.lattices = [make_lattice() for _ in range(n_streams)]
+        self.lattices = [make_lattice() for _ in range(n_models)]
         # persistent workers (a fresh host thread pays HIP's per-thread set-up on its first call)
         self._jobs = [queue.Queue() for _ in range(n_streams)]
         self._done = queue.Queue()
@@ -68,10 +73,10 @@ class SequenceStreams:
             t.start()
 
     def __len__(self):
-        return len(self.models)
+        return self.n_streams
 
     def close(self):
-        for i in range(1, len(self.models)):
+        for i in range(1, self.n_streams):
             self._jobs[i].put(None)
         for t in self._threads:
             t.join()
@@ -87,10 +92,27 @@ class SequenceStreams:
 
     def _work(self, i, sequences, keep_outputs):
         try:
-            model, lat = self.models[i], self.lattices[i]
             outs = []
             with torch.no_grad(), torch.cuda.stream(self.streams[i]):
-                for seq in sequences:
+                if self.pairs:
+                    from .models import forward_pair
+                    models, lats = self.models[2 * i:2 * i + 2], self.lattices[2 * i:2 * i + 2]
+                    k = 0
+                    while k + 1 < len(sequences) and len(sequences[k]) == len(sequences[k + 1]):
+                        sa, sb = sequences[k], sequences[k + 1]
+                        for t in range(len(sa)):
+                            res = forward_pair(models, lats, [sa[t][0], sb[t][0]], [sa[t][1], sb[t][1]],
+                                               t != len(sa) - 1)
+                            lats = [res[0][2], res[1][2]]
+                        for mod in models:
+                            mod.reset_sequence()
+                        if keep_outputs:
+                            outs += [res[0][1], res[1][1]]
+                        k += 2
+                    rest, model, lat = sequences[k:], models[0], lats[0]
+                else:
+                    rest, model, lat = sequences, self.models[i], self.lattices[i]
+                for seq in rest:
                     for t, (p, v) in enumerate(seq):
                         out, raw, lat = model(lat, p, v, t != len(seq) - 1, False)
                     model.reset_sequence()
@@ -102,7 +124,7 @@ class SequenceStreams:
             return None, e
 
     def run(self, batches, keep_outputs=False):
-        n = len(self.models)
+        n = self.n_streams
         assert len(batches) == n
         cur = torch.cuda.current_stream()
         for s in self.streams:           # inputs prepared on the caller's stream are ready for every worker

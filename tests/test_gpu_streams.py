@@ -42,3 +42,37 @@ def test_concurrent_streams_equal_the_single_stream_results(gpu, frame_program):
     if frame_program:
         assert all(getattr(m, "_program", None) is not None for m in pool.models)
     pool.close()
+
+
+def test_lockstep_pairs_match_the_single_sequence_results(gpu):
+    """two sequences per stream in lock-step (shared gather-GEMM launches): every sequence's scores equal its solo
+    run up to the K-summation order of the paired products; with the pairing switched off (two launches per product)
+    they are bitwise equal, which pins the lock-step host logic by itself"""
+    from temporal_latticenet_amd import _lib
+    contents = make_config(rnn_modules=("gru", "gru", "aflow", "gru"), frames=3, sigma=0.7)
+    S = 2
+    seqs = [[(torch.from_numpy(p).to(gpu), torch.from_numpy(v).to(gpu)) for p, v in make_sequence(9000 + 700 * s, 3, seed=170 + s)]
+            for s in range(2 * S + 1)]
+    model = build_model(contents).eval()
+    _alone(model, contents, seqs[0])
+    randomize_parameters(model, seed=19)
+    want = [_alone(model, contents, s) for s in seqs]
+    pool = SequenceStreams(model, lambda: build_model(contents).eval(), lambda: make_lattice(contents), seqs[0], S, pairs=True)
+    assert len(pool.models) == 2 * S and len(pool) == S
+    lib = _lib.lib()
+    try:
+        for off in (1, 0):
+            lib.tln_gemm_pair_disable(off)
+            # stream 0: a pair and an odd one out (solo route); stream 1: a pair
+            got = pool.run([[seqs[0], seqs[1], seqs[4]], [seqs[2], seqs[3]]], keep_outputs=True)
+            flat = got[0][:2] + got[1] + got[0][2:]
+            for k, (g, w) in enumerate(zip(flat, want)):
+                assert g.shape == w.shape
+                if off:
+                    assert torch.equal(g, w), "sequence %d, separate launches" % k
+                else:
+                    err = float((g - w).abs().max())
+                    assert err <= 2e-4 * max(1.0, float(w.abs().max())), "sequence %d: %.3e" % (k, err)
+    finally:
+        lib.tln_gemm_pair_disable(0)
+        pool.close()
