@@ -181,9 +181,10 @@ extern "C" int tln_gru_cell(const float* d_x, const float* d_h, int64_t V, int64
   sh.d_src = d_h;
   sh.src_rows = Vh;
   sh.pad_value = 0.0f;
-  int rc = tln_gather_gemm(V, 3 * C, &sx, nullptr, d_w_ih, 1, d_b_ih, nullptr, 0, 0, gi, 3 * C, stream_);
-  if (rc) return rc;
-  rc = tln_gather_gemm(V, 3 * C, &sh, nullptr, d_w_hh, 1, d_b_hh, nullptr, 0, 0, gh, 3 * C, stream_);
+  // the two products have the same shape: one launch (blockIdx.z = product) when they take the small-M kernel
+  const tln_gemm_call ci{V, 3 * C, &sx, nullptr, d_w_ih, 1, d_b_ih, nullptr, 0, 0, gi, 3 * (int64_t)C, nullptr};
+  const tln_gemm_call ch{V, 3 * C, &sh, nullptr, d_w_hh, 1, d_b_hh, nullptr, 0, 0, gh, 3 * (int64_t)C, nullptr};
+  int rc = tln_gather_gemm_pair(&ci, &ch, stream_);
   if (rc) return rc;
   const int64_t total = V * C;
   hipLaunchKernelGGL(k_gru_gates, dim3((unsigned)tln_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream_, gi, gh, d_h,
