@@ -132,3 +132,54 @@ def test_program_edge_cases_equal_operator_route(gpu, n, sigma, capacity):
         assert a.shape == b.shape
         same = torch.equal(a, b) or bool(((a == b) | (a.isnan() & b.isnan())).all())   # AFlow's 0/0 is a NaN on both
         assert same, "frame %d differs (max %.3e)" % (t, float((a - b).abs().nan_to_num().max()))
+
+
+@pytest.mark.parametrize("rnn,seq_learning,frames", [
+    (("gru", "gru", "aflow", "gru"), True, 3),
+    (("gru", "none", "none", "none"), True, 3),        # early frames stop inside the level-0 prefix
+    (("none", "gru", "none", "none"), True, 2),
+    (("gru", "none", "none", "none"), False, 1),       # no sequence learning: every frame resets the lattice
+    (("maxpool", "linear", "lstm", "cga"), True, 3),
+])
+def test_lockstep_pair_equals_the_solo_frames(gpu, rnn, seq_learning, frames):
+    """models.forward_pair on two sequences of very different size: every frame's outputs (early-return values and
+    final scores) bitwise equal to the solo frame program when the paired products are issued as two launches, and
+    within float rounding of it when they share a launch; hidden states reset with the sequences"""
+    from temporal_latticenet_amd import _lib
+    from temporal_latticenet_amd.models import forward_pair
+    from temporal_latticenet_amd.streams import share_parameters
+    contents = make_config(rnn_modules=rnn, sequence_learning=seq_learning, frames=frames, sigma=0.7)
+    seqs = [make_sequence(12000, frames, seed=31), make_sequence(2500, frames, seed=32)]
+    model = _prepared(contents, seqs[0], gpu)
+    model.use_frame_program = True
+    want = [_run(model, contents, s, gpu)[0] for s in seqs]
+    twin = build_model(contents).eval()
+    _run(twin, contents, seqs[0], gpu)
+    twin = share_parameters(twin, model)
+    twin.use_frame_program = True
+    models = [model, twin]
+    lib = _lib.lib()
+    try:
+        for off in (1, 0, 0):
+            lib.tln_gemm_pair_disable(off)
+            lats = [make_lattice(contents), make_lattice(contents)]
+            with torch.no_grad():
+                for t in range(frames):
+                    pos = [torch.from_numpy(s[t][0]).to(gpu) for s in seqs]
+                    val = [torch.from_numpy(s[t][1]).to(gpu) for s in seqs]
+                    res = forward_pair(models, lats, pos, val, t != frames - 1)
+                    assert all(getattr(m, "_program_active", False) for m in models)
+                    for k in range(2):
+                        for j in range(2):
+                            g, w = res[k][j], want[k][t][j]
+                            assert g.shape == w.shape
+                            if off:
+                                assert torch.equal(g, w), "sequence %d frame %d output %d" % (k, t, j)
+                            else:
+                                err = float((g - w).abs().max())
+                                assert err <= 2e-4 * max(1.0, float(w.abs().max())), (k, t, j, err)
+                        lats[k] = res[k][2]
+            for m in models:
+                m.reset_sequence()
+    finally:
+        lib.tln_gemm_pair_disable(0)
