@@ -15,6 +15,9 @@ from temporal_latticenet_amd.synthetic import make_sequence
 quiet = lambda: contextlib.redirect_stdout(io.StringIO())
 
 
+PAIRS_ONLY = len(sys.argv) > 2 and sys.argv[2] == "pairs"
+
+
 def model_config(name, points, frames, rnn, seq_learning, sigma, capacity, steps):
     contents = make_config(rnn_modules=rnn, sequence_learning=seq_learning, frames=frames, sigma=sigma, capacity=capacity)
     seq = [(torch.from_numpy(p).cuda(), torch.from_numpy(v).cuda()) for p, v in make_sequence(points, frames, seed=1234)]
@@ -31,19 +34,28 @@ def model_config(name, points, frames, rnn, seq_learning, sigma, capacity, steps
             counts.append(l.nr_lattice_vertices())
         model.reset_sequence()
     res = {}
-    for S in (1, 4):
+    # the pair mode gets a process of its own (argv[2] == "pairs"): streams created after two earlier pools land on
+    # hardware queues that share compute pipes, which costs it 30 %
+    runs = ((4, True),) if PAIRS_ONLY else ((1, False), (4, False))
+    for S, pairs in runs:
         with quiet():
-            pool = SequenceStreams(model, lambda: build_model(contents).eval(), lambda: make_lattice(contents), seq, S)
-        pool.run([[seq] * 2 for _ in range(S)])
+            pool = SequenceStreams(model, lambda: build_model(contents).eval(), lambda: make_lattice(contents), seq, S,
+                                   pairs=pairs)
+        per = 2 if pairs else 1          # sequences per stream and step
+        pool.run([[seq] * (2 * per) for _ in range(S)])
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        pool.run([[seq] * steps for _ in range(S)])
+        pool.run([[seq] * (steps * per) for _ in range(S)])
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        res[S] = S * steps * frames / dt
+        res[(S, pairs)] = S * per * steps * frames / dt
         pool.close()
-    print("%-9s %7d pts x %d frames, sigma %.2f, rnn %-22s V0/V1/V2 (last frame) %s : %8.1f clouds/s (1 stream) %8.1f clouds/s (4 streams)"
-          % (name, points, frames, sigma, ",".join(rnn) if seq_learning else "(no sequence learning)", counts, res[1], res[4]), flush=True)
+    head = "%-9s %7d pts x %d frames, sigma %.2f, rnn %-22s V0/V1/V2 (last frame) %s :" % (
+        name, points, frames, sigma, ",".join(rnn) if seq_learning else "(no sequence learning)", counts)
+    if PAIRS_ONLY:
+        print(head, "%8.1f clouds/s (4 streams x 2 lock-stepped sequences)" % res[(4, True)], flush=True)
+    else:
+        print(head, "%8.1f clouds/s (1 stream) %8.1f clouds/s (4 streams)" % (res[(1, False)], res[(4, False)]), flush=True)
 
 
 def config1():
@@ -95,11 +107,11 @@ def config1():
 
 
 CONFIGS = {
-    "2": ("config 2", 120000, 1, ("gru", "none", "none", "none"), False, 0.6, 1 << 18, 40),
-    "3": ("config 3", 120000, 4, ("gru", "gru", "gru", "gru"), True, 0.6, 1 << 18, 20),
-    "headline": ("headline", 120000, 4, ("gru", "gru", "aflow", "gru"), True, 0.6, 1 << 18, 20),
-    "5": ("config 5", 960000, 1, ("gru", "none", "none", "none"), False, 0.6, 1 << 21, 10),
-    "5b": ("config 5b", 120000, 8, ("gru", "gru", "aflow", "gru"), True, 0.6, 1 << 18, 10),
+    "2": ("config 2", 120000, 1, ("gru", "none", "none", "none"), False, 0.6, 1 << 18, 160),
+    "3": ("config 3", 120000, 4, ("gru", "gru", "gru", "gru"), True, 0.6, 1 << 18, 80),
+    "headline": ("headline", 120000, 4, ("gru", "gru", "aflow", "gru"), True, 0.6, 1 << 18, 80),
+    "5": ("config 5", 960000, 1, ("gru", "none", "none", "none"), False, 0.6, 1 << 21, 30),
+    "5b": ("config 5b", 120000, 8, ("gru", "gru", "aflow", "gru"), True, 0.6, 1 << 18, 40),
 }
 
 if __name__ == "__main__":

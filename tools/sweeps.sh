@@ -3,7 +3,7 @@
 set -e
 mkdir -p gpurun_out/sweeps
 : > gpurun_out/sweeps/configs.txt
-for c in 1 2 3 headline 5 5b; do python tools/configs_bench.py $c >> gpurun_out/sweeps/configs.txt 2>&1; echo "config $c done"; done
+for c in 1 2 3 headline 5 5b; do python tools/configs_bench.py $c >> gpurun_out/sweeps/configs.txt 2>&1; [ $c != 1 ] && python tools/configs_bench.py $c pairs >> gpurun_out/sweeps/configs.txt 2>&1; echo "config $c done"; done
 : > gpurun_out/sweeps/sigma.txt
 for s in 0.6 0.4 0.2 0.1 0.05; do for n in 1 4; do
   steps=60; [ "$s" = "0.1" ] && steps=20; [ "$s" = "0.05" ] && steps=8
