@@ -51,9 +51,9 @@ def parse():
     ap.add_argument("--streams", type=int, default=4,
                     help="independent sequences in flight per GPU (one HIP stream + host thread + model replica each); "
                          "one step = one sequence on every stream")
-    ap.add_argument("--pairs", type=int, default=1,
-                    help="1: every stream steps two sequences in lock-step with shared gather-GEMM launches; "
-                         "one step = two sequences on every stream")
+    ap.add_argument("--pairs", type=int, default=4,
+                    help="1: every stream steps two sequences in lock-step with shared gather-GEMM launches (2..4: that "
+                         "many); one step = that many sequences on every stream")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) on the GPU node; gloo for rehearsals")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: all ranks use cuda:0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -152,10 +152,10 @@ def main():
             # every stream gets its own synthetic drive (different seed => different vertex counts per stream)
             from temporal_latticenet_amd.streams import SequenceStreams
             S = max(1, args.streams)
+            per = 1 if args.pairs <= 0 else (2 if args.pairs == 1 else min(args.pairs, 4))
             with quiet:
                 pool = SequenceStreams(model, lambda: build_model(contents).eval(), lambda: make_lattice(contents),
-                                       frames, S, pairs=bool(args.pairs))
-            per = 2 if args.pairs else 1
+                                       frames, S, pairs=per if per > 1 else False)
             per_stream = [frames] + [
                 [(torch.from_numpy(p).cuda(), torch.from_numpy(v).cuda())
                  for p, v in make_sequence(args.points, args.frames, seed=seed + 1000 * i)] for i in range(1, S * per)]
@@ -247,7 +247,8 @@ def main():
                 for k, (cnt, ms, fl) in sorted(shapes.items(), key=lambda kv: -kv[1][1])[:24]:
                     print("    %-22s %4.1f %8.1f %7.2f" % (k, cnt / 3, ms * 1e3 / cnt, fl / ms / 1e9), file=sys.stderr)
 
-    groups = plan.nr_groups if frames_mode else args.gpus * max(1, args.streams) * (2 if args.pairs else 1)
+    per_stream_seqs = 1 if args.pairs <= 0 else (2 if args.pairs == 1 else min(args.pairs, 4))
+    groups = plan.nr_groups if frames_mode else args.gpus * max(1, args.streams) * per_stream_seqs
     clouds = groups * args.steps * args.frames
     value = clouds / elapsed
 
@@ -259,7 +260,7 @@ def main():
         par = ("frames of a sequence sharded over %d ranks (key all-gather + hidden-state hand-off), %d group(s)"
                % (plan.group_size, plan.nr_groups)) if frames_mode else \
             "%d independent sequence stream(s) per GPU, each on its own HIP stream; one step = %s %d-frame sequence%s on " \
-            "every stream (no data-path collective)" % (max(1, args.streams), "two lock-stepped" if args.pairs else "one",
+            "every stream (no data-path collective)" % (max(1, args.streams), ("%d lock-stepped" % per_stream_seqs) if args.pairs else "one",
                                                         args.frames, "s" if args.pairs else "")
         line = {
             "metric": "point-clouds/sec (120k pts, sigma=0.6, 4-frame seq)",

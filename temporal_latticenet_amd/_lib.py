@@ -92,6 +92,7 @@ _PROTOS = {
     "tln_gemm_force_splits": (None, [_i, _i]),
     "tln_gemm_force_direct": (None, [_i]),
     "tln_gather_gemm_pair": (_i, [C.POINTER(GemmCall), C.POINTER(GemmCall), _vp]),
+    "tln_gather_gemm_multi": (_i, [C.POINTER(GemmCall), _i, _vp]),
     "tln_gemm_pair_disable": (None, [_i]),
     "tln_gemm_debug_stamps": (None, [_vp]),
     "tln_gather_gemm_ex": (_i, [_i64, _i, C.POINTER(GemmSrc), C.POINTER(GemmSrc), _vp, _i, _vp, _vp, _i64, _i, _vp, _i64, _vp, _vp]),
@@ -120,6 +121,7 @@ _PROTOS = {
     "tln_program_begin_frame": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, C.POINTER(_i64), _vp]),
     "tln_program_run": (_i, [_vp, _i, _vp, _i64, _i, _vp]),
     "tln_program_run_pair": (_i, [_vp, _vp, _i, _vp, _i64, _vp, _i64, _i, _vp]),
+    "tln_program_run_group": (_i, [C.POINTER(C.c_void_p), _i, _i, C.POINTER(C.c_void_p), C.POINTER(_i64), _i, _vp]),
     "tln_program_capture_gemms": (_i, [_vp, _i]),
     "tln_program_replay_gemms": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(C.c_double),
                                       C.POINTER(C.c_double), _vp]),

@@ -843,14 +843,17 @@ __global__ void __launch_bounds__(768) k_gather_gemm_direct(const GemmArgs g) {
   direct_body<W_NK>(g);
 }
 
-// Two independent products of the same shape class in ONE launch (two sequences stepped in lock-step by one stream,
-// tln_gather_gemm_pair): blockIdx.z selects the problem -- its own operands, tables, row counts, outputs and
-// statistics; weights, N, K and the waves per tile are common.  A block past its problem's rows leaves at once.
-struct GemmArgs2 {
-  GemmArgs a[2];
+// Up to four independent products of the same shape class in ONE launch (the sequences one stream steps in
+// lock-step, tln_gather_gemm_multi; the GRU cell's two products): blockIdx.z selects the problem -- its own operands,
+// tables, row counts, outputs and statistics; N, K and the waves per tile are common.  A block past its problem's
+// rows leaves at once.
+#define TLN_GEMM_MULTI_MAX 4
+template <int NP>
+struct GemmArgsN {
+  GemmArgs a[NP];
 };
-template <bool W_NK>
-__global__ void __launch_bounds__(768) k_gather_gemm_direct_pair(const GemmArgs2 gg) {
+template <bool W_NK, int NP>
+__global__ void __launch_bounds__(768) k_gather_gemm_direct_multi(const GemmArgsN<NP> gg) {
   const GemmArgs& g = gg.a[blockIdx.z];
   if ((int64_t)blockIdx.x * 32 >= g.M) return;
   direct_body<W_NK>(g);
@@ -1220,68 +1223,77 @@ static int run_call(const tln_gemm_call* c, void* stream_) {
                             c->d_out, c->ld_out, c->d_stats, stream_);
 }
 
-extern "C" int tln_gather_gemm_pair(const tln_gemm_call* a, const tln_gemm_call* b, void* stream_) {
-  TLN_REQUIRE(a && b, "null call");
-  if (a->M <= 0 || b->M <= 0 || g_pair_off) {
-    int rc = run_call(a, stream_);
-    return rc ? rc : run_call(b, stream_);
+template <bool W_NK, int NP>
+static int launch_multi(const Prep* q, int n, int G, size_t lds, int64_t mt, hipStream_t s) {
+  GemmArgsN<NP> gg;
+  for (int i = 0; i < NP; ++i) gg.a[i] = q[i < n ? i : 0].g;
+  if (lds > 48 * 1024) {
+    static bool attr = false;  // per instantiation
+    if (!attr) {
+      TLN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gather_gemm_direct_multi<W_NK, NP>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+      attr = true;
+    }
   }
-  Prep qa, qb;
-  int rc = prepare_gemm(a->M, a->N, a->s0, a->s1, a->d_w, a->w_is_nk, a->d_bias, a->d_residual, a->ld_res, a->relu,
-                        a->d_out, a->ld_out, a->d_stats, qa);
-  if (rc) return rc;
-  rc = prepare_gemm(b->M, b->N, b->s0, b->s1, b->d_w, b->w_is_nk, b->d_bias, b->d_residual, b->ld_res, b->relu,
-                    b->d_out, b->ld_out, b->d_stats, qb);
-  if (rc) return rc;
-  const GemmArgs &ga = qa.g, &gb = qb.g;
-  // one launch only for two products of the same shape class that both take the direct kernel as it is
-  bool same = qa.direct && qb.direct && !qa.gn_fallback && !qb.gn_fallback && a->w_is_nk == b->w_is_nk && a->N == b->N &&
-              ga.nsrc == gb.nsrc && qa.nchunks == qb.nchunks && (ga.s[0].gn_part != nullptr) == (gb.s[0].gn_part != nullptr);
-  for (int i = 0; same && i < ga.nsrc; ++i)
-    same = ga.s[i].cin == gb.s[i].cin && ga.s[i].taps == gb.s[i].taps;
-  if (!same) {
-    rc = run_call(a, stream_);
-    return rc ? rc : run_call(b, stream_);
+  dim3 grid((unsigned)mt, (unsigned)tln_cdiv(q[0].g.N, 32), (unsigned)n);
+  hipLaunchKernelGGL((k_gather_gemm_direct_multi<W_NK, NP>), grid, dim3(64 * G), lds, s, gg);
+  return TLN_OK;
+}
+
+extern "C" int tln_gather_gemm_multi(const tln_gemm_call* calls, int n, void* stream_) {
+  TLN_REQUIRE(calls && n >= 1, "bad multi-gemm arguments");
+  auto one_by_one = [&]() {
+    int rc = TLN_OK;
+    for (int i = 0; i < n && !rc; ++i) rc = run_call(&calls[i], stream_);
+    return rc;
+  };
+  if (n == 1 || n > TLN_GEMM_MULTI_MAX || g_pair_off) return one_by_one();
+  for (int i = 0; i < n; ++i)
+    if (calls[i].M <= 0) return one_by_one();
+  Prep q[TLN_GEMM_MULTI_MAX];
+  for (int i = 0; i < n; ++i) {
+    const tln_gemm_call& c = calls[i];
+    int rc = prepare_gemm(c.M, c.N, c.s0, c.s1, c.d_w, c.w_is_nk, c.d_bias, c.d_residual, c.ld_res, c.relu, c.d_out,
+                          c.ld_out, c.d_stats, q[i]);
+    if (rc) return rc;
   }
+  // one launch only for products of the same shape class that all take the direct kernel as it is
+  bool same = true;
+  int64_t mmax = 0, tiles = 0;
+  for (int i = 0; i < n && same; ++i) {
+    const GemmArgs &g0 = q[0].g, &gi = q[i].g;
+    same = q[i].direct && !q[i].gn_fallback && calls[i].w_is_nk == calls[0].w_is_nk && gi.N == g0.N &&
+           gi.nsrc == g0.nsrc && q[i].nchunks == q[0].nchunks && (gi.s[0].gn_part != nullptr) == (g0.s[0].gn_part != nullptr);
+    for (int k = 0; same && k < g0.nsrc; ++k) same = gi.s[k].cin == g0.s[k].cin && gi.s[k].taps == g0.s[k].taps;
+    if (gi.M > mmax) mmax = gi.M;
+    tiles += tln_cdiv(gi.M, 32) * tln_cdiv(gi.N, 32);
+  }
+  if (!same) return one_by_one();
   hipStream_t s = (hipStream_t)stream_;
-  const int64_t mt = tln_cdiv(a->M > b->M ? a->M : b->M, 32);
-  // waves per tile from the work of BOTH problems (they share the CUs)
-  const int64_t tiles = (tln_cdiv(a->M, 32) + tln_cdiv(b->M, 32)) * tln_cdiv(a->N, 32);
-  int G = choose_groups(tiles, qa.nchunks);
+  // waves per tile from the work of ALL problems (they share the CUs)
+  int G = choose_groups(tiles, q[0].nchunks);
   if (G < 1) G = 1;
   if (G > 12) G = 12;
-  if (G > qa.nchunks) G = qa.nchunks;
-  size_t lds = direct_lds_bytes(ga, G);
-  const size_t ldb = direct_lds_bytes(gb, G);
-  if (ldb > lds) lds = ldb;
-  TLN_REQUIRE(lds <= 96 * 1024, "direct gemm: LDS %zu B", lds);
-  GemmArgs2 gg;
-  gg.a[0] = ga;
-  gg.a[1] = gb;
-  dim3 grid((unsigned)mt, (unsigned)tln_cdiv(a->N, 32), 2);
-  if (a->w_is_nk) {
-    if (lds > 48 * 1024) {
-      static bool attr = false;
-      if (!attr) {
-        TLN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gather_gemm_direct_pair<true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-        attr = true;
-      }
-    }
-    hipLaunchKernelGGL(k_gather_gemm_direct_pair<true>, grid, dim3(64 * G), lds, s, gg);
-  } else {
-    if (lds > 48 * 1024) {
-      static bool attr = false;
-      if (!attr) {
-        TLN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gather_gemm_direct_pair<false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-        attr = true;
-      }
-    }
-    hipLaunchKernelGGL(k_gather_gemm_direct_pair<false>, grid, dim3(64 * G), lds, s, gg);
+  if (G > q[0].nchunks) G = q[0].nchunks;
+  size_t lds = 0;
+  for (int i = 0; i < n; ++i) {
+    const size_t l = direct_lds_bytes(q[i].g, G);
+    if (l > lds) lds = l;
   }
+  TLN_REQUIRE(lds <= 96 * 1024, "direct gemm: LDS %zu B", lds);
+  const int64_t mt = tln_cdiv(mmax, 32);
+  int rc;
+  if (calls[0].w_is_nk) rc = n <= 2 ? launch_multi<true, 2>(q, n, G, lds, mt, s) : launch_multi<true, 4>(q, n, G, lds, mt, s);
+  else rc = n <= 2 ? launch_multi<false, 2>(q, n, G, lds, mt, s) : launch_multi<false, 4>(q, n, G, lds, mt, s);
+  if (rc) return rc;
   TLN_LAUNCH_CHECK();
   return TLN_OK;
+}
+
+extern "C" int tln_gather_gemm_pair(const tln_gemm_call* a, const tln_gemm_call* b, void* stream_) {
+  TLN_REQUIRE(a && b, "null call");
+  const tln_gemm_call two[2] = {*a, *b};
+  return tln_gather_gemm_multi(two, 2, stream_);
 }
 
 extern "C" int tln_gather_gemm(int64_t M, int N, const tln_gemm_src* s0, const tln_gemm_src* s1, const float* d_w,

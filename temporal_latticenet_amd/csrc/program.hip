@@ -698,84 +698,79 @@ extern "C" int tln_program_run(tln_program_t* p, int early, float* d_out, int64_
   return rc;
 }
 
-// ---- pair mode: two sequences stepped in lock-step on one stream, their gather-GEMM ops sharing launches -----------
+// ---- group mode: 2..4 sequences stepped in lock-step on one stream, their gather-GEMM ops sharing launches --------
 namespace {
-int launch_pending(tln_program* a, tln_program* b, hipStream_t s) {
-  auto as_call = [](const GemmCall& c) {
-    return tln_gemm_call{c.M, c.N, &c.a[0], c.two ? &c.a[1] : nullptr, c.w, c.w_is_nk, c.bias, c.res, c.ld_res,
-                         c.relu, c.out, c.ld_out, c.stats};
-  };
-  int rc = TLN_OK;
-  if (a->has_pending && b->has_pending) {
-    const tln_gemm_call ca = as_call(a->pending), cb = as_call(b->pending);
-    rc = tln_gather_gemm_pair(&ca, &cb, s);
-  } else {
-    for (tln_program* p : {a, b})
-      if (p->has_pending && !rc) {
-        const GemmCall& c = p->pending;
-        rc = tln_gather_gemm_ex(c.M, c.N, &c.a[0], c.two ? &c.a[1] : nullptr, c.w, c.w_is_nk, c.bias, c.res, c.ld_res,
-                                c.relu, c.out, c.ld_out, c.stats, s);
-      }
-  }
-  for (tln_program* p : {a, b}) {
+constexpr int kMaxGroup = 4;
+
+int launch_pending(tln_program* const* pp, int n, hipStream_t s) {
+  tln_gemm_call calls[kMaxGroup];
+  int m = 0;
+  for (int k = 0; k < n; ++k)
+    if (pp[k]->has_pending) {
+      const GemmCall& c = pp[k]->pending;
+      calls[m++] = tln_gemm_call{c.M, c.N, &c.a[0], c.two ? &c.a[1] : nullptr, c.w, c.w_is_nk, c.bias, c.res, c.ld_res,
+                                 c.relu, c.out, c.ld_out, c.stats};
+    }
+  int rc = m ? tln_gather_gemm_multi(calls, m, s) : TLN_OK;
+  for (int k = 0; k < n; ++k) {
+    tln_program* p = pp[k];
     if (p->has_pending && p->capture && p->pending.M > 0) p->calls.push_back(p->pending);
     p->has_pending = false;
   }
   return rc;
 }
 
-// ops [begin, end) of both programs: everything but the products per program, the products pairwise
-int walk_pair(tln_program* pa, tln_program* pb, int early, float* const d_out[2], const int64_t out_rows[2],
-              const int out_cols[2], hipStream_t s, int begin, int end, bool fresh) {
-  tln_program* pp[2] = {pa, pb};
-  int at[2] = {begin, begin};
+// ops [begin, end) of all programs: everything but the products per program, the products together
+int walk_group(tln_program* const* pp, int n, int early, float* const* d_out, const int64_t* out_rows, int out_cols,
+               hipStream_t s, int begin, int end, bool fresh) {
+  int at[kMaxGroup];
+  for (int k = 0; k < n; ++k) at[k] = begin;
   bool first = true;
   int rc = TLN_OK;
   for (;;) {
     bool any = false;
-    for (int k = 0; k < 2 && !rc; ++k) {
+    for (int k = 0; k < n && !rc; ++k) {
       tln_program* p = pp[k];
       p->has_pending = false;
       if (at[k] >= end || (p->w_finished && !(fresh && first))) continue;
       p->defer = true;
-      rc = walk(p, false, early, d_out[k], out_rows[k], out_cols[k], s, at[k], end, fresh && first);
+      rc = walk(p, false, early, d_out[k], out_rows[k], out_cols, s, at[k], end, fresh && first);
       p->defer = false;
       at[k] = p->w_next;
       any = any || p->has_pending;
     }
     first = false;
-    if (rc) break;
-    if (!any) break;
-    rc = launch_pending(pa, pb, s);
+    if (rc || !any) break;
+    rc = launch_pending(pp, n, s);
     if (rc) break;
   }
-  for (tln_program* p : pp) {
-    p->defer = false;
-    p->has_pending = false;
+  for (int k = 0; k < n; ++k) {
+    pp[k]->defer = false;
+    pp[k]->has_pending = false;
   }
   return rc;
 }
 }  // namespace
 
-extern "C" int tln_program_run_pair(tln_program_t* pa, tln_program_t* pb, int early, float* d_out_a, int64_t out_rows_a,
-                                    float* d_out_b, int64_t out_rows_b, int out_cols, void* stream_) {
-  TLN_REQUIRE(pa && pb && pa != pb && pa->frame_open && pb->frame_open, "tln_program_run_pair without two open frames");
-  TLN_REQUIRE(pa->ops.size() == pb->ops.size() && pa->split == pb->split, "the two programs differ");
+extern "C" int tln_program_run_group(tln_program_t* const* pp, int n, int early, float* const* d_out,
+                                     const int64_t* out_rows, int out_cols, void* stream_) {
+  TLN_REQUIRE(pp && d_out && out_rows && n >= 1 && n <= kMaxGroup, "bad group of %d programs", n);
+  for (int k = 0; k < n; ++k) {
+    TLN_REQUIRE(pp[k] && pp[k]->frame_open, "tln_program_run_group: program %d has no open frame", k);
+    TLN_REQUIRE(pp[k]->ops.size() == pp[0]->ops.size() && pp[k]->split == pp[0]->split, "the programs differ");
+    for (int j = 0; j < k; ++j) TLN_REQUIRE(pp[j] != pp[k], "the same program twice");
+  }
   hipStream_t s = (hipStream_t)stream_;
-  const int n_ops = (int)pa->ops.size();
-  tln_program* pp[2] = {pa, pb};
-  float* const d_out[2] = {d_out_a, d_out_b};
-  const int64_t out_rows[2] = {out_rows_a, out_rows_b};
-  const int out_cols2[2] = {out_cols, out_cols};
+  const int n_ops = (int)pp[0]->ops.size();
   int rc = TLN_OK;
-  for (int k = 0; k < 2 && !rc; ++k) {
+  for (int k = 0; k < n && !rc; ++k) {
     rc = walk(pp[k], true, early, nullptr, out_rows[k], out_cols, s, 0, n_ops, true);
     if (!rc) rc = ensure_buf(pp[k]->arena, pp[k]->alloc.high + kAlign, s);
     pp[k]->calls.clear();
   }
   if (rc) return rc;
-  rc = walk_pair(pa, pb, early, d_out, out_rows, out_cols2, s, 0, pa->split, true);
-  for (int k = 0; k < 2; ++k) {
+  rc = walk_group(pp, n, early, d_out, out_rows, out_cols, s, 0, pp[0]->split, true);
+  for (int k = 0; k < n; ++k) {
     tln_program* p = pp[k];
     int rc2 = tln_lattice_prepare_levels_finish(p->lat, s);
     if (rc == TLN_OK) rc = rc2;
@@ -788,12 +783,20 @@ extern "C" int tln_program_run_pair(tln_program_t* pa, tln_program_t* pb, int ea
       p->exact_known = true;
     }
   }
-  if (rc == TLN_OK) rc = walk_pair(pa, pb, early, d_out, out_rows, out_cols2, s, pa->split, n_ops, false);
-  for (int k = 0; k < 2; ++k) {
+  if (rc == TLN_OK) rc = walk_group(pp, n, early, d_out, out_rows, out_cols, s, pp[0]->split, n_ops, false);
+  for (int k = 0; k < n; ++k) {
     if (rc == TLN_OK) commit_states(pp[k]);
     pp[k]->frame_open = false;
   }
   return rc;
+}
+
+extern "C" int tln_program_run_pair(tln_program_t* pa, tln_program_t* pb, int early, float* d_out_a, int64_t out_rows_a,
+                                    float* d_out_b, int64_t out_rows_b, int out_cols, void* stream_) {
+  tln_program_t* const pp[2] = {pa, pb};
+  float* const outs[2] = {d_out_a, d_out_b};
+  const int64_t rows[2] = {out_rows_a, out_rows_b};
+  return tln_program_run_group(pp, 2, early, outs, rows, out_cols, stream_);
 }
 
 // ---- measurement: the gather-GEMM launches of the last frame, replayed back to back between two HIP events ------

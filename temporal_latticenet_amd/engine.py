@@ -429,19 +429,24 @@ class FrameProgram:
         return early, out, (positions, values)        # the inputs stay alive until the frame has been enqueued
 
     @staticmethod
-    def run_frame_pair(progs, lattices, positions, values, reset_hashmap, early_return):
-        """two sequences in lock-step on the current stream (tln_program_run_pair): -> [(tensor, ls), (tensor, ls)]"""
-        a, b = progs
-        ea, out_a, keep_a = a._begin(lattices[0], positions[0], values[0], reset_hashmap, early_return)
-        eb, out_b, keep_b = b._begin(lattices[1], positions[1], values[1], reset_hashmap, early_return)
-        assert ea == eb and out_a.shape[1] == out_b.shape[1]
-        _lib.check(_lib.lib().tln_program_run_pair(a._h, b._h, 1 if ea else 0, out_a.data_ptr(), out_a.shape[0],
-                                                   out_b.data_ptr(), out_b.shape[0], out_a.shape[1], stream_ptr()),
-                   "tln_program_run_pair")
-        del keep_a, keep_b
-        lattices[0].set_values(out_a)
-        lattices[1].set_values(out_b)
-        return [(out_a, lattices[0]), (out_b, lattices[1])]
+    def run_frame_group(progs, lattices, positions, values, reset_hashmap, early_return):
+        """2..4 sequences in lock-step on the current stream (tln_program_run_group): -> [(tensor, ls), ...]"""
+        n = len(progs)
+        begun = [p._begin(ls, pos, val, reset_hashmap, early_return)
+                 for p, ls, pos, val in zip(progs, lattices, positions, values)]
+        early, outs = begun[0][0], [x[1] for x in begun]
+        assert all(x[0] == early for x in begun) and all(o.shape[1] == outs[0].shape[1] for o in outs)
+        hs = (C.c_void_p * n)(*[p._h for p in progs])
+        ptrs = (C.c_void_p * n)(*[o.data_ptr() for o in outs])
+        rows = (C.c_int64 * n)(*[o.shape[0] for o in outs])
+        _lib.check(_lib.lib().tln_program_run_group(hs, n, 1 if early else 0, ptrs, rows, outs[0].shape[1], stream_ptr()),
+                   "tln_program_run_group")
+        del begun                                      # the inputs stayed alive until the frames were enqueued
+        for ls, o in zip(lattices, outs):
+            ls.set_values(o)
+        return list(zip(outs, lattices))
+
+    run_frame_pair = run_frame_group
 
     def capture_gemms(self, enable=True):
         _lib.check(_lib.lib().tln_program_capture_gemms(self._h, 1 if enable else 0), "tln_program_capture_gemms")

@@ -46,11 +46,14 @@ class SequenceStreams:
     the per-sequence outputs of the last frame."""
 
     def __init__(self, base_model, make_model, make_lattice, warm_sequence, n_streams, pairs=False):
-        """pairs: every stream steps TWO sequences in lock-step (models.forward_pair: their gather-GEMM launches are
-        shared), i.e. 2 * n_streams sequences in flight -- the GPU runs at most four streams of a process at full rate"""
-        self.pairs = bool(pairs)
+        """pairs: True / 2..4: every stream steps that many sequences in lock-step (models.forward_group: their
+        gather-GEMM launches are shared), i.e. pairs * n_streams sequences in flight -- the GPU runs at most four
+        streams of a process at full rate"""
+        self.group = 1 if not pairs else (2 if pairs is True else int(pairs))   # sequences per stream in lock-step
+        assert 1 <= self.group <= 4
+        self.pairs = self.group > 1
         self.n_streams = n_streams
-        n_models = n_streams * (2 if self.pairs else 1)
+        n_models = n_streams * self.group
         self.models = [base_model]
         self.make_lattice = make_lattice
         quiet = contextlib.redirect_stdout(io.StringIO())
@@ -95,20 +98,21 @@ class SequenceStreams:
             outs = []
             with torch.no_grad(), torch.cuda.stream(self.streams[i]):
                 if self.pairs:
-                    from .models import forward_pair
-                    models, lats = self.models[2 * i:2 * i + 2], self.lattices[2 * i:2 * i + 2]
+                    from .models import forward_group
+                    g = self.group
+                    models, lats = self.models[g * i:g * i + g], self.lattices[g * i:g * i + g]
                     k = 0
-                    while k + 1 < len(sequences) and len(sequences[k]) == len(sequences[k + 1]):
-                        sa, sb = sequences[k], sequences[k + 1]
-                        for t in range(len(sa)):
-                            res = forward_pair(models, lats, [sa[t][0], sb[t][0]], [sa[t][1], sb[t][1]],
-                                               t != len(sa) - 1)
-                            lats = [res[0][2], res[1][2]]
+                    while k + g <= len(sequences) and all(len(sequences[k + j]) == len(sequences[k]) for j in range(g)):
+                        grp = sequences[k:k + g]
+                        for t in range(len(grp[0])):
+                            res = forward_group(models, lats, [sq[t][0] for sq in grp], [sq[t][1] for sq in grp],
+                                                t != len(grp[0]) - 1)
+                            lats = [r[2] for r in res]
                         for mod in models:
                             mod.reset_sequence()
                         if keep_outputs:
-                            outs += [res[0][1], res[1][1]]
-                        k += 2
+                            outs += [r[1] for r in res]
+                        k += g
                     rest, model, lat = sequences[k:], models[0], lats[0]
                 else:
                     rest, model, lat = sequences, self.models[i], self.lattices[i]

@@ -76,3 +76,35 @@ def test_lockstep_pairs_match_the_single_sequence_results(gpu):
     finally:
         lib.tln_gemm_pair_disable(0)
         pool.close()
+
+
+@pytest.mark.parametrize("group", [3, 4])
+def test_lockstep_groups_of_three_and_four(gpu, group):
+    """three / four sequences per stream in lock-step (one launch for the products of all of them), a leftover that
+    runs solo: bitwise equal to the solo runs with separate launches, float rounding with shared ones"""
+    from temporal_latticenet_amd import _lib
+    contents = make_config(rnn_modules=("gru", "gru", "aflow", "gru"), frames=2, sigma=0.7)
+    S = 2
+    seqs = [[(torch.from_numpy(p).to(gpu), torch.from_numpy(v).to(gpu)) for p, v in make_sequence(6000 + 900 * s, 2, seed=270 + s)]
+            for s in range(2 * group + 1)]
+    model = build_model(contents).eval()
+    _alone(model, contents, seqs[0])
+    randomize_parameters(model, seed=29)
+    want = [_alone(model, contents, s) for s in seqs]
+    pool = SequenceStreams(model, lambda: build_model(contents).eval(), lambda: make_lattice(contents), seqs[0], S, pairs=group)
+    assert len(pool.models) == group * S
+    lib = _lib.lib()
+    try:
+        for off in (1, 0):
+            lib.tln_gemm_pair_disable(off)
+            got = pool.run([seqs[:group] + seqs[2 * group:], seqs[group:2 * group]], keep_outputs=True)
+            flat = got[0][:group] + got[1] + got[0][group:]
+            for k, (g, w) in enumerate(zip(flat, want)):
+                if off:
+                    assert torch.equal(g, w), "sequence %d, separate launches" % k
+                else:
+                    err = float((g - w).abs().max())
+                    assert err <= 2e-4 * max(1.0, float(w.abs().max())), "sequence %d: %.3e" % (k, err)
+    finally:
+        lib.tln_gemm_pair_disable(0)
+        pool.close()
