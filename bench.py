@@ -51,8 +51,8 @@ def parse():
     ap.add_argument("--streams", type=int, default=4,
                     help="independent sequences in flight per GPU (one HIP stream + host thread + model replica each); "
                          "one step = one sequence on every stream")
-    ap.add_argument("--pairs", type=int, default=4,
-                    help="1: every stream steps two sequences in lock-step with shared gather-GEMM launches (2..4: that "
+    ap.add_argument("--pairs", type=int, default=8,
+                    help="1: every stream steps two sequences in lock-step with shared gather-GEMM launches (2..8: that "
                          "many); one step = that many sequences on every stream")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) on the GPU node; gloo for rehearsals")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: all ranks use cuda:0")
@@ -152,13 +152,26 @@ def main():
             # every stream gets its own synthetic drive (different seed => different vertex counts per stream)
             from temporal_latticenet_amd.streams import SequenceStreams
             S = max(1, args.streams)
-            per = 1 if args.pairs <= 0 else (2 if args.pairs == 1 else min(args.pairs, 4))
+            per = 1 if args.pairs <= 0 else (2 if args.pairs == 1 else min(args.pairs, 8))
             with quiet:
                 pool = SequenceStreams(model, lambda: build_model(contents).eval(), lambda: make_lattice(contents),
                                        frames, S, pairs=per if per > 1 else False)
-            per_stream = [frames] + [
+            # one ray-cast drive per stream (a different seed each: different vertex counts); the further sequences of a
+            # stream's lock-step group are that drive turned about the vertical axis (again other vertex counts, without
+            # paying the CPU ray casting 32 times)
+            drives = [frames] + [
                 [(torch.from_numpy(p).cuda(), torch.from_numpy(v).cuda())
-                 for p, v in make_sequence(args.points, args.frames, seed=seed + 1000 * i)] for i in range(1, S * per)]
+                 for p, v in make_sequence(args.points, args.frames, seed=seed + 1000 * i)] for i in range(1, S)]
+
+            def turned(drive, j):
+                if j == 0:
+                    return drive
+                import math
+                c, s_ = math.cos(0.7 * j), math.sin(0.7 * j)
+                rot = torch.tensor([[c, 0.0, s_], [0.0, 1.0, 0.0], [-s_, 0.0, c]], device="cuda")
+                return [((p @ rot.T).contiguous(), v) for p, v in drive]
+
+            per_stream = [turned(drives[i], j) for i in range(S) for j in range(per)]
 
             def run_steps(n):
                 pool.run([per_stream[per * i:per * i + per] * n for i in range(S)])
@@ -247,7 +260,7 @@ def main():
                 for k, (cnt, ms, fl) in sorted(shapes.items(), key=lambda kv: -kv[1][1])[:24]:
                     print("    %-22s %4.1f %8.1f %7.2f" % (k, cnt / 3, ms * 1e3 / cnt, fl / ms / 1e9), file=sys.stderr)
 
-    per_stream_seqs = 1 if args.pairs <= 0 else (2 if args.pairs == 1 else min(args.pairs, 4))
+    per_stream_seqs = 1 if args.pairs <= 0 else (2 if args.pairs == 1 else min(args.pairs, 8))
     groups = plan.nr_groups if frames_mode else args.gpus * max(1, args.streams) * per_stream_seqs
     clouds = groups * args.steps * args.frames
     value = clouds / elapsed

@@ -160,7 +160,7 @@ typedef struct {
   void* d_stats;
 } tln_gemm_call;
 int tln_gather_gemm_pair(const tln_gemm_call* a, const tln_gemm_call* b, void* stream);
-/* the same for n = 1..4 calls (more than 4: one launch each) */
+/* the same for n = 1..8 calls (more than 8: one launch each) */
 int tln_gather_gemm_multi(const tln_gemm_call* calls, int n, void* stream);
 /* test hook: run tln_gather_gemm_pair as two separate launches (1) or as designed (0) */
 void tln_gemm_pair_disable(int off);
@@ -372,7 +372,7 @@ int tln_program_replay_gemms(tln_program_t* p, int reps, double* ms_total, int64
  * tln_program_run up to the K-summation order of the paired products.  Both outputs have out_cols columns. */
 int tln_program_run_pair(tln_program_t* a, tln_program_t* b, int early, float* d_out_a, int64_t out_rows_a,
                          float* d_out_b, int64_t out_rows_b, int out_cols, void* stream);
-/* the same for a group of n = 1..4 programs (tln_gather_gemm_multi) */
+/* the same for a group of n = 1..8 programs (tln_gather_gemm_multi) */
 int tln_program_run_group(tln_program_t* const* programs, int n, int early, float* const* d_out,
                           const int64_t* out_rows, int out_cols, void* stream);
 /* device pointers of the current frame's K1 outputs ([4N, 3+val_dim+1], [4N], [4N]); valid until the next frame */

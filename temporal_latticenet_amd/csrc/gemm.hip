@@ -843,11 +843,11 @@ __global__ void __launch_bounds__(768) k_gather_gemm_direct(const GemmArgs g) {
   direct_body<W_NK>(g);
 }
 
-// Up to four independent products of the same shape class in ONE launch (the sequences one stream steps in
+// Up to eight independent products of the same shape class in ONE launch (the sequences one stream steps in
 // lock-step, tln_gather_gemm_multi; the GRU cell's two products): blockIdx.z selects the problem -- its own operands,
 // tables, row counts, outputs and statistics; N, K and the waves per tile are common.  A block past its problem's
 // rows leaves at once.
-#define TLN_GEMM_MULTI_MAX 4
+#define TLN_GEMM_MULTI_MAX 8
 template <int NP>
 struct GemmArgsN {
   GemmArgs a[NP];
@@ -1283,8 +1283,12 @@ extern "C" int tln_gather_gemm_multi(const tln_gemm_call* calls, int n, void* st
   TLN_REQUIRE(lds <= 96 * 1024, "direct gemm: LDS %zu B", lds);
   const int64_t mt = tln_cdiv(mmax, 32);
   int rc;
-  if (calls[0].w_is_nk) rc = n <= 2 ? launch_multi<true, 2>(q, n, G, lds, mt, s) : launch_multi<true, 4>(q, n, G, lds, mt, s);
-  else rc = n <= 2 ? launch_multi<false, 2>(q, n, G, lds, mt, s) : launch_multi<false, 4>(q, n, G, lds, mt, s);
+  if (calls[0].w_is_nk)
+    rc = n <= 2 ? launch_multi<true, 2>(q, n, G, lds, mt, s)
+                : (n <= 4 ? launch_multi<true, 4>(q, n, G, lds, mt, s) : launch_multi<true, 8>(q, n, G, lds, mt, s));
+  else
+    rc = n <= 2 ? launch_multi<false, 2>(q, n, G, lds, mt, s)
+                : (n <= 4 ? launch_multi<false, 4>(q, n, G, lds, mt, s) : launch_multi<false, 8>(q, n, G, lds, mt, s));
   if (rc) return rc;
   TLN_LAUNCH_CHECK();
   return TLN_OK;

@@ -698,9 +698,9 @@ extern "C" int tln_program_run(tln_program_t* p, int early, float* d_out, int64_
   return rc;
 }
 
-// ---- group mode: 2..4 sequences stepped in lock-step on one stream, their gather-GEMM ops sharing launches --------
+// ---- group mode: 2..8 sequences stepped in lock-step on one stream, their gather-GEMM ops sharing launches --------
 namespace {
-constexpr int kMaxGroup = 4;
+constexpr int kMaxGroup = 8;
 
 int launch_pending(tln_program* const* pp, int n, hipStream_t s) {
   tln_gemm_call calls[kMaxGroup];

@@ -430,7 +430,7 @@ class FrameProgram:
 
     @staticmethod
     def run_frame_group(progs, lattices, positions, values, reset_hashmap, early_return):
-        """2..4 sequences in lock-step on the current stream (tln_program_run_group): -> [(tensor, ls), ...]"""
+        """2..8 sequences in lock-step on the current stream (tln_program_run_group): -> [(tensor, ls), ...]"""
         n = len(progs)
         begun = [p._begin(ls, pos, val, reset_hashmap, early_return)
                  for p, ls, pos, val in zip(progs, lattices, positions, values)]

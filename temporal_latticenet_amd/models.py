@@ -349,14 +349,14 @@ class LNN_SEQ(torch.nn.Module):
 
 
 def forward_group(models, lattices, positions, values, early_return=False):
-    """One frame of 2..4 independent sequences in lock-step on the current stream (inference): every gather-GEMM op of
+    """One frame of 2..8 independent sequences in lock-step on the current stream (inference): every gather-GEMM op of
     their frame programs is issued as one launch (engine.FrameProgram.run_frame_group, tln_program_run_group).  Same
     return value per model as LNN_SEQ.forward; falls back to one forward call per model when a model cannot take the
     frame program for this frame."""
     from . import engine
     resets = [not (mod.sequence_learning and not mod.first_sequence) for mod in models]
     progs = [mod._program_for_this_frame(False) for mod in models]
-    if len(models) < 2 or len(models) > 4 or any(p is None for p in progs) or any(r != resets[0] for r in resets) or \
+    if len(models) < 2 or len(models) > 8 or any(p is None for p in progs) or any(r != resets[0] for r in resets) or \
             len(set(id(p) for p in progs)) != len(progs):
         return [mod(ls, p, v, early_return, False) for mod, ls, p, v in zip(models, lattices, positions, values)]
     res = engine.FrameProgram.run_frame_group(progs, lattices, positions, values, resets[0], early_return)

@@ -46,11 +46,11 @@ class SequenceStreams:
     the per-sequence outputs of the last frame."""
 
     def __init__(self, base_model, make_model, make_lattice, warm_sequence, n_streams, pairs=False):
-        """pairs: True / 2..4: every stream steps that many sequences in lock-step (models.forward_group: their
+        """pairs: True / 2..8: every stream steps that many sequences in lock-step (models.forward_group: their
         gather-GEMM launches are shared), i.e. pairs * n_streams sequences in flight -- the GPU runs at most four
         streams of a process at full rate"""
         self.group = 1 if not pairs else (2 if pairs is True else int(pairs))   # sequences per stream in lock-step
-        assert 1 <= self.group <= 4
+        assert 1 <= self.group <= 8
         self.pairs = self.group > 1
         self.n_streams = n_streams
         n_models = n_streams * self.group
@@ -62,8 +62,9 @@ class SequenceStreams:
                 m = make_model()
                 m.train(base_model.training)
                 lat = make_lattice()
-                for t, (p, v) in enumerate(warm_sequence):           # creates the lazily built parameters
-                    m(lat, p, v, t != len(warm_sequence) - 1, False)
+                for t, (p, v) in enumerate(warm_sequence):           # creates the lazily built parameters (their
+                    k = min(p.shape[0], 4096)                        # shapes depend on channel counts only)
+                    m(lat, p[:k], v[:k] if v is not None else None, t != len(warm_sequence) - 1, False)
                 m.reset_sequence()
             self.models.append(share_parameters(m, base_model))
         self.streams = [torch.cuda.Stream() for _ in range(n_streams)]

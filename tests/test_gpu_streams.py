@@ -78,14 +78,14 @@ def test_lockstep_pairs_match_the_single_sequence_results(gpu):
         pool.close()
 
 
-@pytest.mark.parametrize("group", [3, 4])
+@pytest.mark.parametrize("group", [3, 4, 8])
 def test_lockstep_groups_of_three_and_four(gpu, group):
     """three / four sequences per stream in lock-step (one launch for the products of all of them), a leftover that
     runs solo: bitwise equal to the solo runs with separate launches, float rounding with shared ones"""
     from temporal_latticenet_amd import _lib
     contents = make_config(rnn_modules=("gru", "gru", "aflow", "gru"), frames=2, sigma=0.7)
     S = 2
-    seqs = [[(torch.from_numpy(p).to(gpu), torch.from_numpy(v).to(gpu)) for p, v in make_sequence(6000 + 900 * s, 2, seed=270 + s)]
+    seqs = [[(torch.from_numpy(p).to(gpu), torch.from_numpy(v).to(gpu)) for p, v in make_sequence(5000 + 400 * s, 2, seed=270 + s)]
             for s in range(2 * group + 1)]
     model = build_model(contents).eval()
     _alone(model, contents, seqs[0])
