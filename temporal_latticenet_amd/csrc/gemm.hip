@@ -852,6 +852,7 @@ template <int NP>
 struct GemmArgsN {
   GemmArgs a[NP];
 };
+static_assert(sizeof(GemmArgsN<TLN_GEMM_MULTI_MAX>) <= 4096, "the argument block must fit the kernarg segment");
 template <bool W_NK, int NP>
 __global__ void __launch_bounds__(768) k_gather_gemm_direct_multi(const GemmArgsN<NP> gg) {
   const GemmArgs& g = gg.a[blockIdx.z];
