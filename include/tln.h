@@ -52,6 +52,14 @@ int tln_lattice_insert_keys(tln_lattice_t* l, const int32_t* d_keys, int64_t n, 
 int tln_distribute(tln_lattice_t* l, const float* d_positions, const float* d_values, int64_t n,
                    int val_dim, int subtract_mean, float* d_distributed, int32_t* d_indices,
                    float* d_weights, void* stream);
+/* the same in two halves: _begin enqueues the insertion / numbering and starts the fetch of the vertex counters,
+ * _finish waits for that fetch only and enqueues the CSR and the mean subtraction.  A caller with several lattices
+ * on one stream (lock-step groups) begins all of them before it finishes the first: one wait instead of one per
+ * lattice.  The buffers given to _begin must stay valid until _finish has returned. */
+int tln_distribute_begin(tln_lattice_t* l, const float* d_positions, const float* d_values, int64_t n,
+                   int val_dim, int subtract_mean, float* d_distributed, int32_t* d_indices,
+                   float* d_weights, void* stream);
+int tln_distribute_finish(tln_lattice_t* l, void* stream);
 
 /* rebuild the CSR from caller-supplied indices (R rows, -1 folded into the tail bucket) */
 int tln_build_csr(tln_lattice_t* l, const int32_t* d_indices, int64_t rows, void* stream);
@@ -356,6 +364,11 @@ int tln_program_reset(tln_program_t* p);
 int tln_program_begin_frame(tln_program_t* p, tln_lattice_t* l, const float* d_positions, const float* d_values,
                             int64_t n, int val_dim, int reset_hashmap, int subtract_mean, int64_t* v_out,
                             void* stream);
+/* the same in two halves (tln_distribute_begin / _finish): a lock-step group starts the frames of all its programs
+ * before it finishes the first, so that the host waits for vertex counters once instead of once per sequence */
+int tln_program_begin_frame_start(tln_program_t* p, tln_lattice_t* l, const float* d_positions, const float* d_values,
+                                  int64_t n, int val_dim, int reset_hashmap, int subtract_mean, void* stream);
+int tln_program_begin_frame_finish(tln_program_t* p, int64_t* v_out, void* stream);
 /* the rest of the frame.  early != 0: stop at the program's STOP_IF_EARLY op and copy that slot to d_out;
  * else the TLN_SLOT_OUT slot is d_out.  d_out must hold out_rows x out_cols floats (checked). */
 int tln_program_run(tln_program_t* p, int early, float* d_out, int64_t out_rows, int out_cols, void* stream);

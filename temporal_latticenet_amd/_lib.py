@@ -74,6 +74,8 @@ _PROTOS = {
     "tln_lattice_keys": (_i, [_vp, _vp, _i64, _vp]),
     "tln_lattice_insert_keys": (_i, [_vp, _vp, _i64, _vp, _vp]),
     "tln_distribute": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp]),
+    "tln_distribute_begin": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp]),
+    "tln_distribute_finish": (_i, [_vp, _vp]),
     "tln_build_csr": (_i, [_vp, _vp, _i64, _vp]),
     "tln_lattice_csr": (_i, [_vp, _vp, _vp, _vp, C.POINTER(_i64), _vp]),
     "tln_pointnet_pool": (_i, [_vp, _vp, _i64, _i, _i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i), _i, _vp, _vp]),
@@ -119,6 +121,8 @@ _PROTOS = {
     "tln_program_destroy": (_i, [_vp]),
     "tln_program_reset": (_i, [_vp]),
     "tln_program_begin_frame": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, C.POINTER(_i64), _vp]),
+    "tln_program_begin_frame_start": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
+    "tln_program_begin_frame_finish": (_i, [_vp, C.POINTER(_i64), _vp]),
     "tln_program_run": (_i, [_vp, _i, _vp, _i64, _i, _vp]),
     "tln_program_run_pair": (_i, [_vp, _vp, _i, _vp, _i64, _vp, _i64, _i, _vp]),
     "tln_program_run_group": (_i, [C.POINTER(C.c_void_p), _i, _i, C.POINTER(C.c_void_p), C.POINTER(_i64), _i, _vp]),

@@ -57,6 +57,14 @@ struct tln_lattice {
   // tln_lattice_prepare_levels_begin without its _finish yet: coarse counters are in flight (root level only)
   int levels_pending = 0;
   hipEvent_t levels_event = nullptr;
+  // tln_distribute_begin .. _finish: the counter fetch in flight and what the second half needs
+  hipEvent_t ctr_event = nullptr;
+  bool dist_pending = false;
+  const float* dist_pos = nullptr;
+  float* dist_out = nullptr;
+  const int32_t* dist_idx = nullptr;
+  int64_t dist_rows = 0;
+  int dist_val_dim = 0, dist_subtract = 0;
   // per-call row workspace
   int64_t rows_cap = 0;
   int32_t* row_slot = nullptr;
@@ -226,6 +234,10 @@ extern "C" int tln_lattice_create(tln_lattice_t** out, int pos_dim, const double
 }
 
 extern "C" int tln_lattice_destroy(tln_lattice_t* l) {
+  if (l && l->ctr_event) {
+    (void)hipEventDestroy(l->ctr_event);
+    l->ctr_event = nullptr;
+  }
   if (l && l->levels_event) {
     (void)hipEventDestroy(l->levels_event);
     l->levels_event = nullptr;
@@ -1198,12 +1210,14 @@ __global__ void __launch_bounds__(256) k_subtract_rows(const float* __restrict__
   d[2] = pos[3 * p + 2] - mean[3 * v + 2];
 }
 
-extern "C" int tln_distribute(tln_lattice_t* l, const float* d_positions, const float* d_values, int64_t n,
-                              int val_dim, int subtract_mean, float* d_distributed, int32_t* d_indices,
-                              float* d_weights, void* stream_) {
+// first half: hash insertion, numbering, row indices; the vertex counters start their way to the host
+extern "C" int tln_distribute_begin(tln_lattice_t* l, const float* d_positions, const float* d_values, int64_t n,
+                                    int val_dim, int subtract_mean, float* d_distributed, int32_t* d_indices,
+                                    float* d_weights, void* stream_) {
   TLN_REQUIRE(l && d_positions && d_distributed && d_indices && d_weights, "null argument");
   TLN_REQUIRE(n > 0 && 4 * n < (1ll << 31), "nr of points %lld out of range", (long long)n);
   TLN_REQUIRE(val_dim >= 0 && val_dim <= 1024 && (val_dim == 0 || d_values), "bad val_dim %d", val_dim);
+  TLN_REQUIRE(!l->dist_pending, "tln_distribute_begin twice without tln_distribute_finish");
   hipStream_t s = (hipStream_t)stream_;
   const int64_t rows = 4 * n;
   int rc = ensure_rows(l, rows);
@@ -1219,22 +1233,54 @@ extern "C" int tln_distribute(tln_lattice_t* l, const float* d_positions, const 
   hipLaunchKernelGGL(k_row_indices, dim3((unsigned)tln_cdiv(rows, 256)), dim3(256), 0, s, t, l->row_slot, rows,
                      d_indices, l->d_ctr, l->sk_in, l->sv_in, sort_totals(l));
   TLN_LAUNCH_CHECK();
-  rc = fetch_counters(l, s);
-  if (rc) return rc;
+  TLN_HIP(hipMemcpyAsync(l->h_ctr, l->d_ctr, CTR_COUNT * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  if (!l->ctr_event) TLN_HIP(hipEventCreateWithFlags(&l->ctr_event, hipEventDisableTiming));
+  TLN_HIP(hipEventRecord(l->ctr_event, s));
+  l->dist_pending = true;
+  l->dist_pos = d_positions;
+  l->dist_out = d_distributed;
+  l->dist_idx = d_indices;
+  l->dist_rows = rows;
+  l->dist_val_dim = val_dim;
+  l->dist_subtract = subtract_mean;
+  return TLN_OK;
+}
+
+// second half: waits for the counters only (not for work enqueued after tln_distribute_begin), then the CSR and means
+extern "C" int tln_distribute_finish(tln_lattice_t* l, void* stream_) {
+  TLN_REQUIRE(l && l->dist_pending, "tln_distribute_finish without tln_distribute_begin");
+  hipStream_t s = (hipStream_t)stream_;
+  l->dist_pending = false;
+  TLN_HIP(hipEventSynchronize(l->ctr_event));
+  l->nr_vertices = l->h_ctr[CTR_NV];
+  l->occupied = l->h_ctr[CTR_OCCUPIED];
+  if (l->h_ctr[CTR_PROBE_FAIL] != 0) {
+    tln_set_error("hash probing failed for %d rows (table too full)", l->h_ctr[CTR_PROBE_FAIL]);
+    return TLN_E_CAPACITY;
+  }
   l->overflow_rows = l->h_ctr[CTR_OVERFLOW];
-  rc = build_csr_sorted(l, rows, s);
+  const int64_t rows = l->dist_rows;
+  int rc = build_csr_sorted(l, rows, s);
   if (rc) return rc;
-  if (subtract_mean && l->nr_vertices > 0) {
+  if (l->dist_subtract && l->nr_vertices > 0) {
     const int64_t nv = l->nr_vertices;
-    hipLaunchKernelGGL(k_mean_pieces, dim3((unsigned)tln_cdiv(rows, MEAN_BLOCK)), dim3(MEAN_BLOCK), 0, s, d_positions,
+    hipLaunchKernelGGL(k_mean_pieces, dim3((unsigned)tln_cdiv(rows, MEAN_BLOCK)), dim3(MEAN_BLOCK), 0, s, l->dist_pos,
                        l->sv_out, l->sk_out, l->seg_start, (int)nv, l->mean, l->pieces);
     hipLaunchKernelGGL(k_mean_combine, dim3((unsigned)tln_cdiv(nv, 256)), dim3(256), 0, s, l->seg_start, (int)nv,
                        l->pieces, l->mean);
-    hipLaunchKernelGGL(k_subtract_rows, dim3((unsigned)tln_cdiv(rows, 256)), dim3(256), 0, s, d_positions, d_indices,
-                       l->mean, rows, 3 + val_dim + 1, d_distributed);
+    hipLaunchKernelGGL(k_subtract_rows, dim3((unsigned)tln_cdiv(rows, 256)), dim3(256), 0, s, l->dist_pos, l->dist_idx,
+                       l->mean, rows, 3 + l->dist_val_dim + 1, l->dist_out);
     TLN_LAUNCH_CHECK();
   }
   return TLN_OK;
+}
+
+extern "C" int tln_distribute(tln_lattice_t* l, const float* d_positions, const float* d_values, int64_t n,
+                              int val_dim, int subtract_mean, float* d_distributed, int32_t* d_indices,
+                              float* d_weights, void* stream_) {
+  int rc = tln_distribute_begin(l, d_positions, d_values, n, val_dim, subtract_mean, d_distributed, d_indices, d_weights,
+                                stream_);
+  return rc ? rc : tln_distribute_finish(l, stream_);
 }
 
 extern "C" int tln_lattice_insert_keys(tln_lattice_t* l, const int32_t* d_keys, int64_t n, int32_t* d_indices_out,

@@ -140,7 +140,7 @@ struct tln_program {
   int split = 0;                     // ops [0, split) only touch level 0: launched before the coarse counts arrive
   int64_t N = 0;
   int dist_cols = 0;
-  bool frame_open = false;
+  bool frame_open = false, frame_started = false;
   DevBuf k1;  // distributed | indices | weights
   float* d_dist = nullptr;
   int32_t* d_idx = nullptr;
@@ -629,10 +629,11 @@ extern "C" int tln_program_reset(tln_program_t* p) {
   return TLN_OK;
 }
 
-extern "C" int tln_program_begin_frame(tln_program_t* p, tln_lattice_t* l, const float* d_positions,
-                                       const float* d_values, int64_t n, int val_dim, int reset_hashmap,
-                                       int subtract_mean, int64_t* v_out, void* stream_) {
-  TLN_REQUIRE(p && l && d_positions && v_out && n > 0 && val_dim >= 0, "bad frame arguments");
+// first half of tln_program_begin_frame: K1 up to the point where the vertex counters start their way to the host
+extern "C" int tln_program_begin_frame_start(tln_program_t* p, tln_lattice_t* l, const float* d_positions,
+                                             const float* d_values, int64_t n, int val_dim, int reset_hashmap,
+                                             int subtract_mean, void* stream_) {
+  TLN_REQUIRE(p && l && d_positions && n > 0 && val_dim >= 0, "bad frame arguments");
   hipStream_t s = (hipStream_t)stream_;
   const int cols = 3 + val_dim + 1;
   const size_t dist_b = align_up((size_t)4 * n * cols * sizeof(float)), idx_b = align_up((size_t)4 * n * sizeof(int32_t));
@@ -646,14 +647,27 @@ extern "C" int tln_program_begin_frame(tln_program_t* p, tln_lattice_t* l, const
     rc = tln_lattice_clear(l, s);
     if (rc) return rc;
   }
-  rc = tln_distribute(l, d_positions, d_values, n, val_dim, subtract_mean, p->d_dist, p->d_idx, p->d_w, s);
-  if (rc) return rc;
-  int64_t vb[TLN_MAX_LEVELS] = {0};
-  rc = tln_lattice_prepare_levels_begin(l, p->n_coarse, vb, s);   // coarse counts stay in flight until tln_program_run
+  rc = tln_distribute_begin(l, d_positions, d_values, n, val_dim, subtract_mean, p->d_dist, p->d_idx, p->d_w, s);
   if (rc) return rc;
   p->lat = l;
   p->N = n;
   p->dist_cols = cols;
+  p->frame_open = false;
+  p->frame_started = true;
+  return TLN_OK;
+}
+
+// second half: waits for this frame's vertex counters only, then the CSR, the means and the coarse levels
+extern "C" int tln_program_begin_frame_finish(tln_program_t* p, int64_t* v_out, void* stream_) {
+  TLN_REQUIRE(p && p->frame_started && v_out, "tln_program_begin_frame_finish without _start");
+  hipStream_t s = (hipStream_t)stream_;
+  p->frame_started = false;
+  tln_lattice_t* l = p->lat;
+  int rc = tln_distribute_finish(l, s);
+  if (rc) return rc;
+  int64_t vb[TLN_MAX_LEVELS] = {0};
+  rc = tln_lattice_prepare_levels_begin(l, p->n_coarse, vb, s);   // coarse counts stay in flight until tln_program_run
+  if (rc) return rc;
   p->exact_known = p->n_coarse == 0;
   tln_lattice_t* lv = l;
   for (int i = 0; i <= p->n_coarse; ++i) {
@@ -666,6 +680,14 @@ extern "C" int tln_program_begin_frame(tln_program_t* p, tln_lattice_t* l, const
   }
   p->frame_open = true;
   return TLN_OK;
+}
+
+extern "C" int tln_program_begin_frame(tln_program_t* p, tln_lattice_t* l, const float* d_positions,
+                                       const float* d_values, int64_t n, int val_dim, int reset_hashmap,
+                                       int subtract_mean, int64_t* v_out, void* stream_) {
+  TLN_REQUIRE(v_out, "bad frame arguments");
+  int rc = tln_program_begin_frame_start(p, l, d_positions, d_values, n, val_dim, reset_hashmap, subtract_mean, stream_);
+  return rc ? rc : tln_program_begin_frame_finish(p, v_out, stream_);
 }
 
 extern "C" int tln_program_run(tln_program_t* p, int early, float* d_out, int64_t out_rows, int out_cols,

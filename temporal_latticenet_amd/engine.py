@@ -410,7 +410,8 @@ class FrameProgram:
         ls.set_values(out)
         return out, ls
 
-    def _begin(self, ls, positions, values, reset_hashmap, early_return):
+    def _start(self, ls, positions, values, reset_hashmap):
+        """first half of a frame's K1 (the vertex counters start their way to the host)"""
         positions = positions.contiguous().float()
         n = positions.shape[0]
         if values is None or values.numel() == 0:
@@ -418,22 +419,29 @@ class FrameProgram:
         else:
             values = values.contiguous().float()
             val_dim = values.shape[1]
-        _lib.check(_lib.lib().tln_program_begin_frame(self._h, ls._h, positions.data_ptr(),
-                                                      values.data_ptr() if values is not None else None, n, val_dim,
-                                                      1 if reset_hashmap else 0, 1 if self.subtract_mean else 0,
-                                                      self._v, stream_ptr()), "tln_program_begin_frame")
+        _lib.check(_lib.lib().tln_program_begin_frame_start(self._h, ls._h, positions.data_ptr(),
+                                                            values.data_ptr() if values is not None else None, n,
+                                                            val_dim, 1 if reset_hashmap else 0,
+                                                            1 if self.subtract_mean else 0, stream_ptr()),
+                   "tln_program_begin_frame_start")
         ls._csr_key = None
+        return n, (positions, values)                 # the inputs stay alive until the frame has been enqueued
+
+    def _finish(self, n, early_return):
+        """second half: vertex counts known, coarse levels begun -> (early, output tensor)"""
+        _lib.check(_lib.lib().tln_program_begin_frame_finish(self._h, self._v, stream_ptr()),
+                   "tln_program_begin_frame_finish")
         early = bool(early_return) and self.stop_shape is not None
         rows_code, cols = self.stop_shape if early else self.out_shape
-        out = torch.empty((self._rows(rows_code, n), cols), dtype=torch.float32, device="cuda")
-        return early, out, (positions, values)        # the inputs stay alive until the frame has been enqueued
+        return early, torch.empty((self._rows(rows_code, n), cols), dtype=torch.float32, device="cuda")
 
     @staticmethod
     def run_frame_group(progs, lattices, positions, values, reset_hashmap, early_return):
         """2..8 sequences in lock-step on the current stream (tln_program_run_group): -> [(tensor, ls), ...]"""
         n = len(progs)
-        begun = [p._begin(ls, pos, val, reset_hashmap, early_return)
-                 for p, ls, pos, val in zip(progs, lattices, positions, values)]
+        # all frames started before the first one is finished: the host waits for vertex counters once, not n times
+        started = [p._start(ls, pos, val, reset_hashmap) for p, ls, pos, val in zip(progs, lattices, positions, values)]
+        begun = [p._finish(st[0], early_return) for p, st in zip(progs, started)]
         early, outs = begun[0][0], [x[1] for x in begun]
         assert all(x[0] == early for x in begun) and all(o.shape[1] == outs[0].shape[1] for o in outs)
         hs = (C.c_void_p * n)(*[p._h for p in progs])
@@ -441,7 +449,7 @@ class FrameProgram:
         rows = (C.c_int64 * n)(*[o.shape[0] for o in outs])
         _lib.check(_lib.lib().tln_program_run_group(hs, n, 1 if early else 0, ptrs, rows, outs[0].shape[1], stream_ptr()),
                    "tln_program_run_group")
-        del begun                                      # the inputs stayed alive until the frames were enqueued
+        del started                                    # the inputs stayed alive until the frames were enqueued
         for ls, o in zip(lattices, outs):
             ls.set_values(o)
         return list(zip(outs, lattices))
