@@ -1217,8 +1217,11 @@ extern "C" int tln_distribute_begin(tln_lattice_t* l, const float* d_positions, 
   TLN_REQUIRE(l && d_positions && d_distributed && d_indices && d_weights, "null argument");
   TLN_REQUIRE(n > 0 && 4 * n < (1ll << 31), "nr of points %lld out of range", (long long)n);
   TLN_REQUIRE(val_dim >= 0 && val_dim <= 1024 && (val_dim == 0 || d_values), "bad val_dim %d", val_dim);
-  TLN_REQUIRE(!l->dist_pending, "tln_distribute_begin twice without tln_distribute_finish");
   hipStream_t s = (hipStream_t)stream_;
+  if (l->dist_pending) {  // an abandoned first half (its caller failed in between): let its counter fetch land
+    TLN_HIP(hipEventSynchronize(l->ctr_event));
+    l->dist_pending = false;
+  }
   const int64_t rows = 4 * n;
   int rc = ensure_rows(l, rows);
   if (rc) return rc;
