@@ -279,7 +279,10 @@ def main():
             "metric": "point-clouds/sec (120k pts, sigma=0.6, 4-frame seq)",
             "value": round(value, 3), "unit": "clouds/s", "n_gpus": args.gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic" if frames_mode or per_stream_seqs == 1 else
+                    "synthetic (one ray-cast drive per stream; the further sequences of its lock-step group are that "
+                    "drive turned about the vertical axis)",
             "config": {"workload": "%d-frame sequence, %d pts/frame, sigma=%s, rnn_modules=[%s], 26 classes, "
                                    "full U-Net lattice encoder/decoder, inference" % (args.frames, args.points, args.sigma, args.rnn),
                        "parallelism": par, "vertices_per_frame_V0_V1_V2": vcounts},
