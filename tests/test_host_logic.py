@@ -140,3 +140,35 @@ def test_synthetic_scan_contract():
         assert pos[:, 1].min() > -3.0 and pos[:, 1].max() < 6.0      # +y is up, ground ~ -1.73
     again = make_sequence(3000, 3, seed=9)
     assert all(np.array_equal(a[0], b[0]) for a, b in zip(seq, again)), "seeded"
+
+
+def test_ctypes_mirrors_match_the_header_layout(tmp_path):
+    """the structs of include/tln.h as gcc lays them out (plain C) against their ctypes mirrors in _lib.py: size and
+    the offset of every field, so that a field added on one side only is caught without a GPU"""
+    import ctypes as C
+    import shutil
+    import subprocess
+    from temporal_latticenet_amd import _lib
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    pairs = {"tln_gemm_src": _lib.GemmSrc, "tln_gemm_call": _lib.GemmCall, "tln_slot": _lib.Slot,
+             "tln_op_src": _lib.OpSrc, "tln_op": _lib.Op, "tln_gn_desc": _lib.GnDesc}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "tln.h"', 'int main(void) {']
+    for cname, cls in pairs.items():
+        lines.append('  printf("%s size %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ in cls._fields_:
+            lines.append('  printf("%s %s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname))
+    lines += ['  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = {}
+    for ln in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n"):
+        if ln.strip():
+            a, b, c = ln.split()
+            got[(a, b)] = int(c)
+    for cname, cls in pairs.items():
+        assert got[(cname, "size")] == C.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert got[(cname, fname)] == getattr(cls, fname).offset, "%s.%s" % (cname, fname)
