@@ -486,9 +486,15 @@ __global__ void __launch_bounds__(128 * WM * G) k_gather_gemm(const GemmArgs g) 
 //   * B: [K,N] weights: 16 coalesced dword loads (row c0+16*half+s, column n0 + lane&31); [N,K] weights: 4 x dwordx4
 //   * G waves per block interleave over the chunk list (G = blockDim/64, up to 12) and are summed through LDS in
 //     fixed order; chunk loads run DEPTH chunks ahead in registers
-//   * the tap indices of a lane's row sit in 9 registers; the GroupNorm finalise of the prologue runs while the
-//     first chunk loads are in flight, with all threads sharing the partial-sum reduction
+//     (`step`: a slot is refilled while its chunk is being multiplied -- the A registers are free once the operands
+//     are prepared, each B register once its MFMA has been issued)
+//   * the tap indices of the block's 32 rows (both sources) sit in LDS; the producer's GroupNorm partial sums are
+//     reduced BEFORE the first operand loads (one barrier with the tap indices), the group statistics after them
+//   * the wave index is read into an SGPR, so the chunk bookkeeping (tap, channel slice, K row, source) is scalar
+//     code; what a wave issues per chunk beside its 16 MFMAs decides the K loop at this size
 // Same arithmetic per output as the tiled kernel up to the order of the K summation (chunk interleave).
+// direct_body is shared by k_gather_gemm_direct (one product) and k_gather_gemm_direct_multi (2..8 products of one
+// shape class in one launch, blockIdx.z = product).
 // ---------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define TLN_DIRECT_DEPTH 2
