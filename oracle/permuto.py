@@ -22,12 +22,20 @@ F32 = np.float32
 
 
 # --------------------------------------------------------------------------
-# S1. scale factors  (Adams 2010 §3.1 without the blur-variance factor)
+# S1. scale factors  (Adams 2010 §3.1, including its (d+1)*sqrt(2/3) factor)
 # --------------------------------------------------------------------------
+# Which constant multiplies 1/(sigma*sqrt((i+1)(i+2))) is a free choice of the un-vendored
+# dependency.  The one sizing statement under /root/reference decides it:
+# seq_config/lnn_train_semantic_kitti.cfg:71, "semantic kitti which splat around 10k with sigma
+# of 1".  Without the factor the lattice points of sigma = 1 are 3.46 m apart (32 m^3 per vertex):
+# the slab a 64-beam scan covers out to 60 m (about 5 m tall) holds < 2k such vertices whatever the
+# scene.  With Adams' factor (0.92 m^3 per vertex) a street scene gives 8-10k
+# (tests/test_scene_calibration.py).
 def scale_factors(sigmas):
-    """scale[i] = float32( 1 / (sigma_i * sqrt((i+1)(i+2))) ), computed in double."""
+    """scale[i] = float32( (d+1)*sqrt(2/3) / (sigma_i * sqrt((i+1)(i+2))) ), computed in double."""
+    d1 = float(len(sigmas) + 1)
     return np.array(
-        [1.0 / (float(s) * math.sqrt(float((i + 1) * (i + 2)))) for i, s in enumerate(sigmas)],
+        [d1 * math.sqrt(2.0 / 3.0) / (float(s) * math.sqrt(float((i + 1) * (i + 2)))) for i, s in enumerate(sigmas)],
         dtype=np.float64,
     ).astype(F32)
 

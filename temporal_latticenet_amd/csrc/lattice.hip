@@ -149,7 +149,9 @@ static int lattice_alloc(tln_lattice** out, int pos_dim, const double* sigmas, i
   l->nslots = ns;
   for (int i = 0; i < 3; ++i) {
     l->sigmas[i] = sigmas[i];
-    l->scale[i] = (float)(1.0 / (sigmas[i] * sqrt((double)((i + 1) * (i + 2)))));
+    // Adams 2010 §3.1 with its (d+1)*sqrt(2/3) factor: the choice that meets the reference's sizing hint
+    // (seq_config/lnn_train_semantic_kitti.cfg:71, ~10k vertices for a KITTI scan at sigma = 1); DESIGN.md §3.1
+    l->scale[i] = (float)(4.0 * sqrt(2.0 / 3.0) / (sigmas[i] * sqrt((double)((i + 1) * (i + 2)))));
   }
   TLN_HIP(hipMalloc(&l->slot_key, ns * sizeof(uint64_t)));
   TLN_HIP(hipMalloc(&l->slot_val, ns * sizeof(int32_t)));

@@ -19,7 +19,7 @@ def test_accumulated_cloud_one_million_vertices(gpu):
     seq = make_sequence(120000, 8, seed=77)
     pos = np.concatenate([p for p, _ in seq], 0)          # accumulate_clouds
     val = np.concatenate([v for _, v in seq], 0)
-    sigma, cap = 0.016, 1 << 21
+    sigma, cap = 0.07, 1 << 21
     lat = Lattice.from_params([sigma] * 3, cap)
     d, i, w = lat.distribute(torch.from_numpy(pos).to(gpu), torch.from_numpy(val).to(gpu))
     V = lat.nr_lattice_vertices()
@@ -61,7 +61,7 @@ def test_default_capacity_overflow_on_accumulated_cloud_is_reported(gpu):
     seq = make_sequence(60000, 4, seed=78)
     pos = np.concatenate([p for p, _ in seq], 0)
     val = np.concatenate([v for _, v in seq], 0)
-    lat = Lattice.from_params([0.02] * 3, 100000)           # the reference's default capacity (cfg:71)
+    lat = Lattice.from_params([0.1] * 3, 100000)           # the reference's default capacity (cfg:71)
     d, i, w = lat.distribute(torch.from_numpy(pos).to(gpu), torch.from_numpy(val).to(gpu))
     assert lat.nr_lattice_vertices() == 100000
     assert lat.overflow_rows() == int((i < 0).sum()) > 0
