@@ -305,6 +305,7 @@ def cpu_baseline(model, contents, args):
     oracle = OracleLNN(model.state_dict(), 26, m["rnn_modules"], m["sequence_learning"], m["pointnet_layers"],
                        m["nr_downsamples"], m["nr_blocks_down_stage"], m["nr_blocks_bottleneck"],
                        m["nr_blocks_up_stage"], [args.sigma] * 3, 1 << 18, m["experiment"])
+    oracle.exact_pool = False                # the timed baseline is plain PyTorch-CPU eager (F.linear)
     seq = make_sequence(args.cpu_points, args.frames, seed=1234)
     done, t0 = 0, time.perf_counter()
     while True:

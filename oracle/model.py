@@ -39,6 +39,9 @@ class OracleLNN:
         self.experiment = experiment
         self.normal_down = nr_levels_down_with_normal_resnet
         self.normal_up = nr_levels_up_with_normal_resnet
+        # True: the PointNet MLP in the pinned fma order (bit-exact twin of csrc/pool.hip, O.linear_fma);
+        # False: torch's F.linear — the eager CPU path bench.py times as `cpu_baseline`
+        self.exact_pool = True
         self.reset_sequence()
 
     # ---- state ----------------------------------------------------------------------------
@@ -173,7 +176,7 @@ class OracleLNN:
         if self.experiment == "attention_pool":
             lv = self._attention_pool(dist, indices, v0)
         else:
-            lv = O.pointnet_pool(dist, indices, v0, ws, bs, 0 if early_maxpool else 4)
+            lv = O.pointnet_pool(dist, indices, v0, ws, bs, 0 if early_maxpool else 4, exact=self.exact_pool)
         if self.seq and self.rnn[0] == "maxpool":
             rowsum = lv[:, : lv.shape[1] // 2].abs().sum(1, keepdim=True)
             lv = lv.masked_fill(rowsum == 0, -9900)

@@ -42,10 +42,12 @@ def distribute(table, positions, values, sigmas, subtract_mean=True):
     if subtract_mean:
         ok = indices >= 0
         v = table.nr_vertices
-        s = np.zeros((v, 3), np.float64)
-        np.add.at(s, indices[ok], pos4[ok].astype(np.float64))
+        # fixed point (units of 2^-20) summed in int64: exact, so the mean is independent of the summation order
+        fixed = np.rint(pos4[ok].astype(np.float64) * 1048576.0).astype(np.int64)
+        s = np.zeros((v, 3), np.int64)
+        np.add.at(s, indices[ok], fixed)
         c = np.bincount(indices[ok], minlength=v).astype(np.float64)
-        mean = (s / np.maximum(c, 1)[:, None]).astype(np.float32)
+        mean = ((s.astype(np.float64) / np.maximum(c, 1)[:, None]) * (1.0 / 1048576.0)).astype(np.float32)
         dist[ok, :3] = pos4[ok] - mean[indices[ok]]
     return dist, indices.astype(np.int32), weights
 
@@ -77,15 +79,65 @@ def scatter_add(src, index, dim_size=None):
 # ------------------------------------------------------------------------------------------
 # K2 PointNet pool, reference lm:448-530 (experiment "none"/default branch)
 # ------------------------------------------------------------------------------------------
-def pointnet_pool(distributed, indices, nr_vertices, weights, biases, min_points=4):
+_POOL_LIB = None
+
+
+def _pool_lib():
+    """oracle/_build/libpool_mlp.so (oracle/csrc/pool_mlp.c, built by oracle/Makefile) or False"""
+    global _POOL_LIB
+    if _POOL_LIB is None:
+        import ctypes
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build", "libpool_mlp.so")
+        try:
+            lib = ctypes.CDLL(path)
+            lib.oracle_linear_fma.restype = None
+            lib.oracle_linear_fma.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p,
+                                              ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+            _POOL_LIB = lib
+        except OSError:
+            _POOL_LIB = False
+    return _POOL_LIB
+
+
+def linear_fma(x, w, b, relu):
+    """y = x @ w.T + b in the ONE summation order DESIGN.md §3.8 fixes for the PointNet MLP:
+    acc = b[o]; for i ascending: acc = fma(x[i], w[o][i], acc) — IEEE fp32 fused multiply-add.  Bit-identical to
+    csrc/pool.hip.  C restatement when built; otherwise emulated through float64 (the product of two fp32 numbers is
+    exact in fp64; the one extra rounding of the sum can differ from a true fma only on an exact fp32 tie)."""
+    x = np.ascontiguousarray(np.asarray(x, np.float32))
+    w = np.ascontiguousarray(np.asarray(w, np.float32))
+    b = None if b is None else np.ascontiguousarray(np.asarray(b, np.float32))
+    rows, cin = x.shape
+    cout = w.shape[0]
+    lib = _pool_lib()
+    if lib:
+        y = np.empty((rows, cout), np.float32)
+        lib.oracle_linear_fma(x.ctypes.data, rows, cin, w.ctypes.data, None if b is None else b.ctypes.data, cout,
+                              1 if relu else 0, y.ctypes.data)
+        return y
+    y = np.broadcast_to(np.zeros(cout, np.float32) if b is None else b, (rows, cout)).astype(np.float32)
+    for i in range(cin):
+        y = (x[:, i:i + 1].astype(np.float64) * w[None, :, i].astype(np.float64) + y.astype(np.float64)).astype(np.float32)
+    return np.maximum(y, np.float32(0)) if relu else y
+
+
+def pointnet_pool(distributed, indices, nr_vertices, weights, biases, min_points=4, exact=True):
+    """exact=True: the MLP in the pinned fma order (linear_fma) — what the HIP kernel is compared with bit for bit;
+    exact=False: torch's F.linear (the eager CPU timing baseline of bench.py)."""
     distributed = torch.as_tensor(distributed)
     indices = torch.as_tensor(indices)
     barycentric_weights = distributed[:, -1]                                   # lm:448
     x = distributed[:, :distributed.shape[1] - 1]                              # lm:452
     for i, (w, b) in enumerate(zip(weights, biases)):                          # lm:460-473
-        x = F.linear(x, w, b)
-        if i < len(weights) - 1:
-            x = torch.relu(x)
+        last = i == len(weights) - 1
+        if exact:
+            x = torch.from_numpy(linear_fma(x.numpy(), w.detach().numpy(), None if b is None else b.detach().numpy(),
+                                            not last))
+        else:
+            x = F.linear(x, w, b)
+            if not last:
+                x = torch.relu(x)
     indices_long = indices.long()                                              # lm:477
     indices_long[indices_long < 0] = 0                                         # lm:480
     reduced, argmax = scatter_max(x, indices_long, nr_vertices)                # lm:512 (dim_size = V, see DESIGN)

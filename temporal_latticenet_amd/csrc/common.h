@@ -66,6 +66,13 @@ __device__ __forceinline__ float tln_ord2f(uint32_t o) {
   return __uint_as_float(u);
 }
 
+// fixed-point positions for the per-vertex local mean: units of 2^-20, summed in int64 — exact, so
+// the mean does not depend on the order in which a vertex's rows are added (oracle/ops.py:distribute does the same)
+__device__ __forceinline__ long long tln_fix20(float p) { return __float2ll_rn(p * 1048576.0f); }
+__device__ __forceinline__ float tln_unfix20(long long sum, double cnt) {
+  return (float)(((double)sum / cnt) * (1.0 / 1048576.0));
+}
+
 // ---- key packing / hashing (d = 3) ------------------------------------------------------
 #define TLN_KEY_BIAS (1 << 20)
 #define TLN_KEY_EMPTY 0xFFFFFFFFFFFFFFFFull

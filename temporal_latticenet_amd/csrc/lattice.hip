@@ -74,7 +74,7 @@ struct tln_lattice {
   size_t sort_temp_bytes = 0;
   int32_t* seg_start = nullptr;  // [capacity+2]
   float* mean = nullptr;         // [capacity][3] local mean of the last distribute
-  double* pieces = nullptr;      // [rows_cap/256+1][2][3] partial sums of segments that span blocks
+  long long* pieces = nullptr;   // [rows_cap/256+1][2][3] fixed-point partial sums of segments that span blocks
   int64_t csr_rows = -1;
   // pool workspace
   unsigned long long* pool_packed = nullptr;
@@ -123,7 +123,7 @@ static int ensure_rows(tln_lattice* l, int64_t rows) {
   TLN_HIP(hipMalloc(&l->sk_out, cap * sizeof(int32_t)));
   TLN_HIP(hipMalloc(&l->sv_in, cap * sizeof(int32_t)));
   TLN_HIP(hipMalloc(&l->sv_out, cap * sizeof(int32_t)));
-  TLN_HIP(hipMalloc(&l->pieces, (cap / 256 + 2) * 6 * sizeof(double)));
+  TLN_HIP(hipMalloc(&l->pieces, (cap / 256 + 2) * 6 * sizeof(long long)));
   // radix-sort scratch: ping-pong keys + values and the [256][blocks] digit histogram
   // + the 256 digit bases and the arrival counter of the fused table scan (counter starts, and is left, at zero)
   const size_t hist_ints = (size_t)256 * (cap / RADIX_KPB + 2);
@@ -1107,7 +1107,8 @@ extern "C" int tln_lattice_csr(tln_lattice_t* l, int32_t* d_order, int32_t* d_so
 // ---------------------------------------------------------------------------------------
 // K1 phase D: local mean per vertex and subtraction, independent of how skewed the rows-per-vertex
 // distribution is (one vertex next to the sensor collects thousands of rows):
-//   k_mean_pieces : 256 consecutive SORTED rows per block, segmented inclusive scan (fp64, fixed tree) by vertex;
+//   k_mean_pieces : 256 consecutive SORTED rows per block, segmented inclusive scan by vertex of the positions in FIXED POINT (int64, units of
+//                   2^-20: exact, hence independent of the summation order and bit-identical to oracle/ops.py:distribute);
 //                   a segment that lies inside one block is finished there, otherwise the block stores the sum of
 //                   its first piece (slot 0, touches the block start) and last piece (slot 1)
 //   k_mean_combine: segments spanning several blocks add their pieces in block order
@@ -1118,8 +1119,8 @@ __global__ void __launch_bounds__(MEAN_BLOCK) k_mean_pieces(const float* __restr
                                                             const int32_t* __restrict__ order,
                                                             const int32_t* __restrict__ sorted_vertex,
                                                             const int32_t* __restrict__ seg_start, int nv,
-                                                            float* __restrict__ mean, double* __restrict__ pieces) {
-  __shared__ double sx[MEAN_BLOCK], sy[MEAN_BLOCK], sz[MEAN_BLOCK];
+                                                            float* __restrict__ mean, long long* __restrict__ pieces) {
+  __shared__ long long sx[MEAN_BLOCK], sy[MEAN_BLOCK], sz[MEAN_BLOCK];
   __shared__ int key[MEAN_BLOCK];
   const int valid_rows = seg_start[nv];  // rows that have a vertex (the tail bucket is excluded)
   const int j = threadIdx.x;
@@ -1127,13 +1128,13 @@ __global__ void __launch_bounds__(MEAN_BLOCK) k_mean_pieces(const float* __restr
   const int gi = base + j;
   const bool ok = gi < valid_rows;
   int v = -1 - j;  // unique dummy keys for the padding lanes
-  double x = 0, y = 0, z = 0;
+  long long x = 0, y = 0, z = 0;
   if (ok) {
     v = sorted_vertex[gi];
     const int64_t p = order[gi] >> 2;
-    x = (double)pos[3 * p];
-    y = (double)pos[3 * p + 1];
-    z = (double)pos[3 * p + 2];
+    x = tln_fix20(pos[3 * p]);
+    y = tln_fix20(pos[3 * p + 1]);
+    z = tln_fix20(pos[3 * p + 2]);
   }
   key[j] = v;
   sx[j] = x;
@@ -1142,7 +1143,7 @@ __global__ void __launch_bounds__(MEAN_BLOCK) k_mean_pieces(const float* __restr
   __syncthreads();
 #pragma unroll
   for (int o = 1; o < MEAN_BLOCK; o <<= 1) {
-    double ax = 0, ay = 0, az = 0;
+    long long ax = 0, ay = 0, az = 0;
     const bool take = (j >= o) && (key[j - o] == v);
     if (take) {
       ax = sx[j - o];
@@ -1164,12 +1165,12 @@ __global__ void __launch_bounds__(MEAN_BLOCK) k_mean_pieces(const float* __restr
   const int b = seg_start[v], e = seg_start[v + 1];
   if (b >= base && e <= base + last + 1) {
     const double cnt = (double)(e - b);
-    mean[3 * v] = (float)(sx[j] / cnt);
-    mean[3 * v + 1] = (float)(sy[j] / cnt);
-    mean[3 * v + 2] = (float)(sz[j] / cnt);
+    mean[3 * v] = tln_unfix20(sx[j], cnt);
+    mean[3 * v + 1] = tln_unfix20(sy[j], cnt);
+    mean[3 * v + 2] = tln_unfix20(sz[j], cnt);
   } else {
     const int slot = (key[0] == v) ? 0 : 1;
-    double* d = pieces + ((int64_t)blockIdx.x * 2 + slot) * 3;
+    long long* d = pieces + ((int64_t)blockIdx.x * 2 + slot) * 3;
     d[0] = sx[j];
     d[1] = sy[j];
     d[2] = sz[j];
@@ -1177,15 +1178,15 @@ __global__ void __launch_bounds__(MEAN_BLOCK) k_mean_pieces(const float* __restr
 }
 
 __global__ void __launch_bounds__(256) k_mean_combine(const int32_t* __restrict__ seg_start, int nv,
-                                                      const double* __restrict__ pieces, float* __restrict__ mean) {
+                                                      const long long* __restrict__ pieces, float* __restrict__ mean) {
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= nv) return;
   const int b = seg_start[v], e = seg_start[v + 1];
   if (b == e) return;
   const int kb = b / MEAN_BLOCK, ke = (e - 1) / MEAN_BLOCK;
   if (kb == ke) return;  // finished by k_mean_pieces
-  const double* d = pieces + ((int64_t)kb * 2 + ((b % MEAN_BLOCK == 0) ? 0 : 1)) * 3;
-  double x = d[0], y = d[1], z = d[2];
+  const long long* d = pieces + ((int64_t)kb * 2 + ((b % MEAN_BLOCK == 0) ? 0 : 1)) * 3;
+  long long x = d[0], y = d[1], z = d[2];
   for (int k = kb + 1; k <= ke; ++k) {
     d = pieces + (int64_t)k * 2 * 3;
     x += d[0];
@@ -1193,9 +1194,9 @@ __global__ void __launch_bounds__(256) k_mean_combine(const int32_t* __restrict_
     z += d[2];
   }
   const double cnt = (double)(e - b);
-  mean[3 * v] = (float)(x / cnt);
-  mean[3 * v + 1] = (float)(y / cnt);
-  mean[3 * v + 2] = (float)(z / cnt);
+  mean[3 * v] = tln_unfix20(x, cnt);
+  mean[3 * v + 1] = tln_unfix20(y, cnt);
+  mean[3 * v + 2] = tln_unfix20(z, cnt);
 }
 
 __global__ void __launch_bounds__(256) k_subtract_rows(const float* __restrict__ pos, const int32_t* __restrict__ indices,

@@ -112,16 +112,18 @@ __global__ void __launch_bounds__(256) k_pool_chunks(const float* __restrict__ d
     if constexpr (H1 == 0) {
       return h[active ? c : 0];
     } else {
-      float acc0 = bias, acc1 = 0.0f;
+      // ONE fma chain in ascending i, as in the front layers: the summation order is part of the specification
+      // (oracle/csrc/pool_mlp.c) because the arg-max row decides a whole output element (lm:513-525)
+      float acc = bias;
 #pragma unroll
       for (int i = 0; i < HL; i += 4) {
         const float4 q = *reinterpret_cast<const float4*>(h + i);   // one address for the whole wave: broadcast
-        acc0 = fmaf(wl[i], q.x, acc0);
-        acc1 = fmaf(wl[i + 1], q.y, acc1);
-        acc0 = fmaf(wl[i + 2], q.z, acc0);
-        acc1 = fmaf(wl[i + 3], q.w, acc1);
+        acc = fmaf(wl[i], q.x, acc);
+        acc = fmaf(wl[i + 1], q.y, acc);
+        acc = fmaf(wl[i + 2], q.z, acc);
+        acc = fmaf(wl[i + 3], q.w, acc);
       }
-      return acc0 + acc1;
+      return acc;
     }
   };
   int cur = tv[0];

@@ -86,3 +86,25 @@ def test_other_fusion_modules(gpu, cls, name, args):
     m = getattr(S, cls)(*args).cuda()
     m.load_state_dict(sd)
     _run(m, z, 2e-5)
+
+
+def test_pointnet_pool_against_the_reference_vectors(gpu):
+    """tests/golden/pointnet_pool.npz came out of the reference's own PointNetSeqModule.forward (lm:407-576, generator
+    tests/golden/make_golden.py): -1 indices, an empty vertex, a vertex with < 4 rows, arg-max rows both <= V and > V.
+    The HIP pool runs on a lattice that holds the fixture's V vertices (any V distinct keys) and the fixture's indices."""
+    from temporal_latticenet_amd import ops
+    from temporal_latticenet_amd.lattice import Lattice
+    z, sd = _load("pointnet_pool.npz")
+    v = int(z["nr_vertices"])
+    lat = Lattice.from_params([1.0] * 3, 1 << 12)
+    keys = np.zeros((v, 3), np.int32)
+    keys[:, 0] = 4 * np.arange(v)                    # lattice points (coordinates congruent mod 4), all different
+    lat.insert_keys(torch.from_numpy(keys).cuda())
+    assert lat.nr_lattice_vertices() == v
+    ws = [sd["layers.%d.weight" % i].cuda() for i in range(3)]
+    bs = [sd["layers.%d.bias" % i].cuda() for i in range(3)]
+    dist = torch.from_numpy(z["distributed"]).cuda()
+    idx = torch.from_numpy(z["indices"].astype(np.int32)).cuda()
+    pooled = ops.pointnet_pool(lat, dist, idx, ws, bs, 4).clone()
+    pooled[0, :] = 0                                 # lm:569-570 (the fixture's last_conv is an identity stand-in)
+    np.testing.assert_allclose(pooled.cpu().numpy(), z["out"], rtol=1e-5, atol=1e-6)

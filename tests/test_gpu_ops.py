@@ -34,7 +34,8 @@ def test_pointnet_pool(gpu, layers):
     out = ops.pointnet_pool(lat, d, i, [x.to(gpu) for x in Ws], [x.to(gpu) for x in Bs], 4)
     want = O.pointnet_pool(od, oi, tab.nr_vertices, Ws, Bs, 4)
     assert out.shape == want.shape
-    np.testing.assert_allclose(out.cpu().numpy(), want.numpy(), rtol=1e-5, atol=1e-5)
+    # the MLP's summation order is part of the specification: identical bits, arg-max rows included
+    assert np.array_equal(out.cpu().numpy(), want.numpy())
 
 
 def test_pool_folds_invalid_rows_into_vertex0(gpu):

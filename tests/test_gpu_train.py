@@ -44,6 +44,7 @@ def test_parameter_gradients_match_oracle_autograd(gpu, rnn):
     got = {k: p.grad.detach().cpu() for k, p in model.named_parameters() if p.grad is not None}
 
     oracle = oracle_from_model(model, contents)
+    oracle.exact_pool = False            # autograd needs the differentiable F.linear MLP (same values up to rounding)
     for v in oracle.sd.values():
         if v.is_floating_point():
             v.requires_grad_(True)
