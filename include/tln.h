@@ -179,6 +179,9 @@ void tln_gemm_force_splits(int splits, int wm);
 /* tuning hook: the small-M "direct" kernel (operands from global memory, no LDS tiles): 0 = heuristic,
  * 1 = whenever the shape is eligible (channels multiple of 32, aligned), -1 = never */
 void tln_gemm_force_direct(int mode);
+/* tuning hook: the large-M kernel (csrc/gemm_v2.hip: 128-row block tiles, operands staged once per block by LDS-DMA):
+ * off != 0 switches it off; min_m > 0 sets the smallest M that takes it (default 12288) */
+void tln_gemm_v2_config(int off, int64_t min_m);
 /* diagnostic hook: block (0,0,0) of every following gather-GEMM writes five s_memtime stamps (start, after the
  * index/GroupNorm prologue, after the K loop, after the reductions, end) to d_buf (5 x u64); NULL switches it off */
 void tln_gemm_debug_stamps(void* d_buf);

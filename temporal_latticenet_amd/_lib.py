@@ -93,6 +93,7 @@ _PROTOS = {
     "tln_gemm_force_groups": (None, [_i]),
     "tln_gemm_force_splits": (None, [_i, _i]),
     "tln_gemm_force_direct": (None, [_i]),
+    "tln_gemm_v2_config": (None, [_i, _i64]),
     "tln_gather_gemm_pair": (_i, [C.POINTER(GemmCall), C.POINTER(GemmCall), _vp]),
     "tln_gather_gemm_multi": (_i, [C.POINTER(GemmCall), _i, _vp]),
     "tln_gemm_pair_disable": (None, [_i]),

@@ -15,6 +15,7 @@ SOURCES = {
     "lattice.hip": ["-ffp-contract=off"],
     "pool.hip": [],
     "gemm.hip": [],
+    "gemm_v2.hip": [],
     "fused.hip": [],
     "program.hip": [],
 }
@@ -37,7 +38,8 @@ def _stale(target, deps):
 
 def build(force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(INCLUDE, "tln.h"), os.path.abspath(__file__)]
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_args.h"), os.path.join(INCLUDE, "tln.h"),
+               os.path.abspath(__file__)]
     hipcc = _hipcc()
     jobs = []
     for src, extra in SOURCES.items():

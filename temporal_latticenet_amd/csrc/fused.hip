@@ -45,35 +45,55 @@ __global__ void __launch_bounds__(256) k_gn_partial(const float* __restrict__ x,
   }
 }
 
+// one BLOCK per group: thread t adds the group's partial sums t, t+256, ... (fixed order), the 256 subtotals are
+// combined by a fixed tree => deterministic.  (One wave per group, as this kernel used to be, walks 6k partials of a
+// 30k-vertex level serially: 18 us; a block takes 3.)
 __global__ void __launch_bounds__(256) k_gn_finalize(const double2* __restrict__ partial, int nblk, int64_t V, int C,
                                                      int groups, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float eps,
                                                      float* __restrict__ scale, float* __restrict__ shift) {
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  __shared__ double2 red[256];
+  const int g = blockIdx.x;
   const int cpg = C / groups;
-  for (int g = blockIdx.x * 4 + wid; g < groups; g += gridDim.x * 4) {
-    double s = 0.0, q = 0.0;
-    const int64_t items = (int64_t)nblk * cpg;
-    for (int64_t i = lane; i < items; i += 64) {
-      const int64_t b = i / cpg;
-      const int c = g * cpg + (int)(i - b * cpg);
-      const double2 p = partial[b * C + c];
-      s += p.x;
-      q += p.y;
+  const int64_t items = (int64_t)nblk * cpg;
+  double s0 = 0.0, q0 = 0.0, s1 = 0.0, q1 = 0.0;
+  int64_t i = threadIdx.x;
+  for (; i + 256 < items; i += 512) {          // two independent loads in flight per round
+    const int64_t b0 = i / cpg, b1 = (i + 256) / cpg;
+    const double2 p0 = partial[b0 * C + g * cpg + (int)(i - b0 * cpg)];
+    const double2 p1 = partial[b1 * C + g * cpg + (int)(i + 256 - b1 * cpg)];
+    s0 += p0.x;
+    q0 += p0.y;
+    s1 += p1.x;
+    q1 += p1.y;
+  }
+  if (i < items) {
+    const int64_t b0 = i / cpg;
+    const double2 p0 = partial[b0 * C + g * cpg + (int)(i - b0 * cpg)];
+    s0 += p0.x;
+    q0 += p0.y;
+  }
+  red[threadIdx.x] = make_double2(s0 + s1, q0 + q1);
+  __syncthreads();
+#pragma unroll
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      red[threadIdx.x].x += red[threadIdx.x + o].x;
+      red[threadIdx.x].y += red[threadIdx.x + o].y;
     }
-    s = tln_wave_sum(s);
-    q = tln_wave_sum(q);
-    const double cnt = (double)V * (double)cpg;
-    const double mean = s / cnt;
-    double var = q / cnt - mean * mean;
-    if (var < 0.0) var = 0.0;
-    const double rstd = 1.0 / sqrt(var + (double)eps);
-    for (int c = g * cpg + lane; c < (g + 1) * cpg; c += 64) {
-      const double gm = gamma ? (double)gamma[c] : 1.0;
-      const double bt = beta ? (double)beta[c] : 0.0;
-      scale[c] = (float)(gm * rstd);
-      shift[c] = (float)(bt - mean * rstd * gm);
-    }
+    __syncthreads();
+  }
+  const double s = red[0].x, q = red[0].y;
+  const double cnt = (double)V * (double)cpg;
+  const double mean = s / cnt;
+  double var = q / cnt - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const double rstd = 1.0 / sqrt(var + (double)eps);
+  for (int c = g * cpg + threadIdx.x; c < (g + 1) * cpg; c += 256) {
+    const double gm = gamma ? (double)gamma[c] : 1.0;
+    const double bt = beta ? (double)beta[c] : 0.0;
+    scale[c] = (float)(gm * rstd);
+    shift[c] = (float)(bt - mean * rstd * gm);
   }
 }
 
@@ -91,7 +111,7 @@ extern "C" int tln_groupnorm_stats(const float* d_x, int64_t V, int C, int group
   hipStream_t s = (hipStream_t)stream_;
   const int nblk = (int)tln_cdiv(V, GN_ROWS_PER_BLOCK);
   hipLaunchKernelGGL(k_gn_partial, dim3(nblk, (unsigned)tln_cdiv(C, 64)), dim3(256), 0, s, d_x, V, C, (double2*)d_ws);
-  hipLaunchKernelGGL(k_gn_finalize, dim3((unsigned)tln_cdiv(groups, 4)), dim3(256), 0, s, (const double2*)d_ws, nblk, V,
+  hipLaunchKernelGGL(k_gn_finalize, dim3((unsigned)groups), dim3(256), 0, s, (const double2*)d_ws, nblk, V,
                      C, groups, d_gamma, d_beta, eps, d_scale, d_shift);
   TLN_LAUNCH_CHECK();
   return TLN_OK;
@@ -113,7 +133,7 @@ extern "C" int tln_groupnorm_from_partials(const void* d_partials, int64_t V, in
   TLN_REQUIRE(V > 0 && C > 0 && groups > 0 && C % groups == 0, "bad groupnorm shape V=%lld C=%d G=%d", (long long)V, C,
               groups);
   const int nblk = (int)tln_cdiv(V, GN_ROWS_PER_BLOCK);
-  hipLaunchKernelGGL(k_gn_finalize, dim3((unsigned)tln_cdiv(groups, 4)), dim3(256), 0, (hipStream_t)stream_,
+  hipLaunchKernelGGL(k_gn_finalize, dim3((unsigned)groups), dim3(256), 0, (hipStream_t)stream_,
                      (const double2*)d_partials, nblk, V, C, groups, d_gamma, d_beta, eps, d_scale, d_shift);
   TLN_LAUNCH_CHECK();
   return TLN_OK;

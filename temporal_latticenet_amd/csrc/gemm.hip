@@ -23,46 +23,7 @@
 // loads of the next two chunks are in flight while the current one feeds the MFMAs.
 // Epilogue: + bias, + residual, ReLU, and optionally the per-32-row (sum, sum^2) of every output column in fp64 —
 // the GroupNorm statistics of the NEXT layer, so that no separate pass over the tensor is needed.
-#include "common.h"
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-struct SrcDev {
-  const float* src;
-  const int32_t* table;
-  const float* scale;
-  const float* shift;
-  int64_t src_rows, ld;
-  int cin, taps, relu;
-  float pad;
-  // GroupNorm finalised inside the kernel from per-32-row partial sums (source 0 only)
-  const double2* gn_part;
-  const float* gn_gamma;
-  const float* gn_beta;
-  int64_t gn_rows;
-  int gn_nblk, gn_groups;
-  float gn_eps;
-};
-
-struct GemmArgs {
-  int64_t M;
-  int N, K0;
-  SrcDev s[2];
-  int nsrc;
-  const float* W;
-  int64_t ldw;
-  const float* bias;
-  const float* res;
-  int64_t ld_res;
-  int relu;
-  float* out;
-  int64_t ld_out;
-  double2* stats;   // optional [cdiv(M,32)][N] (sum, sumsq) of the final values
-  float* slab;      // split-K partial tiles [S][tiles][TM*TN*16][GT]
-  int* counters;    // split-K arrival counters [tiles], zero between launches
-  int splits;
-  unsigned long long* dbg;  // diagnostic: s_memtime stamps of block (0,0,0) (tools/gemm_stamps.py), else NULL
-};
+#include "gemm_args.h"
 
 template <int WM, int TM, int TN, int BK, int G, bool W_NK, bool VEC>
 __global__ void __launch_bounds__(128 * WM * G) k_gather_gemm(const GemmArgs g) {
@@ -1081,7 +1042,7 @@ static Plan make_plan(int64_t M, int N, int nchunks) {
 // everything tln_gather_gemm_ex decides before it launches anything
 struct Prep {
   GemmArgs g;
-  bool vec = false, bk32 = false, gn_fallback = false, direct = false;
+  bool vec = false, bk32 = false, gn_fallback = false, direct = false, v2 = false;
   int nchunks = 0, K = 0;
   Plan p{2, 1, 1, 1, 1};
 };
@@ -1145,6 +1106,13 @@ static int prepare_gemm(int64_t M, int N, const tln_gemm_src* s0, const tln_gemm
   }
   const bool direct_small = q.p.wm == 1;
   q.direct = direct_ok && g_force_direct >= 0 && (direct_small || g_force_direct > 0);
+  // large M: 128-row block tiles with both operands staged once per block (gemm_v2.hip); not under the tuning overrides
+  q.v2 = g_force_direct == 0 && !g_force_tm && !g_force_tn && !g_force_groups && !g_force_splits &&
+         tln_gemm_v2_ok(g, w_is_nk != 0, vec);
+  if (q.v2) {
+    q.direct = false;
+    q.gn_fallback = g.s[0].gn_part != nullptr;   // statistics finalised by their own (parallel) launch
+  }
   return TLN_OK;
 }
 
@@ -1203,6 +1171,12 @@ extern "C" int tln_gather_gemm_ex(int64_t M, int N, const tln_gemm_src* s0, cons
                                      const_cast<float*>(s0->d_shift), stream_);
     if (rc) return rc;
     g.s[0].gn_part = nullptr;
+  }
+  if (q.v2) {
+    rc = tln_gemm_v2_launch(g, w_is_nk != 0, s);
+    if (rc) return rc;
+    TLN_LAUNCH_CHECK();
+    return TLN_OK;
   }
   if (!q.vec) {
     rc = w_is_nk ? launch_gemm<2, 1, 1, 16, 1, true, false>(g, 1, s) : launch_gemm<2, 1, 1, 16, 1, false, false>(g, 1, s);

@@ -1,0 +1,48 @@
+// Argument block shared by the gather-GEMM kernels (gemm.hip: tiled small/medium M and direct; gemm_v2.hip: large M).
+#pragma once
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct SrcDev {
+  const float* src;
+  const int32_t* table;
+  const float* scale;
+  const float* shift;
+  int64_t src_rows, ld;
+  int cin, taps, relu;
+  float pad;
+  // GroupNorm finalised inside the kernel from per-32-row partial sums (source 0 only)
+  const double2* gn_part;
+  const float* gn_gamma;
+  const float* gn_beta;
+  int64_t gn_rows;
+  int gn_nblk, gn_groups;
+  float gn_eps;
+};
+
+struct GemmArgs {
+  int64_t M;
+  int N, K0;
+  SrcDev s[2];
+  int nsrc;
+  const float* W;
+  int64_t ldw;
+  const float* bias;
+  const float* res;
+  int64_t ld_res;
+  int relu;
+  float* out;
+  int64_t ld_out;
+  double2* stats;   // optional [cdiv(M,32)][N] (sum, sumsq) of the final values
+  float* slab;      // split-K partial tiles [S][tiles][TM*TN*16][GT]
+  int* counters;    // split-K arrival counters [tiles], zero between launches
+  int splits;
+  unsigned long long* dbg;  // diagnostic: s_memtime stamps of block (0,0,0) (tools/gemm_stamps.py), else NULL
+};
+
+
+// gemm_v2.hip: the large-M kernel (block tile 128 x N, operands staged by LDS-DMA).  tln_gemm_v2_ok decides from the
+// prepared arguments alone, so every route (operator call, frame program, lock-step group) takes the same kernel.
+bool tln_gemm_v2_ok(const GemmArgs& g, bool w_is_nk, bool vec);
+int tln_gemm_v2_launch(GemmArgs& g, bool w_is_nk, hipStream_t s);

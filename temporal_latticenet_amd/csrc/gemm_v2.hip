@@ -1,0 +1,301 @@
+// K3+K4 for LARGE M (a level-0 lattice of a SemanticKITTI-sized scan: 2-3 x 10^4 vertices and more).
+//
+// Same product as gemm.hip (reference call sites lattice_modules.py:301/440/573, models.py:353/398, the 1x1 linears
+// and the GRU projections lm:47-62): out[M,N] = prologue(gather(src, table))[M, taps*cin] @ W (+bias, +residual, ReLU),
+// `v_mfma_f32_32x32x2_f32` (exact fp32).  What changes is who fetches what.  At M ~ 3 x 10^4 the direct kernel
+// (one wave per 32x32 tile) gathers every source row N/32 times and the 64x64-tile kernel N/64 times, each wave
+// through its own vector-memory path: the gather, not the matrix pipe, sets their pace (80 / 62 TFLOP/s on
+// 192 -> 192).  Here a block owns 128 rows x ALL its columns (up to 192 per block):
+//   * A (gathered rows) and B (weights) are staged ONCE per block and K chunk by LDS-DMA (`global_load_lds_dwordx4`,
+//     16 B per lane, no VGPR round trip): A as 128-byte row pieces [BM][32 floats] whose 16-byte slots are
+//     XOR-swizzled with the row ((row>>1)&7, applied on the SOURCE address since the DMA image is lane-linear), so
+//     that the operand reads are conflict-free `ds_read_b128`; B as [32][BN] ([K,N] weights, `ds_read_b32`) or as
+//     [BN][32] ([N,K] weights, like A);
+//   * a ring of three LDS stages, loads two chunks ahead, ONE barrier per chunk: `s_waitcnt vmcnt(pieces)` (the
+//     next chunk's DMAs stay in flight) -> `s_barrier` -> issue chunk t+2 -> multiply chunk t;
+//   * four waves as 2 x 2 (or 4 x 1 for narrow N), each 64 x 96 / 64 x 64 / 32 x 64 outputs; the k order inside a
+//     chunk is permuted (lane half h takes k = 8j + 4h + e), identically for A and B, so one b128 read feeds 4 MFMAs;
+//   * the GroupNorm affine + ReLU of the consumer side (GN -> ReLU -> conv) is applied when a fragment is read, a
+//     missing neighbour stays an exact zero row (flag from the tap table in LDS), as in gemm.hip;
+//   * epilogue as in gemm.hip: bias, residual, ReLU, per-32-row (sum, sum^2) in fp64 for the next GroupNorm.
+// One source only (the two-source products live on small levels); rows past the source read as zeros (pad = 0).
+#include "gemm_args.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __attribute__((aligned(16))) float g_v2_zero[4] = {0.f, 0.f, 0.f, 0.f};
+
+#define V2_STAGES 3
+
+template <int WM, int WN, int TM, int TN, bool W_NK, bool PRO>
+__global__ void __launch_bounds__(64 * WM * WN) k_gather_gemm_v2(const GemmArgs g) {
+  constexpr int NT = 64 * WM * WN;
+  constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
+  constexpr int STAGE = A_BYTES + B_BYTES;
+  constexpr int A_PIECES = BM * 8 / NT, B_PIECES = BN * 8 / NT;
+  constexpr int PIECES = A_PIECES + B_PIECES;
+  static_assert((BM * 8) % NT == 0 && (BN * 8) % NT == 0, "whole pieces per thread");
+  static_assert(PIECES < 32, "vmcnt immediate");
+
+  extern __shared__ __attribute__((aligned(16))) char smem2[];
+  char* ring = smem2;
+  int* Is = reinterpret_cast<int*>(smem2 + V2_STAGES * STAGE);            // [BM][taps]
+  const SrcDev& s = g.s[0];
+  const int taps = s.taps;
+  float* Gsc = reinterpret_cast<float*>(Is + BM * TLN_TAPS);
+  float* Gsh = Gsc + s.cin;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wv / WN, wn = wv % WN;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int64_t m0 = (int64_t)blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const bool has_table = s.table != nullptr;
+  const int src_rows = (int)s.src_rows;
+
+  // ---- block prologue: tap indices (or the row's own index) and the GroupNorm scale / shift -> LDS
+  for (int i = tid; i < BM * taps; i += NT) {
+    const int r = i / taps;
+    const int64_t m = m0 + r;
+    int idx = -1;
+    if (m < g.M) idx = has_table ? s.table[m * taps + (i - r * taps)] : (int)m;
+    if (idx >= src_rows) idx = -1;            // rows past the source: zeros (pad value 0, checked on the host)
+    Is[i] = idx;
+  }
+  if (PRO) {
+    for (int c = tid; c < s.cin; c += NT) {
+      Gsc[c] = s.scale[c];
+      Gsh[c] = s.shift[c];
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const int cpt = s.cin >> 5;                 // chunks per tap
+  const int nchunks = taps * cpt;
+  const float* zero = g_v2_zero;
+
+  // issue the LDS-DMAs of chunk t into stage st: every thread PIECES x 16 bytes, lane-linear pieces of 1 KiB per wave
+  auto issue = [&](int t, int st) {
+    const int tap = t / cpt;
+    const int c0 = (t - tap * cpt) << 5;
+    const int kbase = tap * s.cin + c0;
+    char* As = ring + st * STAGE;
+    char* Bs = As + A_BYTES;
+#pragma unroll
+    for (int p = 0; p < A_PIECES; ++p) {
+      const int e = p * NT + tid;
+      const int r = e >> 3, q = e & 7;
+      const int idx = Is[r * taps + tap];
+      const float* src = idx >= 0 ? s.src + (int64_t)idx * s.ld + c0 + 4 * (q ^ ((r >> 1) & 7)) : zero;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(As + (p * NT + wv * 64) * 16), 16, 0, 0);
+    }
+#pragma unroll
+    for (int p = 0; p < B_PIECES; ++p) {
+      const int e = p * NT + tid;
+      const float* src;
+      if (!W_NK) {
+        const int k = e / (BN / 4), nq = e - k * (BN / 4);
+        const int n = n0 + 4 * nq;
+        src = n < g.N ? g.W + (int64_t)(kbase + k) * g.ldw + n : zero;
+      } else {
+        const int r = e >> 3, q = e & 7;
+        const int n = n0 + r;
+        src = n < g.N ? g.W + (int64_t)n * g.ldw + kbase + 4 * (q ^ ((r >> 1) & 7)) : zero;
+      }
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(Bs + (p * NT + wv * 64) * 16), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  const int arow0 = wm * 32 * TM + l31;       // this lane's A row of tile 0 inside the block
+  const int bcol0 = wn * 32 * TN + l31;       // this lane's B column of tile 0 inside the block
+
+  // One chunk = four steps of 8 k (lane half h holds k = 8j + 4h + e, e = 0..3).  The fragments of step j+1 are
+  // requested BEFORE the MFMAs of step j are issued (two register sets), so that with one wave per SIMD the LDS
+  // latency and the prologue arithmetic sit behind 4*TM*TN MFMAs instead of in front of them; the DMAs of chunk t+2
+  // are issued after the first step's MFMAs for the same reason.
+  struct Frag {
+    f32x4 a[TM];
+    float b[TN][4];
+  };
+  auto frag_load = [&](int j, const char* As, const char* Bs, Frag& f) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int r = arow0 + 32 * i;
+      f.a[i] = *reinterpret_cast<const f32x4*>(As + r * 128 + (((2 * j + half) ^ ((r >> 1) & 7)) << 4));
+    }
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn) {
+      if (!W_NK) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          f.b[jn][e] = *reinterpret_cast<const float*>(Bs + ((8 * j + 4 * half + e) * BN + bcol0 + 32 * jn) * 4);
+      } else {
+        const int r = bcol0 + 32 * jn;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(Bs + r * 128 + (((2 * j + half) ^ ((r >> 1) & 7)) << 4));
+        f.b[jn][0] = v[0];
+        f.b[jn][1] = v[1];
+        f.b[jn][2] = v[2];
+        f.b[jn][3] = v[3];
+      }
+    }
+  };
+  auto frag_mma = [&](int j, int c0, const bool (&live)[TM], Frag& f) {
+    if (PRO) {
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(Gsc + c0 + 8 * j + 4 * half);
+      const f32x4 sh = *reinterpret_cast<const f32x4*>(Gsh + c0 + 8 * j + 4 * half);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          // GroupNorm affine, ReLU as an integer max on the bit pattern, then the zero row of a missing neighbour
+          const float v = fmaf(f.a[i][e], sc[e], sh[e]);
+          const float rl = __int_as_float(max(__float_as_int(v), 0));
+          f.a[i][e] = live[i] ? rl : 0.0f;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn)
+          acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][e], f.b[jn][e], acc[i][jn], 0, 0, 0);
+  };
+
+  // ---- main loop: ring of three stages, DMAs two chunks ahead, one barrier per chunk
+  issue(0, 0);
+  if (nchunks > 1) issue(1, 1);
+  int st = 0;
+  for (int t = 0; t < nchunks; ++t) {
+    // this thread's DMAs of chunk t have landed (those of chunk t+1 may still fly); after the barrier everybody's
+    // have, and everybody has finished reading the stage that chunk t+2 is about to overwrite
+    if (t + 1 < nchunks) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PIECES) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    const int tap = t / cpt;
+    const int c0 = (t - tap * cpt) << 5;
+    const char* As = ring + st * STAGE;
+    const char* Bs = As + A_BYTES;
+    bool live[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) live[i] = PRO ? Is[(arow0 + 32 * i) * taps + tap] >= 0 : true;
+    Frag f0, f1;
+    frag_load(0, As, Bs, f0);
+    frag_load(1, As, Bs, f1);
+    frag_mma(0, c0, live, f0);
+    if (t + 2 < nchunks) issue(t + 2, st == 0 ? 2 : st - 1);
+    frag_load(2, As, Bs, f0);
+    frag_mma(1, c0, live, f1);
+    frag_load(3, As, Bs, f1);
+    frag_mma(2, c0, live, f0);
+    frag_mma(3, c0, live, f1);
+    st = st == V2_STAGES - 1 ? 0 : st + 1;
+  }
+
+  // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).  The residual is loaded for a whole
+  // 32x32 tile at once from clamped (always valid) addresses: a per-element "load or not" makes the compiler branch
+  // around every load and wait for each one.
+  const bool has_res = g.res != nullptr;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * 32 * TN + j * 32 + l31;
+      const bool ncol = n < g.N;
+      const int nc = ncol ? n : g.N - 1;
+      const float bias = g.bias ? g.bias[nc] : 0.f;
+      const int64_t mrow0 = m0 + wm * 32 * TM + i * 32;
+      float rv[16];
+      if (has_res) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t m = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          rv[r] = g.res[(m < g.M ? m : g.M - 1) * g.ld_res + nc];
+        }
+      }
+      double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t m = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const bool ok = ncol && m < g.M;
+        float v = acc[i][j][r] + bias;
+        if (has_res) v += rv[r];
+        if (g.relu) v = fmaxf(v, 0.f);
+        if (ok) g.out[m * g.ld_out + n] = v;
+        const double dv = ok ? (double)v : 0.0;
+        s1 += dv;
+        s2 += dv * dv;
+      }
+      if (g.stats) {  // wave-uniform
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        if (half == 0 && ncol && mrow0 < g.M) g.stats[(mrow0 >> 5) * g.N + n] = make_double2(s1, s2);
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------
+static int64_t g_v2_min_m = 12288;   // below: gemm.hip's kernels (one wave per 32x32 tile fills the CUs better)
+static int g_v2_off = 0;
+extern "C" void tln_gemm_v2_config(int off, int64_t min_m) {
+  g_v2_off = off;
+  if (min_m > 0) g_v2_min_m = min_m;
+}
+
+bool tln_gemm_v2_ok(const GemmArgs& g, bool w_is_nk, bool vec) {
+  if (g_v2_off || !vec || g.nsrc != 1 || g.M < g_v2_min_m) return false;
+  const SrcDev& s = g.s[0];
+  if (s.cin % 32 != 0 || s.cin > 1024 || s.pad != 0.f) return false;
+  if (!(s.taps == 1 || s.taps == TLN_TAPS)) return false;
+  if (s.src_rows >= (1ll << 31) || g.M >= (1ll << 31)) return false;
+  // prologue: none, or GroupNorm affine + ReLU (scale/shift given, or partial sums with the scale/shift scratch)
+  const bool affine = s.scale != nullptr || s.gn_part != nullptr;
+  if (affine && (!s.relu || s.scale == nullptr || s.shift == nullptr)) return false;
+  if (!affine && s.relu) return false;
+  if (g.N % 32 != 0 && g.N != 96) return false;
+  const int n = g.N;
+  return n == 64 || n == 96 || n % 128 == 0 || n % 192 == 0;
+}
+
+template <int WM, int WN, int TM, int TN, bool W_NK, bool PRO>
+static int launch_v2(GemmArgs& g, hipStream_t s) {
+  constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+  const size_t lds = (size_t)V2_STAGES * (BM + BN) * 128 + (size_t)BM * TLN_TAPS * 4 + (size_t)2 * g.s[0].cin * 4;
+  TLN_REQUIRE(lds <= 160 * 1024, "gemm v2: LDS %zu B", lds);
+  auto kern = k_gather_gemm_v2<WM, WN, TM, TN, W_NK, PRO>;
+  // set every time: the attribute is per device and this library serves several (one process per GPU is the normal case)
+  TLN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  dim3 grid((unsigned)tln_cdiv(g.M, BM), (unsigned)tln_cdiv(g.N, BN), 1);
+  g.splits = 1;
+  hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, s, g);
+  return TLN_OK;
+}
+
+template <bool W_NK, bool PRO>
+static int dispatch_v2(GemmArgs& g, hipStream_t s) {
+  const int n = g.N;
+  if (n % 192 == 0) return launch_v2<2, 2, 2, 3, W_NK, PRO>(g, s);   // 128 x 192, waves 64 x 96
+  if (n % 128 == 0) return launch_v2<2, 2, 2, 2, W_NK, PRO>(g, s);   // 128 x 128, waves 64 x 64
+  if (n == 96) return launch_v2<4, 1, 1, 3, W_NK, PRO>(g, s);        // 128 x 96, waves 32 x 96
+  return launch_v2<4, 1, 1, 2, W_NK, PRO>(g, s);                     // 128 x 64, waves 32 x 64
+}
+
+int tln_gemm_v2_launch(GemmArgs& g, bool w_is_nk, hipStream_t s) {
+  const bool pro = g.s[0].scale != nullptr;
+  if (w_is_nk) return pro ? dispatch_v2<true, true>(g, s) : dispatch_v2<true, false>(g, s);
+  return pro ? dispatch_v2<false, true>(g, s) : dispatch_v2<false, false>(g, s);
+}

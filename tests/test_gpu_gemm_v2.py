@@ -1,0 +1,133 @@
+"""GPU: the large-M gather-GEMM (csrc/gemm_v2.hip: 128-row block tiles, operands staged by LDS-DMA) against the
+oracle's im2row @ W and against the small/medium-M kernels of gemm.hip on the same inputs.  The kernel normally takes
+over at M >= 12288; here it is forced on for a ~9k-vertex lattice (ragged last tile) and also run at its natural size."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ops as O
+from oracle import permuto as P
+from temporal_latticenet_amd.synthetic import make_sequence
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lattice(gpu):
+    from temporal_latticenet_amd.lattice import Lattice
+    pos, val = make_sequence(20000, 1, seed=21)[0]
+    lat = Lattice.from_params([0.5] * 3, 1 << 17)
+    lat.distribute(torch.from_numpy(pos).to(gpu), torch.from_numpy(val).to(gpu))
+    tab = P.VertexTable(3, 1 << 17)
+    O.distribute(tab, pos, val, [0.5] * 3)
+    assert tab.nr_vertices == lat.nr_lattice_vertices()
+    return lat, P.neighbour_table(tab)
+
+
+@pytest.fixture
+def v2_forced():
+    from temporal_latticenet_amd import _lib
+    lib = _lib.lib()
+    lib.tln_gemm_v2_config(0, 1)
+    yield lib
+    lib.tln_gemm_v2_config(0, 12288)
+
+
+# (cin, cout, taps, weights as [N,K], GroupNorm+ReLU prologue, bias, residual, relu)
+CASES = [
+    (64, 64, 9, False, True, False, True, False),      # level-0 ResNet conv: GN -> ReLU -> conv + identity
+    (128, 64, 9, False, True, False, False, False),    # finefy-shaped
+    (192, 192, 9, False, True, True, True, True),      # the K-heavy level-0 product, every epilogue switch
+    (256, 128, 9, False, False, True, False, False),   # 128-column tile, no prologue
+    (192, 96, 1, True, True, False, False, False),     # slice step-down 1x1 (Linear weights are [out, in])
+    (192, 576, 1, True, False, True, False, False),    # GRU projection x @ W_ih^T + b_ih
+    (64, 192, 1, True, False, True, False, False),
+    (128, 384, 1, True, False, True, False, False),
+    (64, 256, 1, False, False, False, False, True),
+]
+
+
+@pytest.mark.parametrize("cin,cout,taps,nk,pro,use_bias,use_res,relu", CASES)
+def test_v2_matches_oracle_and_the_other_kernels(gpu, lattice, v2_forced, cin, cout, taps, nk, pro, use_bias, use_res, relu):
+    from temporal_latticenet_amd import ops
+    lat, table = lattice
+    V = lat.nr_lattice_vertices()
+    assert V % 128 != 0
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    lv = torch.randn(V, cin, generator=g)
+    W = torch.randn(taps * cin, cout, generator=g) / np.sqrt(taps * cin)
+    bias = torch.randn(cout, generator=g) if use_bias else None
+    res = torch.randn(V, cout, generator=g) if use_res else None
+    gamma, beta = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g)
+
+    def run():
+        kw = {}
+        if pro:
+            sc, sh = ops.groupnorm_stats(lv.to(gpu), 32, gamma.to(gpu), beta.to(gpu))
+            kw = dict(scale=sc, shift=sh, relu=True)
+        s0 = ops.gemm_src(lv.to(gpu), lat.neighbour_table_ptr() if taps == 9 else None, taps, **kw)
+        Wd = (W.t().contiguous() if nk else W).to(gpu)
+        return ops.gather_gemm(V, Wd, s0, w_is_nk=nk, bias=None if bias is None else bias.to(gpu),
+                               residual=None if res is None else res.to(gpu), relu=relu, stats=True)
+
+    out = run()
+    again = run()
+    assert torch.equal(out, again), "bitwise reproducible"
+    x = torch.relu(O.group_norm(lv, gamma, beta)) if pro else lv
+    want = (O.im2row(x, table) if taps == 9 else x) @ W
+    if bias is not None:
+        want = want + bias
+    if res is not None:
+        want = want + res
+    if relu:
+        want = torch.relu(want)
+    np.testing.assert_allclose(out.cpu().numpy(), want.numpy(), rtol=1e-4, atol=5e-5)
+    # the fused GroupNorm partial sums describe the tensor that was written
+    st = out._tln_stats.cpu()
+    got = out.cpu().double()
+    nb = (V + 31) // 32
+    blk = torch.cat([got, torch.zeros(nb * 32 - V, cout, dtype=torch.float64)]).reshape(nb, 32, cout)
+    np.testing.assert_allclose(st[:, :, 0].numpy(), blk.sum(1).numpy(), rtol=1e-12, atol=1e-9)
+    np.testing.assert_allclose(st[:, :, 1].numpy(), (blk * blk).sum(1).numpy(), rtol=1e-12, atol=1e-9)
+    # same product from gemm.hip's kernels (v2 off): equal up to the order of the K summation
+    v2_forced.tln_gemm_v2_config(1, 0)
+    try:
+        other = run()
+    finally:
+        v2_forced.tln_gemm_v2_config(0, 1)
+    np.testing.assert_allclose(out.cpu().numpy(), other.cpu().numpy(), rtol=1e-4, atol=5e-5)
+
+
+def test_v2_rows_past_the_source_read_as_zeros(gpu, lattice, v2_forced):
+    """the GRU's h @ W_hh: the hidden state has fewer rows than the frame's lattice (lm:59-60 pads with zeros)"""
+    from temporal_latticenet_amd import ops
+    lat, _ = lattice
+    V = lat.nr_lattice_vertices()
+    Vh = V - 1234
+    g = torch.Generator().manual_seed(3)
+    h = torch.randn(Vh, 64, generator=g)
+    W = torch.randn(192, 64, generator=g) / 8
+    b = torch.randn(192, generator=g)
+    s0 = ops.gemm_src(h.to(gpu), None, 1)
+    out = ops.gather_gemm(V, W.to(gpu), s0, w_is_nk=True, bias=b.to(gpu))
+    want = torch.cat([h, torch.zeros(V - Vh, 64)]) @ W.t() + b
+    np.testing.assert_allclose(out.cpu().numpy(), want.numpy(), rtol=1e-4, atol=2e-5)
+
+
+def test_v2_at_its_natural_size(gpu):
+    """a 120k-point frame at sigma 0.6 (~19k vertices): the library picks the kernel by itself"""
+    from temporal_latticenet_amd import ops
+    from temporal_latticenet_amd.lattice import Lattice
+    pos, val = make_sequence(120000, 1)[0]
+    lat = Lattice.from_params([0.6] * 3, 1 << 17)
+    lat.distribute(torch.from_numpy(pos).to(gpu), torch.from_numpy(val).to(gpu))
+    V = lat.nr_lattice_vertices()
+    assert V >= 12288
+    nb = lat.neighbour_table().cpu().numpy()
+    g = torch.Generator().manual_seed(9)
+    lv = torch.randn(V, 192, generator=g)
+    W = torch.randn(9 * 192, 192, generator=g) / np.sqrt(9 * 192)
+    out = ops.gather_gemm(V, W.to(gpu), ops.gemm_src(lv.to(gpu), lat.neighbour_table_ptr(), 9))
+    rows = np.random.default_rng(0).choice(V, 2048, replace=False)
+    want = O.im2row(lv, nb[rows]) @ W
+    np.testing.assert_allclose(out.cpu().numpy()[rows], want.numpy(), rtol=1e-4, atol=2e-5)
