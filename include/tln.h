@@ -48,12 +48,14 @@ int tln_lattice_insert_keys(tln_lattice_t* l, const int32_t* d_keys, int64_t n, 
 /* d_positions [n,3], d_values [n,val_dim] -> d_distributed [4n, 3+val_dim+1],
  * d_indices [4n] (-1 = not inserted), d_weights [4n].  subtract_mean: rows carry
  * position - mean position of their vertex (0 for the *_no_local_mean experiments).
- * Leaves a vertex-sorted row list (CSR) in the handle for tln_pointnet_pool. */
+ * Leaves the frame's rows grouped by vertex ("bins": payload moved to one contiguous segment per vertex, no sort) in
+ * the handle; tln_pointnet_pool called with the same d_distributed / rows reads them.  d_distributed may be NULL when
+ * only the pool of the same frame consumes the rows (the frame program does that). */
 int tln_distribute(tln_lattice_t* l, const float* d_positions, const float* d_values, int64_t n,
                    int val_dim, int subtract_mean, float* d_distributed, int32_t* d_indices,
                    float* d_weights, void* stream);
 /* the same in two halves: _begin enqueues the insertion / numbering and starts the fetch of the vertex counters,
- * _finish waits for that fetch only and enqueues the CSR and the mean subtraction.  A caller with several lattices
+ * and the bins, _finish waits for that fetch only and enqueues the mean subtraction of d_distributed.  A caller with several lattices
  * on one stream (lock-step groups) begins all of them before it finishes the first: one wait instead of one per
  * lattice.  The buffers given to _begin must stay valid until _finish has returned. */
 int tln_distribute_begin(tln_lattice_t* l, const float* d_positions, const float* d_values, int64_t n,
@@ -61,7 +63,10 @@ int tln_distribute_begin(tln_lattice_t* l, const float* d_positions, const float
                    float* d_weights, void* stream);
 int tln_distribute_finish(tln_lattice_t* l, void* stream);
 
-/* rebuild the CSR from caller-supplied indices (R rows, -1 folded into the tail bucket) */
+/* forget the bins of the last distribute (the caller edited d_distributed in place): the next pool goes through a CSR */
+int tln_lattice_drop_bins(tln_lattice_t* l);
+
+/* build the vertex-sorted row list (CSR) from caller-supplied indices (R rows, -1 folded into the tail bucket) */
 int tln_build_csr(tln_lattice_t* l, const int32_t* d_indices, int64_t rows, void* stream);
 
 /* copy the handle's CSR out (any pointer may be NULL): order[rows] = row ids sorted stably by vertex,

@@ -73,6 +73,22 @@ __device__ __forceinline__ float tln_unfix20(long long sum, double cnt) {
   return (float)(((double)sum / cnt) * (1.0 / 1048576.0));
 }
 
+// the vertex bins of the last distribute (lattice.hip) as the pool (pool.hip) sees them
+struct tln_lattice;
+struct TlnBins {
+  const float4* xyzv;      // [rows] position, value — grouped by vertex, rows without a vertex last
+  const float* w;          // [rows] barycentric weight
+  const int32_t* row;      // [rows] row id (4 * point + simplex vertex)
+  const int32_t* vtx;      // [rows] vertex index, -1 = none
+  const int32_t* vstart;   // [V] first bin position of a vertex
+  const int32_t* vcnt;     // [V] rows of the frame on a vertex
+  const float* mean;       // [V][3] local mean of the frame (valid when subtract)
+  const int32_t* ctr;      // device counters: [0] = V, [6] = rows placed in vertex segments
+  const float* weights;    // [rows] barycentric weights in row order
+  int subtract;
+};
+bool tln_lat_bins(const tln_lattice* l, const float* d_distributed, int64_t rows, TlnBins* out);
+
 // ---- key packing / hashing (d = 3) ------------------------------------------------------
 #define TLN_KEY_BIAS (1 << 20)
 #define TLN_KEY_EMPTY 0xFFFFFFFFFFFFFFFFull

@@ -27,7 +27,8 @@ extern "C" int tln_version(void) { return 1; }
 // ---------------------------------------------------------------------------------------
 // handle
 // ---------------------------------------------------------------------------------------
-enum { CTR_NV = 0, CTR_NEW = 1, CTR_OVERFLOW = 2, CTR_PROBE_FAIL = 3, CTR_VOLD = 4, CTR_OCCUPIED = 5, CTR_COUNT = 8 };
+enum { CTR_NV = 0, CTR_NEW = 1, CTR_OVERFLOW = 2, CTR_PROBE_FAIL = 3, CTR_VOLD = 4, CTR_OCCUPIED = 5,
+       CTR_CURSOR = 6 /* rows placed in vertex bins */, CTR_TAIL = 7 /* rows without a vertex */, CTR_COUNT = 8 };
 #define TLN_MAX_PROBES 8192
 #define TLN_SCAN_BLOCK 1024
 
@@ -46,13 +47,10 @@ struct tln_lattice {
   int64_t occupied = 0;  // claimed slots (numbered vertices + keys rejected by the capacity)
   // tables (owned)
   int32_t* nbr = nullptr;
-  int64_t nbr_built_for = -1;
   tln_lattice* coarse = nullptr;
   tln_lattice* parent = nullptr;
   int32_t* c2f = nullptr;
-  int64_t c2f_vc = -1, c2f_vf = -1;
   int32_t* f2c = nullptr;
-  int64_t f2c_vc = -1, f2c_vf = -1;
   int64_t embedded_fine = 0;
   // tln_lattice_prepare_levels_begin without its _finish yet: coarse counters are in flight (root level only)
   int levels_pending = 0;
@@ -79,6 +77,30 @@ struct tln_lattice {
   // pool workspace
   unsigned long long* pool_packed = nullptr;
   int64_t pool_packed_elems = 0;
+  // ---- vertex bins of the last distribute (level 0 only): the frame's rows grouped by vertex WITHOUT a sort.
+  // k_distribute_insert counts the rows of every slot (the atomic's return value is the row's rank inside its
+  // vertex), k_bins_alloc hands every vertex a contiguous segment, k_bins_scatter moves the row payload there.  The
+  // order of the rows inside a segment and of the segments is arbitrary; everything computed from them (max / arg-max
+  // with the smallest-row tie rule, fixed-point means) is order-independent.
+  uint32_t* slot_cnt = nullptr;   // [nslots] rows of the current frame per slot; zero between frames
+  int32_t* vslot = nullptr;       // [capacity] slot of vertex v
+  int32_t* row_rank = nullptr;    // [rows_cap]
+  int32_t* vcnt = nullptr;        // [capacity] rows of the frame on vertex v
+  int32_t* vstart = nullptr;      // [capacity] first bin position of vertex v
+  long long* vsum = nullptr;      // [capacity][3] fixed-point position sums of the frame
+  float4* bin_xyzv = nullptr;     // [rows_cap] position, value
+  float* bin_w = nullptr;         // [rows_cap] barycentric weight
+  int32_t* bin_row = nullptr;     // [rows_cap] row id
+  int32_t* bin_vtx = nullptr;     // [rows_cap] vertex (-1: none)
+  int64_t bins_rows = -1;         // rows of the frame the bins hold (-1: none)
+  const float* bins_dist = nullptr;
+  const float* bins_weights = nullptr;
+  int bins_subtract = 0;
+  bool overflow_stale = false;    // CTR_OVERFLOW of the last distribute is still on the device only
+  // structure generation: bumped whenever the vertex set may have changed (clear, any insertion that numbered a
+  // vertex); the neighbour / cross-level tables remember the generations they were built for
+  uint64_t gen = 1;
+  uint64_t nbr_gen = 0, c2f_gen_c = 0, c2f_gen_f = 0, f2c_gen_c = 0, f2c_gen_f = 0;
 };
 
 // accessors for the other translation units
@@ -86,16 +108,30 @@ const int32_t* tln_lat_order(const tln_lattice* l) { return l->sv_out; }
 const int32_t* tln_lat_sorted_vertex(const tln_lattice* l) { return l->sk_out; }
 const int32_t* tln_lat_seg_start(const tln_lattice* l) { return l->seg_start; }
 int64_t tln_lat_csr_rows(const tln_lattice* l) { return l->csr_rows; }
+// the pool's packed (value, ~row) accumulators.  INVARIANT: all zero between pool calls (both finalise kernels write the
+// zeros back), so no per-frame memset of V x 64 x 8 bytes; sized once for the level's capacity.
 int tln_lat_pool_ws(tln_lattice* l, int64_t elems, unsigned long long** out) {
   if (elems > l->pool_packed_elems) {
-    if (l->pool_packed) (void)hipFree(l->pool_packed);
+    if (l->pool_packed) {
+      TLN_HIP(hipDeviceSynchronize());
+      (void)hipFree(l->pool_packed);
+    }
     l->pool_packed = nullptr;
     l->pool_packed_elems = 0;
-    TLN_HIP(hipMalloc(&l->pool_packed, (size_t)elems * sizeof(unsigned long long)));
-    l->pool_packed_elems = elems;
+    int64_t want = l->capacity * 64;
+    if (want < elems) want = elems;
+    TLN_HIP(hipMalloc(&l->pool_packed, (size_t)want * sizeof(unsigned long long)));
+    TLN_HIP(hipMemset(l->pool_packed, 0, (size_t)want * sizeof(unsigned long long)));
+    TLN_HIP(hipDeviceSynchronize());
+    l->pool_packed_elems = want;
   }
   *out = l->pool_packed;
   return TLN_OK;
+}
+
+static void set_vertices(tln_lattice* l, int64_t n) {
+  if (n != l->nr_vertices) ++l->gen;
+  l->nr_vertices = n;
 }
 
 static int bits_for(int64_t v) {
@@ -110,10 +146,15 @@ static int ensure_rows(tln_lattice* l, int64_t rows) {
   if (rows <= l->rows_cap) return TLN_OK;
   int64_t cap = 1;
   while (cap < rows) cap <<= 1;
-  void* ptrs[] = {l->row_slot, l->block_cnt, l->sk_in, l->sk_out, l->sv_in, l->sv_out, l->sort_temp, l->pieces};
+  void* ptrs[] = {l->row_slot, l->block_cnt, l->sk_in, l->sk_out, l->sv_in, l->sv_out, l->sort_temp, l->pieces,
+                  l->row_rank, l->bin_xyzv, l->bin_w, l->bin_row, l->bin_vtx};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   l->row_slot = l->block_cnt = l->sk_in = l->sk_out = l->sv_in = l->sv_out = nullptr;
+  l->row_rank = l->bin_row = l->bin_vtx = nullptr;
+  l->bin_xyzv = nullptr;
+  l->bin_w = nullptr;
+  l->bins_rows = -1;
   l->sort_temp = nullptr;
   l->pieces = nullptr;
   l->rows_cap = 0;
@@ -124,6 +165,13 @@ static int ensure_rows(tln_lattice* l, int64_t rows) {
   TLN_HIP(hipMalloc(&l->sv_in, cap * sizeof(int32_t)));
   TLN_HIP(hipMalloc(&l->sv_out, cap * sizeof(int32_t)));
   TLN_HIP(hipMalloc(&l->pieces, (cap / 256 + 2) * 6 * sizeof(long long)));
+  if (l->level == 0) {
+    TLN_HIP(hipMalloc(&l->row_rank, cap * sizeof(int32_t)));
+    TLN_HIP(hipMalloc(&l->bin_xyzv, cap * sizeof(float4)));
+    TLN_HIP(hipMalloc(&l->bin_w, cap * sizeof(float)));
+    TLN_HIP(hipMalloc(&l->bin_row, cap * sizeof(int32_t)));
+    TLN_HIP(hipMalloc(&l->bin_vtx, cap * sizeof(int32_t)));
+  }
   // radix-sort scratch: ping-pong keys + values and the [256][blocks] digit histogram
   // + the 256 digit bases and the arrival counter of the fused table scan (counter starts, and is left, at zero)
   const size_t hist_ints = (size_t)256 * (cap / RADIX_KPB + 2);
@@ -161,6 +209,13 @@ static int lattice_alloc(tln_lattice** out, int pos_dim, const double* sigmas, i
   TLN_HIP(hipHostMalloc(&l->h_ctr, CTR_COUNT * sizeof(int32_t)));
   TLN_HIP(hipMalloc(&l->seg_start, (capacity + 2) * sizeof(int32_t)));
   TLN_HIP(hipMalloc(&l->mean, capacity * 3 * sizeof(float)));
+  if (level == 0) {
+    TLN_HIP(hipMalloc(&l->slot_cnt, ns * sizeof(uint32_t)));
+    TLN_HIP(hipMalloc(&l->vslot, capacity * sizeof(int32_t)));
+    TLN_HIP(hipMalloc(&l->vcnt, capacity * sizeof(int32_t)));
+    TLN_HIP(hipMalloc(&l->vstart, capacity * sizeof(int32_t)));
+    TLN_HIP(hipMalloc(&l->vsum, capacity * 3 * sizeof(long long)));
+  }
   *out = l;
   return TLN_OK;
 }
@@ -171,6 +226,7 @@ struct ClearJobs {
     uint64_t* key;
     int32_t* val;
     uint32_t* touch;
+    uint32_t* cnt;   // per-slot row counts (level 0), may be NULL
     int32_t* ctr;
     int64_t nslots;
   } j[4];
@@ -184,11 +240,13 @@ __global__ void __launch_bounds__(256) k_clear_levels(ClearJobs jobs) {
     ulonglong2* key2 = reinterpret_cast<ulonglong2*>(jobs.j[k].key);
     int2* val2 = reinterpret_cast<int2*>(jobs.j[k].val);
     uint2* touch2 = reinterpret_cast<uint2*>(jobs.j[k].touch);
+    uint2* cnt2 = reinterpret_cast<uint2*>(jobs.j[k].cnt);
     const int64_t pairs = jobs.j[k].nslots >> 1;  // slot counts are powers of two
     for (int64_t i = id; i < pairs; i += stride) {
       key2[i] = make_ulonglong2(~0ull, ~0ull);
       val2[i] = make_int2(-1, -1);
       touch2[i] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+      if (cnt2) cnt2[i] = make_uint2(0u, 0u);
     }
     if (id < CTR_COUNT) jobs.j[k].ctr[id] = 0;
   }
@@ -209,14 +267,16 @@ extern "C" int tln_lattice_clear(tln_lattice_t* l, void* stream_) {
     jobs.j[jobs.n].key = p->slot_key;
     jobs.j[jobs.n].val = p->slot_val;
     jobs.j[jobs.n].touch = p->slot_touch;
+    jobs.j[jobs.n].cnt = p->slot_cnt;
     jobs.j[jobs.n].ctr = p->d_ctr;
     jobs.j[jobs.n].nslots = p->nslots;
     ++jobs.n;
     p->nr_vertices = 0;
     p->overflow_rows = 0;
     p->occupied = 0;
-    p->nbr_built_for = -1;
-    p->c2f_vc = p->c2f_vf = p->f2c_vc = p->f2c_vf = -1;
+    ++p->gen;
+    p->bins_rows = -1;
+    p->overflow_stale = false;
     p->embedded_fine = 0;
     p->csr_rows = -1;
   }
@@ -248,7 +308,8 @@ extern "C" int tln_lattice_destroy(tln_lattice_t* l) {
   if (l->coarse) tln_lattice_destroy(l->coarse);
   void* ptrs[] = {l->slot_key, l->slot_val, l->slot_touch, l->vkeys, l->d_ctr, l->nbr, l->c2f, l->f2c,
                   l->row_slot, l->block_cnt, l->sk_in, l->sk_out, l->sv_in, l->sv_out, l->sort_temp,
-                  l->seg_start, l->pool_packed, l->mean, l->pieces};
+                  l->seg_start, l->pool_packed, l->mean, l->pieces, l->slot_cnt, l->vslot, l->vcnt, l->vstart, l->vsum,
+                  l->row_rank, l->bin_xyzv, l->bin_w, l->bin_row, l->bin_vtx};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (l->h_ctr) (void)hipHostFree(l->h_ctr);
@@ -259,7 +320,19 @@ extern "C" int tln_lattice_destroy(tln_lattice_t* l) {
 extern "C" int64_t tln_lattice_nr_vertices(const tln_lattice_t* l) { return l ? l->nr_vertices : -1; }
 extern "C" int64_t tln_lattice_capacity(const tln_lattice_t* l) { return l ? l->capacity : -1; }
 extern "C" int tln_lattice_level(const tln_lattice_t* l) { return l ? l->level : -1; }
-extern "C" int64_t tln_lattice_overflow_rows(const tln_lattice_t* l) { return l ? l->overflow_rows : -1; }
+extern "C" int64_t tln_lattice_overflow_rows(const tln_lattice_t* lc) {
+  if (!lc) return -1;
+  tln_lattice_t* l = const_cast<tln_lattice_t*>(lc);
+  if (l->overflow_stale) {   // the count of the last distribute was finished on the device after the counter fetch
+    int32_t v = 0;
+    if (hipDeviceSynchronize() != hipSuccess ||
+        hipMemcpy(&v, l->d_ctr + CTR_OVERFLOW, sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess)
+      return -1;
+    l->overflow_rows = v;
+    l->overflow_stale = false;
+  }
+  return l->overflow_rows;
+}
 
 // ---------------------------------------------------------------------------------------
 // device: table access
@@ -431,7 +504,8 @@ __device__ __forceinline__ void coarse_simplex(int f0, int f1, int f2, int rem0[
 // slot table growth: probing must never fail, so that ONLY the first-touch numbering decides which
 // keys fit into `capacity` (deterministic overflow, identical to the sequential oracle)
 // ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_rehash(const int32_t* __restrict__ vkeys, int64_t nv, TableRef t) {
+__global__ void __launch_bounds__(256) k_rehash(const int32_t* __restrict__ vkeys, int64_t nv, TableRef t,
+                                                int32_t* __restrict__ vslot) {
   const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= nv) return;
   const uint64_t K = tln_pack_key(vkeys[4 * v], vkeys[4 * v + 1], vkeys[4 * v + 2]);
@@ -441,6 +515,7 @@ __global__ void __launch_bounds__(256) k_rehash(const int32_t* __restrict__ vkey
                                    (unsigned long long)K);
     if (old == TLN_KEY_EMPTY) {
       t.slot_val[slot] = (int32_t)v;
+      if (vslot) vslot[v] = (int32_t)slot;
       return;
     }
     slot = (slot + 1) & t.mask;
@@ -462,6 +537,12 @@ static int ensure_slots(tln_lattice* l, int64_t rows, hipStream_t s) {
   TLN_HIP(hipMemsetAsync(nk, 0xFF, ns * sizeof(uint64_t), s));
   TLN_HIP(hipMemsetAsync(nv, 0xFF, ns * sizeof(int32_t), s));
   TLN_HIP(hipMemsetAsync(nt, 0xFF, ns * sizeof(uint32_t), s));
+  if (l->slot_cnt) {   // between frames every count is zero: the new array just starts that way
+    (void)hipFree(l->slot_cnt);
+    l->slot_cnt = nullptr;
+    TLN_HIP(hipMalloc(&l->slot_cnt, ns * sizeof(uint32_t)));
+    TLN_HIP(hipMemsetAsync(l->slot_cnt, 0, ns * sizeof(uint32_t), s));
+  }
   (void)hipFree(l->slot_key);
   (void)hipFree(l->slot_val);
   (void)hipFree(l->slot_touch);
@@ -471,7 +552,7 @@ static int ensure_slots(tln_lattice* l, int64_t rows, hipStream_t s) {
   l->nslots = ns;
   if (l->nr_vertices > 0) {
     hipLaunchKernelGGL(k_rehash, dim3((unsigned)tln_cdiv(l->nr_vertices, 256)), dim3(256), 0, s, l->vkeys,
-                       l->nr_vertices, table_ref(l));
+                       l->nr_vertices, table_ref(l), l->vslot);
     TLN_LAUNCH_CHECK();
   }
   // keys that were rejected by the capacity are dropped here; they are retried by later insertions
@@ -479,7 +560,7 @@ static int ensure_slots(tln_lattice* l, int64_t rows, hipStream_t s) {
   TLN_HIP(hipMemcpyAsync(l->d_ctr + CTR_OCCUPIED, &occ, sizeof(int32_t), hipMemcpyHostToDevice, s));
   TLN_HIP(hipStreamSynchronize(s));
   l->occupied = l->nr_vertices;
-  l->nbr_built_for = -1;
+  ++l->gen;   // slot numbers changed: nothing cached by slot survives (the tables hold vertex indices, rebuilt anyway)
   return TLN_OK;
 }
 
@@ -492,7 +573,9 @@ static int ensure_slots(tln_lattice* l, int64_t rows, hipStream_t s) {
 __global__ void __launch_bounds__(256) k_distribute_insert(const float* __restrict__ pos, const float* __restrict__ val,
                                                            int64_t n, int val_dim, float s0, float s1, float s2,
                                                            TableRef t, int32_t* __restrict__ row_slot,
-                                                           float* __restrict__ weights, float* __restrict__ dist) {
+                                                           float* __restrict__ weights, float* __restrict__ dist,
+                                                           uint32_t* __restrict__ slot_cnt,
+                                                           int32_t* __restrict__ row_rank) {
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool live_row = (gid >> 2) < n;
   const int64_t p = live_row ? (gid >> 2) : n - 1;   // lanes past the end shadow the last point and store nothing
@@ -515,22 +598,35 @@ __global__ void __launch_bounds__(256) k_distribute_insert(const float* __restri
     const uint64_t K = valid ? tln_pack_key(k0, k1, k2) : 0ull;
     const int lane = threadIdx.x & 63;
     int leader = lane;
+    unsigned long long group = 1ull << lane;
     unsigned long long todo = __ballot(valid);
     while (todo) {                                        // one round per distinct key, no memory traffic
       const int first = __builtin_ctzll(todo);
       const uint64_t kf = __shfl(K, first, 64);
       const unsigned long long same = __ballot(valid && K == kf);
-      if (valid && K == kf) leader = first;
+      if (valid && K == kf) {
+        leader = first;
+        group = same;
+      }
       todo &= ~same;
     }
     int slot = -1;
-    if (valid && leader == lane) slot = probe_insert(t, K, id);
+    int base = 0;
+    if (valid && leader == lane) {
+      slot = probe_insert(t, K, id);
+      // rows of this frame on the slot: the value the atomic returns numbers the group's rows inside their vertex
+      // (the bins of k_bins_scatter; any order will do there)
+      if (slot_cnt && slot >= 0) base = (int)atomicAdd(&slot_cnt[slot], (uint32_t)__popcll(group));
+    }
     slot = __shfl(slot, leader, 64);
+    base = __shfl(base, leader, 64);
     if (live_row) {
       row_slot[id] = valid ? slot : -1;
       weights[id] = b;
+      if (row_rank) row_rank[id] = base + __popcll(group & ((1ull << lane) - 1ull));
     }
   }
+  if (dist == nullptr) return;   // the caller does not want the [4N, 5] rows (frame program: the pool reads the bins)
   if (val_dim == 1) {
     // the 64 rows of a wave are 64 x 20 contiguous bytes: staged through LDS and written as five fully coalesced
     // 256-byte stores instead of five 20-byte-strided ones
@@ -618,6 +714,10 @@ __device__ __forceinline__ bool is_first_touch(const TableRef& t, const int32_t*
 __global__ void __launch_bounds__(TLN_SCAN_BLOCK) k_count_new(TableRef t, const int32_t* __restrict__ row_slot,
                                                               int64_t rows, int32_t* __restrict__ block_cnt) {
   __shared__ int wave_cnt[TLN_SCAN_BLOCK / 64];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {   // the bin allocator of this frame starts from zero
+    t.ctr[CTR_CURSOR] = 0;
+    t.ctr[CTR_TAIL] = 0;
+  }
   const int64_t id = (int64_t)blockIdx.x * TLN_SCAN_BLOCK + threadIdx.x;
   int slot;
   const bool f = is_first_touch(t, row_slot, id, rows, slot);
@@ -637,7 +737,8 @@ __global__ void __launch_bounds__(TLN_SCAN_BLOCK) k_count_new(TableRef t, const 
 __global__ void __launch_bounds__(TLN_SCAN_BLOCK) k_assign_new(TableRef t, const int32_t* __restrict__ row_slot,
                                                                int64_t rows, const int32_t* __restrict__ block_cnt,
                                                                int32_t* __restrict__ ctr, int vold, int capacity,
-                                                               int32_t* __restrict__ vkeys) {
+                                                               int32_t* __restrict__ vkeys,
+                                                               int32_t* __restrict__ vslot) {
   __shared__ int wave_cnt[TLN_SCAN_BLOCK / 64];
   __shared__ int wave_pre[TLN_SCAN_BLOCK / 64];
   const int64_t id = (int64_t)blockIdx.x * TLN_SCAN_BLOCK + threadIdx.x;
@@ -673,6 +774,7 @@ __global__ void __launch_bounds__(TLN_SCAN_BLOCK) k_assign_new(TableRef t, const
   const long long v = (long long)vold + rank;
   if (v < capacity) {
     t.slot_val[slot] = (int)v;
+    if (vslot) vslot[v] = slot;
     int k0, k1, k2;
     tln_unpack_key(t.slot_key[slot], k0, k1, k2);
     int4 kk = make_int4(k0, k1, k2, -(k0 + k1 + k2));
@@ -706,12 +808,17 @@ __global__ void __launch_bounds__(256) k_row_indices(TableRef t, const int32_t* 
 // launch of a single block that walks the rows in order
 __global__ void __launch_bounds__(TLN_SCAN_BLOCK) k_number_small(TableRef t, const int32_t* __restrict__ row_slot,
                                                                  int64_t rows, int32_t* __restrict__ ctr, int capacity,
-                                                                 int32_t* __restrict__ vkeys) {
+                                                                 int32_t* __restrict__ vkeys,
+                                                                 int32_t* __restrict__ vslot) {
   __shared__ int wave_cnt[TLN_SCAN_BLOCK / 64];
   __shared__ int running_s;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int vold = ctr[CTR_NV];
-  if (threadIdx.x == 0) running_s = 0;
+  if (threadIdx.x == 0) {
+    running_s = 0;
+    ctr[CTR_CURSOR] = 0;
+    ctr[CTR_TAIL] = 0;
+  }
   __syncthreads();
   for (int64_t base = 0; base < rows; base += TLN_SCAN_BLOCK) {
     const int64_t id = base + threadIdx.x;
@@ -730,6 +837,7 @@ __global__ void __launch_bounds__(TLN_SCAN_BLOCK) k_number_small(TableRef t, con
       const long long v = (long long)vold + running + woff + __popcll(m & ((1ull << lane) - 1ull));
       if (v < capacity) {
         t.slot_val[slot] = (int)v;
+        if (vslot) vslot[v] = slot;
         int k0, k1, k2;
         tln_unpack_key(t.slot_key[slot], k0, k1, k2);
         *reinterpret_cast<int4*>(vkeys + 4 * v) = make_int4(k0, k1, k2, -(k0 + k1 + k2));
@@ -756,13 +864,13 @@ static int number_new(tln_lattice* l, int64_t rows, hipStream_t s) {
   TableRef t = table_ref(l);
   if (rows <= 16 * TLN_SCAN_BLOCK) {
     hipLaunchKernelGGL(k_number_small, dim3(1), dim3(TLN_SCAN_BLOCK), 0, s, t, l->row_slot, rows, l->d_ctr,
-                       (int)l->capacity, l->vkeys);
+                       (int)l->capacity, l->vkeys, l->vslot);
     TLN_LAUNCH_CHECK();
     return TLN_OK;
   }
   hipLaunchKernelGGL(k_count_new, dim3(nblocks), dim3(TLN_SCAN_BLOCK), 0, s, t, l->row_slot, rows, l->block_cnt);
   hipLaunchKernelGGL(k_assign_new, dim3(nblocks), dim3(TLN_SCAN_BLOCK), 0, s, t, l->row_slot, rows, l->block_cnt,
-                     l->d_ctr, (int)l->nr_vertices, (int)l->capacity, l->vkeys);
+                     l->d_ctr, (int)l->nr_vertices, (int)l->capacity, l->vkeys, l->vslot);
   TLN_LAUNCH_CHECK();
   return TLN_OK;
 }
@@ -770,7 +878,7 @@ static int number_new(tln_lattice* l, int64_t rows, hipStream_t s) {
 static int fetch_counters(tln_lattice* l, hipStream_t s) {
   TLN_HIP(hipMemcpyAsync(l->h_ctr, l->d_ctr, CTR_COUNT * sizeof(int32_t), hipMemcpyDeviceToHost, s));
   TLN_HIP(hipStreamSynchronize(s));
-  l->nr_vertices = l->h_ctr[CTR_NV];
+  set_vertices(l, l->h_ctr[CTR_NV]);
   l->occupied = l->h_ctr[CTR_OCCUPIED];
   if (l->h_ctr[CTR_PROBE_FAIL] != 0) {
     tln_set_error("hash probing failed for %d rows (table too full)", l->h_ctr[CTR_PROBE_FAIL]);
@@ -1213,35 +1321,169 @@ __global__ void __launch_bounds__(256) k_subtract_rows(const float* __restrict__
   d[2] = pos[3 * p + 2] - mean[3 * v + 2];
 }
 
-// first half: hash insertion, numbering, row indices; the vertex counters start their way to the host
+// ---------------------------------------------------------------------------------------
+// K1 phase D (distribute path): vertex bins instead of a sort.
+//   k_bins_alloc    one thread per vertex: its row count of this frame (from the slot counts of phase A) and a
+//                   contiguous segment of the bin arrays (wave prefix sum + ONE atomic per wave on the cursor)
+//   k_bins_scatter  one thread per row: vertex index (the `indices` output), the row's payload to
+//                   segment start + rank, fixed-point position sums per vertex (int64 atomics: exact, hence
+//                   order-independent), reset of the slot count by the row of rank 0
+//   k_bins_mean     one thread per vertex: mean = sum / count
+// Rows without a vertex (key out of range, rejected by the capacity) go to the tail behind all segments.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_bins_alloc(int32_t* __restrict__ ctr, const int32_t* __restrict__ vslot,
+                                                    const uint32_t* __restrict__ slot_cnt, int32_t* __restrict__ vcnt,
+                                                    int32_t* __restrict__ vstart, long long* __restrict__ vsum) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nv = ctr[CTR_NV];
+  const int lane = threadIdx.x & 63;
+  if (__ballot(v < nv) == 0ull) return;
+  const int c = v < nv ? (int)slot_cnt[vslot[v]] : 0;
+  int incl = c;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int u = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += u;
+  }
+  const int total = __shfl(incl, 63, 64);
+  int base = 0;
+  if (lane == 0 && total > 0) base = atomicAdd(&ctr[CTR_CURSOR], total);
+  base = __shfl(base, 0, 64);
+  if (v < nv) {
+    vcnt[v] = c;
+    vstart[v] = base + incl - c;
+    vsum[3 * v] = 0;
+    vsum[3 * v + 1] = 0;
+    vsum[3 * v + 2] = 0;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_bins_scatter(TableRef t, const int32_t* __restrict__ row_slot,
+                                                      const int32_t* __restrict__ row_rank, int64_t rows,
+                                                      const float* __restrict__ pos, const float* __restrict__ val,
+                                                      int val_dim, const float* __restrict__ weights, int subtract,
+                                                      uint32_t* __restrict__ slot_cnt, const int32_t* __restrict__ vstart,
+                                                      long long* __restrict__ vsum, int32_t* __restrict__ indices,
+                                                      float4* __restrict__ bin_xyzv, float* __restrict__ bin_w,
+                                                      int32_t* __restrict__ bin_row, int32_t* __restrict__ bin_vtx) {
+  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= rows) return;
+  const int slot = row_slot[row];
+  const int rank = row_rank[row];
+  int v = -1;
+  if (slot >= 0) {
+    v = t.slot_val[slot];
+    if (rank == 0) slot_cnt[slot] = 0;   // exactly one row per touched slot: the counts are zero again for the next frame
+  }
+  indices[row] = v;
+  const int64_t p = row >> 2;
+  const float x = pos[3 * p], y = pos[3 * p + 1], z = pos[3 * p + 2];
+  int dest;
+  if (v >= 0) {
+    dest = vstart[v] + rank;
+    if (subtract) {
+      atomicAdd(reinterpret_cast<unsigned long long*>(&vsum[3 * v]), (unsigned long long)tln_fix20(x));
+      atomicAdd(reinterpret_cast<unsigned long long*>(&vsum[3 * v + 1]), (unsigned long long)tln_fix20(y));
+      atomicAdd(reinterpret_cast<unsigned long long*>(&vsum[3 * v + 2]), (unsigned long long)tln_fix20(z));
+    }
+  } else {
+    atomicAdd(&t.ctr[CTR_OVERFLOW], 1);
+    // behind all segments: CTR_CURSOR is final here (k_bins_alloc has completed)
+    dest = t.ctr[CTR_CURSOR] + atomicAdd(&t.ctr[CTR_TAIL], 1);
+  }
+  bin_xyzv[dest] = make_float4(x, y, z, val_dim == 1 ? val[p] : 0.f);
+  bin_w[dest] = weights[row];
+  bin_row[dest] = (int32_t)row;
+  bin_vtx[dest] = v;
+}
+
+__global__ void __launch_bounds__(256) k_bins_mean(const int32_t* __restrict__ ctr, const int32_t* __restrict__ vcnt,
+                                                   const long long* __restrict__ vsum, float* __restrict__ mean) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= ctr[CTR_NV]) return;
+  const int c = vcnt[v];
+  const double cnt = (double)(c > 0 ? c : 1);
+  mean[3 * v] = tln_unfix20(vsum[3 * v], cnt);
+  mean[3 * v + 1] = tln_unfix20(vsum[3 * v + 1], cnt);
+  mean[3 * v + 2] = tln_unfix20(vsum[3 * v + 2], cnt);
+}
+
+// accessors for pool.hip: the bins of the last distribute, if they describe (d_distributed, rows)
+bool tln_lat_bins(const tln_lattice* l, const float* d_distributed, int64_t rows, TlnBins* out) {
+  if (!l || l->bins_rows != rows || rows <= 0 || l->bins_dist != d_distributed || l->dist_val_dim != 1) return false;
+  out->xyzv = l->bin_xyzv;
+  out->w = l->bin_w;
+  out->row = l->bin_row;
+  out->vtx = l->bin_vtx;
+  out->vstart = l->vstart;
+  out->vcnt = l->vcnt;
+  out->mean = l->mean;
+  out->ctr = l->d_ctr;
+  out->weights = l->bins_weights;
+  out->subtract = l->bins_subtract;
+  return true;
+}
+
+extern "C" int tln_lattice_drop_bins(tln_lattice_t* l) {
+  TLN_REQUIRE(l, "null lattice");
+  l->bins_rows = -1;
+  return TLN_OK;
+}
+
+static void publish_counts(tln_lattice* l) {
+  set_vertices(l, l->h_ctr[CTR_NV]);
+  l->occupied = l->h_ctr[CTR_OCCUPIED];
+}
+
+// first half: hash insertion + per-slot row counts, numbering; the vertex counters start their way to the host; then
+// (already behind that fetch) the bins.  d_distributed may be NULL: the [4N, 3+val_dim+1] rows are then not produced
+// (the pool of the same frame reads the bins).
 extern "C" int tln_distribute_begin(tln_lattice_t* l, const float* d_positions, const float* d_values, int64_t n,
                                     int val_dim, int subtract_mean, float* d_distributed, int32_t* d_indices,
                                     float* d_weights, void* stream_) {
-  TLN_REQUIRE(l && d_positions && d_distributed && d_indices && d_weights, "null argument");
+  TLN_REQUIRE(l && d_positions && d_indices && d_weights, "null argument");
+  TLN_REQUIRE(l->level == 0, "distribute works on the finest level");
   TLN_REQUIRE(n > 0 && 4 * n < (1ll << 31), "nr of points %lld out of range", (long long)n);
   TLN_REQUIRE(val_dim >= 0 && val_dim <= 1024 && (val_dim == 0 || d_values), "bad val_dim %d", val_dim);
   hipStream_t s = (hipStream_t)stream_;
-  if (l->dist_pending) {  // an abandoned first half (its caller failed in between): let its counter fetch land
+  if (l->dist_pending) {
+    // an abandoned first half (its caller failed in between): its kernels have numbered vertices on the device, so the
+    // host's counts must follow before anything else is inserted
     TLN_HIP(hipEventSynchronize(l->ctr_event));
     l->dist_pending = false;
+    publish_counts(l);
+    l->bins_rows = -1;
+    TLN_REQUIRE(l->h_ctr[CTR_PROBE_FAIL] == 0, "hash probing failed for %d rows (table too full)", l->h_ctr[CTR_PROBE_FAIL]);
   }
   const int64_t rows = 4 * n;
   int rc = ensure_rows(l, rows);
   if (rc) return rc;
   rc = ensure_slots(l, rows, s);
   if (rc) return rc;
+  l->bins_rows = -1;
+  l->csr_rows = -1;
   TableRef t = table_ref(l);
   hipLaunchKernelGGL(k_distribute_insert, dim3((unsigned)tln_cdiv(4 * n, 256)), dim3(256), 0, s, d_positions, d_values, n,
-                     val_dim, l->scale[0], l->scale[1], l->scale[2], t, l->row_slot, d_weights, d_distributed);
+                     val_dim, l->scale[0], l->scale[1], l->scale[2], t, l->row_slot, d_weights, d_distributed,
+                     l->slot_cnt, l->row_rank);
   TLN_LAUNCH_CHECK();
   rc = number_new(l, rows, s);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_row_indices, dim3((unsigned)tln_cdiv(rows, 256)), dim3(256), 0, s, t, l->row_slot, rows,
-                     d_indices, l->d_ctr, l->sk_in, l->sv_in, sort_totals(l));
-  TLN_LAUNCH_CHECK();
   TLN_HIP(hipMemcpyAsync(l->h_ctr, l->d_ctr, CTR_COUNT * sizeof(int32_t), hipMemcpyDeviceToHost, s));
   if (!l->ctr_event) TLN_HIP(hipEventCreateWithFlags(&l->ctr_event, hipEventDisableTiming));
   TLN_HIP(hipEventRecord(l->ctr_event, s));
+  // the bins: the host only knows an upper bound of the vertex count here, the kernels read the exact one
+  int64_t vbound = l->nr_vertices + rows;
+  if (vbound > l->capacity) vbound = l->capacity;
+  hipLaunchKernelGGL(k_bins_alloc, dim3((unsigned)tln_cdiv(vbound, 256)), dim3(256), 0, s, l->d_ctr, l->vslot,
+                     l->slot_cnt, l->vcnt, l->vstart, l->vsum);
+  hipLaunchKernelGGL(k_bins_scatter, dim3((unsigned)tln_cdiv(rows, 256)), dim3(256), 0, s, t, l->row_slot, l->row_rank, rows,
+                     d_positions, d_values, val_dim, d_weights, subtract_mean, l->slot_cnt, l->vstart, l->vsum, d_indices,
+                     l->bin_xyzv, l->bin_w, l->bin_row, l->bin_vtx);
+  if (subtract_mean)
+    hipLaunchKernelGGL(k_bins_mean, dim3((unsigned)tln_cdiv(vbound, 256)), dim3(256), 0, s, l->d_ctr, l->vcnt, l->vsum,
+                       l->mean);
+  TLN_LAUNCH_CHECK();
   l->dist_pending = true;
   l->dist_pos = d_positions;
   l->dist_out = d_distributed;
@@ -1249,31 +1491,28 @@ extern "C" int tln_distribute_begin(tln_lattice_t* l, const float* d_positions, 
   l->dist_rows = rows;
   l->dist_val_dim = val_dim;
   l->dist_subtract = subtract_mean;
+  l->bins_weights = d_weights;
   return TLN_OK;
 }
 
-// second half: waits for the counters only (not for work enqueued after tln_distribute_begin), then the CSR and means
+// second half: waits for the counters only (not for work enqueued after them); the mean subtraction of the [4N, .]
+// rows when the caller asked for them
 extern "C" int tln_distribute_finish(tln_lattice_t* l, void* stream_) {
   TLN_REQUIRE(l && l->dist_pending, "tln_distribute_finish without tln_distribute_begin");
   hipStream_t s = (hipStream_t)stream_;
   l->dist_pending = false;
   TLN_HIP(hipEventSynchronize(l->ctr_event));
-  l->nr_vertices = l->h_ctr[CTR_NV];
-  l->occupied = l->h_ctr[CTR_OCCUPIED];
+  publish_counts(l);
   if (l->h_ctr[CTR_PROBE_FAIL] != 0) {
     tln_set_error("hash probing failed for %d rows (table too full)", l->h_ctr[CTR_PROBE_FAIL]);
     return TLN_E_CAPACITY;
   }
-  l->overflow_rows = l->h_ctr[CTR_OVERFLOW];
+  l->overflow_stale = true;   // counted by k_bins_scatter, after the fetch: read on demand (tln_lattice_overflow_rows)
   const int64_t rows = l->dist_rows;
-  int rc = build_csr_sorted(l, rows, s);
-  if (rc) return rc;
-  if (l->dist_subtract && l->nr_vertices > 0) {
-    const int64_t nv = l->nr_vertices;
-    hipLaunchKernelGGL(k_mean_pieces, dim3((unsigned)tln_cdiv(rows, MEAN_BLOCK)), dim3(MEAN_BLOCK), 0, s, l->dist_pos,
-                       l->sv_out, l->sk_out, l->seg_start, (int)nv, l->mean, l->pieces);
-    hipLaunchKernelGGL(k_mean_combine, dim3((unsigned)tln_cdiv(nv, 256)), dim3(256), 0, s, l->seg_start, (int)nv,
-                       l->pieces, l->mean);
+  l->bins_rows = rows;
+  l->bins_dist = l->dist_out;
+  l->bins_subtract = l->dist_subtract;
+  if (l->dist_out && l->dist_subtract && l->nr_vertices > 0) {
     hipLaunchKernelGGL(k_subtract_rows, dim3((unsigned)tln_cdiv(rows, 256)), dim3(256), 0, s, l->dist_pos, l->dist_idx,
                        l->mean, rows, 3 + l->dist_val_dim + 1, l->dist_out);
     TLN_LAUNCH_CHECK();
@@ -1408,12 +1647,12 @@ extern "C" int tln_neighbour_table(tln_lattice_t* l, const int32_t** d_table_out
   TLN_REQUIRE(l && d_table_out, "null argument");
   int rc = ensure_table(&l->nbr, l->capacity);
   if (rc) return rc;
-  if (l->nbr_built_for != l->nr_vertices && l->nr_vertices > 0) {
+  if (l->nbr_gen != l->gen && l->nr_vertices > 0) {
     const int64_t total = l->nr_vertices * TLN_TAPS;
     hipLaunchKernelGGL(k_neighbour_table, dim3((unsigned)tln_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream_,
                        l->vkeys, l->nr_vertices, table_ref(l), 0, l->nbr);
     TLN_LAUNCH_CHECK();
-    l->nbr_built_for = l->nr_vertices;
+    l->nbr_gen = l->gen;
   }
   *d_table_out = l->nbr;
   return TLN_OK;
@@ -1505,13 +1744,13 @@ extern "C" int tln_coarse_to_fine_table(tln_lattice_t* c, const int32_t** d_tabl
   tln_lattice* f = c->parent;
   int rc = ensure_table(&c->c2f, c->capacity);
   if (rc) return rc;
-  if ((c->c2f_vc != c->nr_vertices || c->c2f_vf != f->nr_vertices) && c->nr_vertices > 0) {
+  if ((c->c2f_gen_c != c->gen || c->c2f_gen_f != f->gen) && c->nr_vertices > 0) {
     const int64_t total = c->nr_vertices * TLN_TAPS;
     hipLaunchKernelGGL(k_neighbour_table, dim3((unsigned)tln_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream_,
                        c->vkeys, c->nr_vertices, table_ref(f), 1, c->c2f);
     TLN_LAUNCH_CHECK();
-    c->c2f_vc = c->nr_vertices;
-    c->c2f_vf = f->nr_vertices;
+    c->c2f_gen_c = c->gen;
+    c->c2f_gen_f = f->gen;
   }
   *d_table_out = c->c2f;
   return TLN_OK;
@@ -1526,13 +1765,13 @@ extern "C" int tln_fine_to_coarse_table(tln_lattice_t* c, const int32_t** d_tabl
   tln_lattice* f = c->parent;
   int rc = ensure_table(&c->f2c, f->capacity);
   if (rc) return rc;
-  if ((c->f2c_vc != c->nr_vertices || c->f2c_vf != f->nr_vertices) && f->nr_vertices > 0) {
+  if ((c->f2c_gen_c != c->gen || c->f2c_gen_f != f->gen) && f->nr_vertices > 0) {
     const int64_t total = f->nr_vertices * TLN_TAPS;
     hipLaunchKernelGGL(k_neighbour_table, dim3((unsigned)tln_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream_,
                        f->vkeys, f->nr_vertices, table_ref(c), 2, c->f2c);
     TLN_LAUNCH_CHECK();
-    c->f2c_vc = c->nr_vertices;
-    c->f2c_vf = f->nr_vertices;
+    c->f2c_gen_c = c->gen;
+    c->f2c_gen_f = f->gen;
   }
   *d_table_out = c->f2c;
   return TLN_OK;
@@ -1594,7 +1833,7 @@ extern "C" int tln_lattice_prepare_levels_finish(tln_lattice_t* l0, void* stream
     TLN_HIP(hipEventSynchronize(l0->levels_event));
     int lvl = 0;
     for (tln_lattice* c = l0->coarse; c && lvl < nr_coarse_levels; c = c->coarse, ++lvl) {
-      c->nr_vertices = c->h_ctr[CTR_NV];
+      set_vertices(c, c->h_ctr[CTR_NV]);
       c->occupied = c->h_ctr[CTR_OCCUPIED];
       c->embedded_fine = c->parent->nr_vertices;
       if (c->h_ctr[CTR_PROBE_FAIL] != 0) {
@@ -1619,9 +1858,9 @@ extern "C" int tln_lattice_prepare_levels_finish(tln_lattice_t* l0, void* stream
     if (p->nr_vertices <= 0) continue;
     int rc = ensure_table(&p->nbr, p->capacity);
     if (rc) return rc;
-    if (p->nbr_built_for != p->nr_vertices) {
+    if (p->nbr_gen != p->gen) {
       add(p->vkeys, p->nr_vertices, p, 0, p->nbr);
-      p->nbr_built_for = p->nr_vertices;
+      p->nbr_gen = p->gen;
     }
     if (p->parent && p->parent->nr_vertices > 0) {
       tln_lattice* f = p->parent;
@@ -1629,15 +1868,15 @@ extern "C" int tln_lattice_prepare_levels_finish(tln_lattice_t* l0, void* stream
       if (rc) return rc;
       rc = ensure_table(&p->f2c, f->capacity);
       if (rc) return rc;
-      if (p->c2f_vc != p->nr_vertices || p->c2f_vf != f->nr_vertices) {
+      if (p->c2f_gen_c != p->gen || p->c2f_gen_f != f->gen) {
         add(p->vkeys, p->nr_vertices, f, 1, p->c2f);
-        p->c2f_vc = p->nr_vertices;
-        p->c2f_vf = f->nr_vertices;
+        p->c2f_gen_c = p->gen;
+        p->c2f_gen_f = f->gen;
       }
-      if (p->f2c_vc != p->nr_vertices || p->f2c_vf != f->nr_vertices) {
+      if (p->f2c_gen_c != p->gen || p->f2c_gen_f != f->gen) {
         add(f->vkeys, f->nr_vertices, p, 2, p->f2c);
-        p->f2c_vc = p->nr_vertices;
-        p->f2c_vf = f->nr_vertices;
+        p->f2c_gen_c = p->gen;
+        p->f2c_gen_f = f->gen;
       }
     }
     if (jobs.n >= 7) break;

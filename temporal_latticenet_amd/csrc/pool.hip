@@ -151,7 +151,7 @@ __global__ void __launch_bounds__(256) k_pool_chunks(const float* __restrict__ d
   }
 }
 
-__global__ void __launch_bounds__(256) k_pool_finalize(const unsigned long long* __restrict__ packed,
+__global__ void __launch_bounds__(256) k_pool_finalize(const unsigned long long* packed,
                                                        const int32_t* __restrict__ seg_start, int nv, int cout,
                                                        const float* __restrict__ dist, int cols, int64_t rows,
                                                        int min_points, float* __restrict__ out,
@@ -163,6 +163,7 @@ __global__ void __launch_bounds__(256) k_pool_finalize(const unsigned long long*
   int count = seg_start[v + 1] - seg_start[v];
   if (v == 0) count += seg_start[nv + 1] - seg_start[nv];  // folded rows (index -1)
   const unsigned long long p = packed[gid];
+  if (p != 0ull) const_cast<unsigned long long*>(packed)[gid] = 0ull;   // the accumulators are zero between calls
   float val = 0.0f;          // torch_scatter: empty segment -> 0
   int64_t arg = rows;        // torch_scatter: empty segment -> src.size(0)
   if (p != 0ull) {
@@ -180,6 +181,208 @@ __global__ void __launch_bounds__(256) k_pool_finalize(const unsigned long long*
   }
   out[v * (2 * cout) + c] = val;
   out[v * (2 * cout) + cout + c] = bary;
+}
+
+// ---------------------------------------------------------------------------------------
+// The same pool on the VERTEX BINS of the distribute of this frame (lattice.hip, k_bins_*): the rows of a vertex are
+// contiguous in the bin arrays, so a wave streams 64 x (16 + 4 + 4 + 4) contiguous bytes instead of gathering 20-byte
+// rows through a sorted index list, and subtracts the vertex's local mean on the way (the [4N,5] `distributed`
+// tensor is never read).  A vertex whose rows all lie inside the wave's 64-row chunk — three quarters of them — is
+// FINISHED here: its output row (max, barycentric weight of the arg-max row with the lm:514 clamp, < min_points
+// mask) is written directly; only vertices whose segment crosses a chunk boundary (and vertex 0, which also takes the
+// rows without a vertex, lm:480) go through the packed 64-bit atomicMax and k_pool_bins_finalize.
+// The rows of a segment arrive in arbitrary order: ties go to the smallest row id explicitly.
+// ---------------------------------------------------------------------------------------
+template <int CIN, int H1, int H2, int COUT>
+__global__ void __launch_bounds__(256) k_pool_bins(const TlnBins bn, int64_t rows, int min_points,
+                                                   const float* __restrict__ w1, const float* __restrict__ b1,
+                                                   const float* __restrict__ w2, const float* __restrict__ b2,
+                                                   const float* __restrict__ w3, const float* __restrict__ b3,
+                                                   unsigned long long* __restrict__ packed, float* __restrict__ out,
+                                                   int32_t* __restrict__ argrow) {
+  constexpr int HL = (H1 == 0) ? CIN : (H2 ? H2 : H1);
+  constexpr int TS = ((HL + 3) / 4) * 4 + 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float* tile = smem + wid * (64 * TS + 256);
+  int* tv = reinterpret_cast<int*>(tile + 64 * TS);
+  int* tr = tv + 64;
+  float* tw = reinterpret_cast<float*>(tr + 64);
+  int* tf = reinterpret_cast<int*>(tw + 64);
+
+  const int64_t chunk = (int64_t)blockIdx.x * 4 + wid;
+  const int64_t j0 = chunk * 64;
+  if (j0 >= rows) return;  // no block barrier below: the tile is private to the wave
+  const int cnt = (int)((rows - j0) < 64 ? (rows - j0) : 64);
+  const int nv = bn.ctr[0];
+  const float w0 = bn.weights[0];   // lm:514: an arg-max row id > V reads the barycentric weight of row 0
+
+  // ---- phase 1: lane = row
+  if (lane < cnt) {
+    const int64_t at = j0 + lane;
+    float4 q = bn.xyzv[at];
+    const int v = bn.vtx[at];
+    int flags = 0, vv = 0;      // rows without a vertex fold into vertex 0 with their raw position (lm:480)
+    if (v >= 0) {
+      vv = v;
+      if (bn.subtract) {
+        q.x -= bn.mean[3 * v];
+        q.y -= bn.mean[3 * v + 1];
+        q.z -= bn.mean[3 * v + 2];
+      }
+      if (v != 0) {
+        const int st = bn.vstart[v], c = bn.vcnt[v];
+        if ((int64_t)st == at) flags |= 1;            // first row of its vertex
+        if ((int64_t)st + c == at + 1) flags |= 2;    // last row of its vertex
+        if (c < min_points) flags |= 4;
+      }
+    }
+    const float xin[4] = {q.x, q.y, q.z, q.w};
+    float x[CIN];
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) x[c] = xin[c];
+    float hl[HL];
+    if constexpr (H1 == 0) {
+#pragma unroll
+      for (int c = 0; c < HL; ++c) hl[c] = x[c];
+    } else if constexpr (H2 == 0) {
+      dense<CIN, H1, true>(w1, b1, x, hl);
+    } else {
+      float h1[H1];
+      dense<CIN, H1, true>(w1, b1, x, h1);
+      dense<H1, H2, true>(w2, b2, h1, hl);
+    }
+#pragma unroll
+    for (int c = 0; c < HL; ++c) tile[lane * TS + c] = hl[c];
+    tv[lane] = vv;
+    tr[lane] = bn.row[at];
+    tw[lane] = bn.w[at];
+    tf[lane] = flags;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the wave's own LDS writes have landed
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  // ---- phase 2: lane = output channel of the last layer
+  const int c = lane;
+  const bool active = c < COUT;
+  float wl[HL];
+  float bias = 0.0f;
+  if constexpr (H1 != 0) {
+    const float* wlast = H2 ? w3 : w2;
+    const float* blast = H2 ? b3 : b2;
+#pragma unroll
+    for (int i = 0; i < HL; ++i) wl[i] = active ? wlast[c * HL + i] : 0.0f;
+    bias = active ? blast[c] : 0.0f;
+  }
+  auto value_of = [&](int j) {
+    const float* h = tile + j * TS;
+    if constexpr (H1 == 0) {
+      return h[active ? c : 0];
+    } else {
+      float acc = bias;   // ONE fma chain in ascending i (oracle/csrc/pool_mlp.c)
+#pragma unroll
+      for (int i = 0; i < HL; i += 4) {
+        const float4 q = *reinterpret_cast<const float4*>(h + i);   // one address for the whole wave: broadcast
+        acc = fmaf(wl[i], q.x, acc);
+        acc = fmaf(wl[i + 1], q.y, acc);
+        acc = fmaf(wl[i + 2], q.z, acc);
+        acc = fmaf(wl[i + 3], q.w, acc);
+      }
+      return acc;
+    }
+  };
+  // a vertex's rows [js, je] of this chunk are done: its result goes straight to the output when they are ALL its rows
+  auto flush = [&](int v, int js, int je, float best, int bj) {
+    const bool whole = (tf[js] & 1) && (tf[je] & 2);   // wave-uniform
+    if (!active) return;
+    const int arg = tr[bj];
+    if (whole) {
+      const bool masked = (tf[js] & 4) != 0;
+      const float bary = arg > nv ? w0 : tw[bj];
+      out[(int64_t)v * (2 * COUT) + c] = masked ? 0.0f : best;
+      out[(int64_t)v * (2 * COUT) + COUT + c] = masked ? 0.0f : bary;
+      if (argrow) argrow[(int64_t)v * COUT + c] = masked ? -1 : arg;
+    } else {
+      const unsigned long long p = ((unsigned long long)tln_f2ord(best) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)arg);
+      atomicMax(&packed[(int64_t)v * COUT + c], p);
+    }
+  };
+  int cur = tv[0], js = 0, bj = 0;
+  float best = value_of(0);
+  for (int j = 1; j < cnt; ++j) {
+    const int v = tv[j];
+    const float val = value_of(j);
+    if (v != cur) {  // wave-uniform
+      flush(cur, js, j - 1, best, bj);
+      cur = v;
+      js = j;
+      best = val;
+      bj = j;
+    } else if (val > best || (val == best && tr[j] < tr[bj])) {   // ties: the smallest row id
+      best = val;
+      bj = j;
+    }
+  }
+  flush(cur, js, cnt - 1, best, bj);
+}
+
+// what k_pool_bins left open: vertices without rows (zeros, torch_scatter's empty segment), vertices whose segment
+// crosses a 64-row chunk boundary and vertex 0 (packed accumulators -> value, barycentric weight, mask)
+__global__ void __launch_bounds__(256) k_pool_bins_finalize(unsigned long long* packed, const TlnBins bn, int nv, int cout,
+                                                            int64_t rows, int min_points, float* __restrict__ out,
+                                                            int32_t* __restrict__ argrow) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t v = gid / cout;
+  const int c = (int)(gid - v * cout);
+  if (v >= nv) return;
+  const int st = bn.vstart[v];
+  int count = bn.vcnt[v];
+  const bool crossing = v == 0 || (count > 0 && (st >> 6) != ((st + count - 1) >> 6));
+  if (v == 0) count += (int)(rows - bn.ctr[6]);   // the rows without a vertex fold into vertex 0
+  if (count > 0 && !crossing) return;              // written by k_pool_bins
+  float val = 0.0f, bary = 0.0f;
+  int32_t argout = -1;
+  if (count > 0) {
+    const unsigned long long p = packed[gid];
+    packed[gid] = 0ull;                            // zero between calls
+    int64_t arg = rows;
+    if (p != 0ull) {
+      val = tln_ord2f((uint32_t)(p >> 32));
+      arg = (int64_t)(0xFFFFFFFFu - (uint32_t)(p & 0xFFFFFFFFull));
+    }
+    if (p != 0ull && count >= min_points) argout = (int32_t)arg;
+    if (arg > (int64_t)nv) arg = 0;   // lm:514
+    if (arg >= rows) arg = 0;
+    bary = bn.weights[arg];
+    if (count < min_points) {
+      val = 0.0f;
+      bary = 0.0f;
+    }
+  }
+  if (argrow) argrow[gid] = argout;
+  out[v * (2 * cout) + c] = val;
+  out[v * (2 * cout) + cout + c] = bary;
+}
+
+template <int CIN, int H1, int H2, int COUT>
+static int launch_pool_bins(const TlnBins& bn, int64_t rows, const float* const* w, const float* const* b, int min_points,
+                            unsigned long long* packed, float* d_out, int32_t* d_argrow, hipStream_t s) {
+  constexpr int HL = (H1 == 0) ? CIN : (H2 ? H2 : H1);
+  constexpr int TS = ((HL + 3) / 4) * 4 + 4;
+  const size_t lds = (size_t)(4 * (64 * TS + 256)) * sizeof(float);
+  MlpParams mp{};
+  for (int i = 0; i < 3; ++i) {
+    mp.w[i] = (H1 && w) ? w[i < (H2 ? 3 : 2) ? i : 0] : nullptr;
+    mp.b[i] = (H1 && b) ? b[i < (H2 ? 3 : 2) ? i : 0] : nullptr;
+  }
+  const int64_t chunks = tln_cdiv(rows, 64);
+  auto kern = k_pool_bins<CIN, H1, H2, COUT>;
+  TLN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3((unsigned)tln_cdiv(chunks, 4)), dim3(256), lds, s, bn, rows, min_points, mp.w[0], mp.b[0],
+                     mp.w[1], mp.b[1], mp.w[2], mp.b[2], packed, d_out, d_argrow);
+  TLN_LAUNCH_CHECK();
+  return TLN_OK;
 }
 
 template <int CIN, int H1, int H2, int COUT>
@@ -205,9 +408,7 @@ static int launch_pool(tln_lattice* l, const float* d_dist, int64_t rows, int co
 extern "C" int tln_pointnet_pool_ex(tln_lattice_t* l, const float* d_distributed, int64_t rows, int dist_cols,
                                     int nr_layers, const float* const* d_w, const float* const* d_b, const int* dims,
                                     int min_points, float* d_out, int32_t* d_argrow, void* stream_) {
-  TLN_REQUIRE(l && d_distributed && d_out && dims, "null argument");
-  TLN_REQUIRE(tln_lat_csr_rows(l) == rows, "pool needs the CSR of a distribute/build_csr call over the same %lld rows",
-              (long long)rows);
+  TLN_REQUIRE(l && d_out && dims, "null argument");
   hipStream_t s = (hipStream_t)stream_;
   const int nv = (int)tln_lattice_nr_vertices(l);
   if (nv <= 0) return TLN_OK;
@@ -216,7 +417,30 @@ extern "C" int tln_pointnet_pool_ex(tln_lattice_t* l, const float* d_distributed
   unsigned long long* packed = nullptr;
   int rc = tln_lat_pool_ws(l, (int64_t)nv * cout, &packed);
   if (rc) return rc;
-  TLN_HIP(hipMemsetAsync(packed, 0, (size_t)nv * cout * sizeof(unsigned long long), s));
+  // the rows of this very frame's distribute: pool them from the vertex bins (no sorted row list, no [4N,5] reads)
+  TlnBins bn;
+  if (cin <= 4 && dist_cols == 5 && tln_lat_bins(l, d_distributed, rows, &bn)) {
+#define POOLB_CASE(CI, A, B, CO) rc = launch_pool_bins<CI, A, B, CO>(bn, rows, d_w, d_b, min_points, packed, d_out, d_argrow, s)
+    bool taken = true;
+    if (nr_layers == 3 && cin == 4 && dims[1] == 16 && dims[2] == 32 && dims[3] == 64) POOLB_CASE(4, 16, 32, 64);
+    else if (nr_layers == 2 && cin == 4 && dims[1] == 16 && dims[2] == 32) POOLB_CASE(4, 16, 0, 32);
+    else if (nr_layers == 3 && cin == 3 && dims[1] == 16 && dims[2] == 32 && dims[3] == 64) POOLB_CASE(3, 16, 32, 64);
+    else if (nr_layers == 0 && cin == 4) POOLB_CASE(4, 0, 0, 4);
+    else if (nr_layers == 0 && cin == 3) POOLB_CASE(3, 0, 0, 3);
+    else taken = false;
+#undef POOLB_CASE
+    if (taken) {
+      if (rc) return rc;
+      const int64_t total = (int64_t)nv * cout;
+      hipLaunchKernelGGL(k_pool_bins_finalize, dim3((unsigned)tln_cdiv(total, 256)), dim3(256), 0, s, packed, bn, nv, cout,
+                         rows, min_points, d_out, d_argrow);
+      TLN_LAUNCH_CHECK();
+      return TLN_OK;
+    }
+  }
+  TLN_REQUIRE(d_distributed, "the pool needs the distributed rows (or the bins of this frame's distribute)");
+  TLN_REQUIRE(tln_lat_csr_rows(l) == rows, "pool needs the CSR of a tln_build_csr call over the same %lld rows",
+              (long long)rows);
 #define POOL_CASE(CI, A, B, CO) rc = launch_pool<CI, A, B, CO>(l, d_distributed, rows, dist_cols, d_w, d_b, nv, packed, s)
   if (nr_layers == 3 && cin == 4 && dims[1] == 16 && dims[2] == 32 && dims[3] == 64) POOL_CASE(4, 16, 32, 64);
   else if (nr_layers == 2 && cin == 4 && dims[1] == 16 && dims[2] == 32) POOL_CASE(4, 16, 0, 32);

@@ -636,11 +636,15 @@ extern "C" int tln_program_begin_frame_start(tln_program_t* p, tln_lattice_t* l,
   TLN_REQUIRE(p && l && d_positions && n > 0 && val_dim >= 0, "bad frame arguments");
   hipStream_t s = (hipStream_t)stream_;
   const int cols = 3 + val_dim + 1;
-  const size_t dist_b = align_up((size_t)4 * n * cols * sizeof(float)), idx_b = align_up((size_t)4 * n * sizeof(int32_t));
+  // the [4N, 5] `distributed` rows are not materialised when the pool can take the frame's rows from the lattice's
+  // vertex bins (one value channel: every supported PointNet shape); the pool then gets d_distributed = NULL
+  const bool want_dist = val_dim != 1;
+  const size_t dist_b = want_dist ? align_up((size_t)4 * n * cols * sizeof(float)) : 0;
+  const size_t idx_b = align_up((size_t)4 * n * sizeof(int32_t));
   int rc = ensure_buf(p->k1, dist_b + 2 * idx_b, s);
   if (rc) return rc;
   char* b = reinterpret_cast<char*>(p->k1.p);
-  p->d_dist = reinterpret_cast<float*>(b);
+  p->d_dist = want_dist ? reinterpret_cast<float*>(b) : nullptr;
   p->d_idx = reinterpret_cast<int32_t*>(b + dist_b);
   p->d_w = reinterpret_cast<float*>(b + dist_b + idx_b);
   if (reset_hashmap) {
@@ -912,8 +916,8 @@ extern "C" int tln_program_replay_gemms(tln_program_t* p, int reps, double* ms_t
 
 extern "C" int tln_program_frame_rows(tln_program_t* p, const float** d_distributed, const int32_t** d_indices,
                                       const float** d_weights, int64_t* rows, int* cols) {
-  TLN_REQUIRE(p && p->d_dist, "no frame yet");
-  if (d_distributed) *d_distributed = p->d_dist;
+  TLN_REQUIRE(p && p->d_idx, "no frame yet");
+  if (d_distributed) *d_distributed = p->d_dist;   // NULL when the frame's pool read the vertex bins instead
   if (d_indices) *d_indices = p->d_idx;
   if (d_weights) *d_weights = p->d_w;
   if (rows) *rows = 4 * p->N;

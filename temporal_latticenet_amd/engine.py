@@ -402,6 +402,8 @@ class FrameProgram:
                                                1 if reset_hashmap else 0, 1 if self.subtract_mean else 0, self._v, s),
                    "tln_program_begin_frame")
         ls._csr_key = None
+        ls._bins_key = None
+        ls._last_indices = None
         early = bool(early_return) and self.stop_shape is not None
         rows_code, cols = self.stop_shape if early else self.out_shape
         rows = self._rows(rows_code, n)
@@ -425,6 +427,8 @@ class FrameProgram:
                                                             1 if self.subtract_mean else 0, stream_ptr()),
                    "tln_program_begin_frame_start")
         ls._csr_key = None
+        ls._bins_key = None
+        ls._last_indices = None
         return n, (positions, values)                 # the inputs stay alive until the frame has been enqueued
 
     def _finish(self, n, early_return):

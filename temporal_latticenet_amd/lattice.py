@@ -236,13 +236,34 @@ class Lattice:
                                            1 if subtract_mean else 0, _ptr(distributed), _ptr(indices),
                                            _ptr(weights), stream_ptr())
         _lib.check(rc, "tln_distribute")
-        self._csr_key = (indices, indices._version)
+        # the handle now holds the frame's rows grouped by vertex ("bins"): the PointNet pool of these very tensors
+        # reads them instead of a sorted row list; the sorted CSR is only built on demand (ensure_csr)
+        self._csr_key = None
+        self._bins_key = (distributed, distributed._version, indices, indices._version)
+        self._last_indices = indices
         return distributed, indices, weights
+
+    def bins_valid_for(self, distributed):
+        k = getattr(self, "_bins_key", None)
+        return k is not None and k[0].data_ptr() == distributed.data_ptr()
+
+    def drop_bins(self):
+        """the rows were edited after the distribute: the native pool must not take them from the bins"""
+        _lib.check(_lib.lib().tln_lattice_drop_bins(self._h), "tln_lattice_drop_bins")
+        self._bins_key = None
+
+    def bins_describe(self, distributed, indices):
+        """True when `distributed` / `indices` are the untouched outputs of the last distribute on this lattice"""
+        k = getattr(self, "_bins_key", None)
+        return k is not None and k[0] is distributed and k[1] == distributed._version and k[2] is indices and \
+            k[3] == indices._version
 
     def csr(self):
         """(order, sorted_vertex, seg_start) of the native CSR left by the last distribute / ensure_csr: row ids
         sorted stably by vertex, rejected rows in the tail bucket V.  Test / debug read-out."""
         import ctypes
+        if self._csr_key is None and getattr(self, "_last_indices", None) is not None:
+            self.ensure_csr(self._last_indices)        # a distribute leaves bins, not the sorted list: build it now
         rows = ctypes.c_int64(0)
         _lib.check(_lib.lib().tln_lattice_csr(self._h, None, None, None, ctypes.byref(rows), stream_ptr()),
                    "tln_lattice_csr")

@@ -171,8 +171,14 @@ def affine_act(x, scale, shift, relu=False):
 def pointnet_pool(lattice: Lattice, distributed, indices, weights, biases, min_points=4, want_argrow=False):
     """Fused per-row MLP + segment max (+argmax barycentric) of PointNetSeqModule (lm:448-530).
     want_argrow=True also returns [V, cout] int32: the row that produced each pooled value (-1 = empty/masked)."""
+    # rows straight from this lattice's last distribute: the native pool takes them from the vertex bins (it checks the
+    # buffer address); anything else (other tensors, edited rows) goes through a vertex-sorted row list
+    from_bins = lattice.bins_describe(distributed, indices)
     distributed = _f32c(distributed)
-    lattice.ensure_csr(indices)
+    if not from_bins:
+        if lattice.bins_valid_for(distributed):
+            lattice.drop_bins()
+        lattice.ensure_csr(indices)
     rows, cols = distributed.shape
     nl = len(weights)
     ws = [_f32c(w) for w in weights]
