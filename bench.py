@@ -17,8 +17,14 @@ temporal_latticenet_amd/streams.py).  value = clouds of all streams and ranks / 
 Both are "scaling": "weak" (fixed work per GPU).
 
 Prints ONE JSON line (rank 0) with `value` = clouds/sec of the whole job, plus
-  roofline     : the dominant kernel (k_gather_gemm, fp32 MFMA) timed per launch with HIP events on the launch stream
-  cpu_baseline : the CPU oracle (PyTorch eager restatement, kind "port") on a bounded sample, rank 0 / N=1 only.
+  roofline         : the dominant kernel family (gather-GEMM, fp32 MFMA, GRU projections included): every product of a
+                     sequence replayed back to back between two HIP events on the launch stream (`mode`), and the same
+                     flops over the TIMED step (`whole_step`: a lower bound of the MFMA rate in the timed mode itself)
+  roofline_scatter : K1 distribute + K2 PointNet pool + K8 slice: algorithmic bytes over their kernel
+                     time (HIP events on the launch stream around each stage), per stage and summed, against 8 TB/s
+  value_h2d        : the same job with every frame copied from pinned host memory inside the timed region
+                     (train_ln.py:164-166 does that copy per frame)
+  cpu_baseline     : the CPU oracle (PyTorch eager restatement, kind "port") on a bounded sample, rank 0 / N=1 only.
 """
 import argparse
 import contextlib
@@ -36,12 +42,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: dense fp32 matrix peak
+HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--points", type=int, default=120000)
     ap.add_argument("--frames", type=int, default=4)
@@ -51,9 +58,10 @@ def parse():
     ap.add_argument("--streams", type=int, default=4,
                     help="independent sequences in flight per GPU (one HIP stream + host thread + model replica each); "
                          "one step = one sequence on every stream")
-    ap.add_argument("--pairs", type=int, default=8,
-                    help="1: every stream steps two sequences in lock-step with shared gather-GEMM launches (2..8: that "
-                         "many); one step = that many sequences on every stream")
+    ap.add_argument("--pairs", type=int, default=0,
+                    help="0 (default): one sequence per stream and step.  1: every stream steps two sequences in lock-step "
+                         "with shared gather-GEMM launches (2..8: that many) -- pays on lattices of a few thousand "
+                         "vertices only, not on SemanticKITTI-sized ones")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) on the GPU node; gloo for rehearsals")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: all ranks use cuda:0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -183,6 +191,24 @@ def main():
         barrier()
         elapsed = D.max_over_ranks(time.perf_counter() - t0, device=None if via_host else "cuda")
 
+        # ---- the same job with the frames waiting in pinned host memory (the reference's loop copies every frame to
+        # the device, train_ln.py:164-166): a shorter second timed region, sequence mode only
+        value_h2d = None
+        if not frames_mode:
+            host = [[(p.cpu().pin_memory(), v.cpu().pin_memory()) for p, v in sq] for sq in per_stream]
+            n_h = max(2, args.steps // 4)
+
+            def run_h2d(n):
+                pool.run([host[per * i:per * i + per] * n for i in range(S)])
+
+            run_h2d(1)
+            barrier()
+            t0 = time.perf_counter()
+            run_h2d(n_h)
+            barrier()
+            el_h = D.max_over_ranks(time.perf_counter() - t0, device=None if via_host else "cuda")
+            value_h2d = args.gpus * S * per * n_h * args.frames / el_h
+
         # vertex counts of the workload (data dependent; printed with every result)
         model.reset_sequence()
         lat = make_lattice(contents)
@@ -193,48 +219,83 @@ def main():
             vcounts.append([lat.nr_lattice_vertices(), l1.nr_lattice_vertices(), l1.coarsen().nr_lattice_vertices()])
         model.reset_sequence()
 
-        # ---- roofline pass: the dominant kernel (gather-GEMM, fp32 MFMA) over the same workload.  The frame program
-        # remembers the resolved arguments of every gather-GEMM launch of a frame; right after the frame those launches
-        # are replayed back to back between two HIP events on the launch stream (tln_program_replay_gemms), so the
-        # average covers kernel time plus the launch gap and nothing else.
-        roof = None
+        # ---- roofline passes over the same workload, one sequence on one stream (rank 0).
+        # (1) gather-GEMM (fp32 MFMA): the frame program remembers the resolved arguments of every product of a frame
+        #     (the GRU cell's two projections included); right after the frame they are replayed back to back between
+        #     two HIP events on the launch stream (tln_program_replay_gemms): kernel time + launch gap, nothing else.
+        # (2) scatter / gather stages (HBM): HIP events on the launch stream around K1 (all kernels of the distribute),
+        #     K2 (PointNet pool) and K8 (slice kernels) of every frame (tln_program_timing), algorithmic bytes of
+        #     K1 128 N, K2 96 N + 512 V0, K8 768 V0 + 148 N (26 classes, C = 192).
+        roof, scatter = None, None
         if rank == 0:
             reps = 5
             tot_ms, tot_n, tot_fl, tot_by = 0.0, 0, 0.0, 0.0
+            st_ms, st_by, st_n = [0.0, 0.0, 0.0], [0.0, 0.0, 0.0], [0, 0, 0]
             lat = make_lattice(contents)
-            for t, (pos, val) in enumerate(frames):
-                model(lat, pos, val, t != len(frames) - 1, False)
-                prog = getattr(model, "_program", None)
-                if prog is None or not getattr(model, "_program_active", False):
-                    break
+            n_pts = args.points
+            run_sequence(model, lat, frames)            # warm: this lattice's tables and pool workspace exist now
+            prog = getattr(model, "_program", None)
+            if prog is not None:
                 prog.capture_gemms(True)
-                if t == 0:      # capture starts with the NEXT frame: run frame 0 again on a fresh lattice
-                    model.reset_sequence()
-                    lat = make_lattice(contents)
-                    model(lat, pos, val, t != len(frames) - 1, False)
+                prog.stage_timing(True)
+            for t, (pos, val) in enumerate(frames):
+                if prog is None:
+                    break
+                model(lat, pos, val, t != len(frames) - 1, False)
+                if not getattr(model, "_program_active", False):
+                    break
+                v0 = lat.nr_lattice_vertices()
+                for k, (ms, by) in enumerate(zip(prog.stage_times_ms(),
+                                                 (128.0 * n_pts, 96.0 * n_pts + 512.0 * v0, 768.0 * v0 + 148.0 * n_pts))):
+                    if ms is not None:
+                        st_ms[k] += ms
+                        st_by[k] += by
+                        st_n[k] += 1
                 ms, n, fl, by = prog.replay_gemms(reps)
                 tot_ms, tot_n, tot_fl, tot_by = tot_ms + ms, tot_n + n, tot_fl + fl, tot_by + by
             model.reset_sequence()
             if getattr(model, "_program", None) is not None:
                 model._program.capture_gemms(False)
+                model._program.stage_timing(False)
             if tot_n:
                 achieved = tot_fl / (tot_ms * 1e-3) / 1e12
-                roof = {"kernel": "k_gather_gemm", "bound": "mfma", "achieved": round(achieved, 3),
-                        "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-                        "traffic": None, "launches_per_step": tot_n // reps,
-                        "avg_launch_us": round(tot_ms * 1e3 / tot_n, 2),
+                seqs_per_step = (S * per) if not frames_mode else plan.nr_groups / max(1, args.gpus)
+                step_tf = (tot_fl / reps) * seqs_per_step / (elapsed / args.steps) / 1e12
+                roof = {"kernel": "gather-GEMM (k_gather_gemm_v2 on level 0, k_gather_gemm_direct on the coarse levels)",
+                        "bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                        "launches_per_sequence": tot_n // reps, "avg_launch_us": round(tot_ms * 1e3 / tot_n, 2),
                         "flops_per_launch": tot_fl / tot_n, "algorithmic_bytes_per_launch": tot_by / tot_n,
-                        "note": "every gather-GEMM op of one 4-frame sequence (the GRU cell's two internal products "
-                                "excluded), replayed back to back on one stream running alone"}
+                        "mode": "every gather-GEMM product of one %d-frame sequence (GRU projections included) "
+                                "replayed back to back on one stream running alone" % args.frames,
+                        "whole_step": {"achieved": round(step_tf, 3), "frac": round(step_tf / FP32_MFMA_PEAK_TFLOPS, 4),
+                                       "note": "the same flops per sequence x sequences per step / measured step time of "
+                                               "the TIMED region (all streams): lower bound of the MFMA rate in that mode"}}
                 # HBM-side traffic per launch cannot be read from inside the process: it comes from the two rocprofv3
                 # --pmc passes of this same workload (FETCH_SIZE, WRITE_SIZE) summarised by tools/pmc_summary.py
                 pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
                 default_workload = (args.points, args.frames, args.sigma, args.rnn) == (120000, 4, 0.6, "gru,gru,aflow,gru")
                 if os.path.exists(pmc) and default_workload:
                     with open(pmc) as f:
-                        roof["traffic"] = round(json.load(f)["hbm_bytes_per_launch"])
+                        tr = json.load(f)
+                    roof["traffic"] = round(tr["hbm_bytes_per_launch"])
                     roof["traffic_unit"] = "B per launch (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc passes, " \
                                            "profiles/pmc_traffic.json)"
+            if st_n[0]:
+                names = ("K1_distribute", "K2_pointnet_pool", "K8_slice")
+                stages = {}
+                for k, nm in enumerate(names):
+                    if st_n[k]:
+                        gbps = st_by[k] / (st_ms[k] * 1e-3) / 1e9
+                        stages[nm] = {"algorithmic_bytes": round(st_by[k] / st_n[k]), "us": round(st_ms[k] * 1e3 / st_n[k], 2),
+                                      "GBps": round(gbps, 1), "frac": round(gbps / HBM_PEAK_GBPS, 4), "frames": st_n[k]}
+                # "splat -> conv -> slice" scatter + gather fraction of one (last) frame: K1 + K2 + K8 bytes over their time
+                tot_b = sum(st_by[k] / st_n[k] for k in range(3) if st_n[k])
+                tot_t = sum(st_ms[k] / st_n[k] for k in range(3) if st_n[k]) * 1e-3
+                scatter = {"bound": "hbm", "achieved": round(tot_b / tot_t / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                           "frac": round(tot_b / tot_t / 1e9 / HBM_PEAK_GBPS, 4), "stages": stages,
+                           "note": "HIP events on the launch stream around each stage of every frame of one sequence "
+                                   "running alone; bytes = SURVEY.md 8d (K1 128 N; K2 96 N + 512 V0; K8 768 V0 + 148 N)"}
             if args.breakdown:
                 model.use_frame_program = False
                 ops.profile_begin()
@@ -273,20 +334,20 @@ def main():
         par = ("frames of a sequence sharded over %d ranks (key all-gather + hidden-state hand-off), %d group(s)"
                % (plan.group_size, plan.nr_groups)) if frames_mode else \
             "%d independent sequence stream(s) per GPU, each on its own HIP stream; one step = %s %d-frame sequence%s on " \
-            "every stream (no data-path collective)" % (max(1, args.streams), ("%d lock-stepped" % per_stream_seqs) if args.pairs else "one",
-                                                        args.frames, "s" if args.pairs else "")
+            "every stream (no data-path collective)" % (max(1, args.streams), ("%d lock-stepped" % per_stream_seqs) if per_stream_seqs > 1 else "one",
+                                                        args.frames, "s" if per_stream_seqs > 1 else "")
         line = {
-            "metric": "point-clouds/sec (120k pts, sigma=0.6, 4-frame seq)",
+            "metric": "point-clouds/sec (%dk pts, sigma=%s, %d-frame seq)" % (args.points // 1000, args.sigma, args.frames),
             "value": round(value, 3), "unit": "clouds/s", "n_gpus": args.gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic" if frames_mode or per_stream_seqs == 1 else
-                    "synthetic (one ray-cast drive per stream; the further sequences of its lock-step group are that "
-                    "drive turned about the vertical axis)",
+            "data": "synthetic (temporal_latticenet_amd/synthetic.py: street scene calibrated to the reference's sizing "
+                    "hint, cfg:71: ~10k vertices per 120k-point scan at sigma = 1; inputs resident in HBM)",
             "config": {"workload": "%d-frame sequence, %d pts/frame, sigma=%s, rnn_modules=[%s], 26 classes, "
                                    "full U-Net lattice encoder/decoder, inference" % (args.frames, args.points, args.sigma, args.rnn),
                        "parallelism": par, "vertices_per_frame_V0_V1_V2": vcounts},
-            "roofline": roof, "cpu_baseline": cpu,
+            "value_h2d": None if value_h2d is None else round(value_h2d, 3),
+            "roofline": roof, "roofline_scatter": scatter, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
     if world > 1:
@@ -300,7 +361,9 @@ def cpu_baseline(model, contents, args):
     from temporal_latticenet_amd.synthetic import make_sequence
     from oracle.model import OracleLNN
     m = contents["model"]
-    cores = min(os.cpu_count() or 1, 32)     # eager ops on a few-thousand-row lattice do not scale past this
+    # threads actually used: PyTorch-CPU eager on a 3 x 10^4-row lattice stops scaling (and then collapses) well before
+    # the core count of a GPU host; 32 is the fastest setting measured on the 256-core box
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     oracle = OracleLNN(model.state_dict(), 26, m["rnn_modules"], m["sequence_learning"], m["pointnet_layers"],
                        m["nr_downsamples"], m["nr_blocks_down_stage"], m["nr_blocks_bottleneck"],

@@ -383,8 +383,14 @@ int tln_program_run(tln_program_t* p, int early, float* d_out, int64_t out_rows,
 /* measurement (bench.py roofline): with capture on, tln_program_run remembers the resolved arguments of every
  * gather-GEMM it launches; replay launches that list `reps` times back to back between two HIP events on `stream`
  * and returns the elapsed milliseconds, the number of launches and their algorithmic flops / bytes.
- * The frame's buffers are still in place, so the replays recompute the same values. */
+ * The GRU cell's two projections are on the list too.  The frame's buffers are still in place, so the replays
+ * recompute the same values. */
 int tln_program_capture_gemms(tln_program_t* p, int enable);
+/* measurement (bench.py roofline_scatter): with timing on, every frame records HIP events on its launch stream around
+ * K1 (all kernels of the distribute), K2 (the PointNet pool) and K8 (the slice kernels); _read waits for them and
+ * returns the three durations of the last frame in milliseconds (-1 where the frame had no such stage) */
+int tln_program_timing(tln_program_t* p, int enable);
+int tln_program_timing_read(tln_program_t* p, float* ms_out /* [3] */);
 int tln_program_replay_gemms(tln_program_t* p, int reps, double* ms_total, int64_t* launches, double* flops,
                              double* bytes, void* stream);
 /* Pair mode: two programs compiled from the same model (same weights), each with its own open frame

@@ -129,6 +129,8 @@ _PROTOS = {
     "tln_program_run_pair": (_i, [_vp, _vp, _i, _vp, _i64, _vp, _i64, _i, _vp]),
     "tln_program_run_group": (_i, [C.POINTER(C.c_void_p), _i, _i, C.POINTER(C.c_void_p), C.POINTER(_i64), _i, _vp]),
     "tln_program_capture_gemms": (_i, [_vp, _i]),
+    "tln_program_timing": (_i, [_vp, _i]),
+    "tln_program_timing_read": (_i, [_vp, C.POINTER(C.c_float)]),
     "tln_program_replay_gemms": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(C.c_double),
                                       C.POINTER(C.c_double), _vp]),
     "tln_program_frame_rows": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i64),

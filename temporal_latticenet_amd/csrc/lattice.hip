@@ -87,7 +87,6 @@ struct tln_lattice {
   int32_t* row_rank = nullptr;    // [rows_cap]
   int32_t* vcnt = nullptr;        // [capacity] rows of the frame on vertex v
   int32_t* vstart = nullptr;      // [capacity] first bin position of vertex v
-  long long* vsum = nullptr;      // [capacity][3] fixed-point position sums of the frame
   float4* bin_xyzv = nullptr;     // [rows_cap] position, value
   float* bin_w = nullptr;         // [rows_cap] barycentric weight
   int32_t* bin_row = nullptr;     // [rows_cap] row id
@@ -214,7 +213,6 @@ static int lattice_alloc(tln_lattice** out, int pos_dim, const double* sigmas, i
     TLN_HIP(hipMalloc(&l->vslot, capacity * sizeof(int32_t)));
     TLN_HIP(hipMalloc(&l->vcnt, capacity * sizeof(int32_t)));
     TLN_HIP(hipMalloc(&l->vstart, capacity * sizeof(int32_t)));
-    TLN_HIP(hipMalloc(&l->vsum, capacity * 3 * sizeof(long long)));
   }
   *out = l;
   return TLN_OK;
@@ -308,7 +306,7 @@ extern "C" int tln_lattice_destroy(tln_lattice_t* l) {
   if (l->coarse) tln_lattice_destroy(l->coarse);
   void* ptrs[] = {l->slot_key, l->slot_val, l->slot_touch, l->vkeys, l->d_ctr, l->nbr, l->c2f, l->f2c,
                   l->row_slot, l->block_cnt, l->sk_in, l->sk_out, l->sv_in, l->sv_out, l->sort_temp,
-                  l->seg_start, l->pool_packed, l->mean, l->pieces, l->slot_cnt, l->vslot, l->vcnt, l->vstart, l->vsum,
+                  l->seg_start, l->pool_packed, l->mean, l->pieces, l->slot_cnt, l->vslot, l->vcnt, l->vstart,
                   l->row_rank, l->bin_xyzv, l->bin_w, l->bin_row, l->bin_vtx};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -1326,44 +1324,43 @@ __global__ void __launch_bounds__(256) k_subtract_rows(const float* __restrict__
 //   k_bins_alloc    one thread per vertex: its row count of this frame (from the slot counts of phase A) and a
 //                   contiguous segment of the bin arrays (wave prefix sum + ONE atomic per wave on the cursor)
 //   k_bins_scatter  one thread per row: vertex index (the `indices` output), the row's payload to
-//                   segment start + rank, fixed-point position sums per vertex (int64 atomics: exact, hence
-//                   order-independent), reset of the slot count by the row of rank 0
-//   k_bins_mean     one thread per vertex: mean = sum / count
+//                   segment start + rank, reset of the slot count by the row of rank 0
+//   k_bins_mean     one wave per vertex: fixed-point position sum of its segment (int64: exact, hence
+//                   order-independent) / count
 // Rows without a vertex (key out of range, rejected by the capacity) go to the tail behind all segments.
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_bins_alloc(int32_t* __restrict__ ctr, const int32_t* __restrict__ vslot,
                                                     const uint32_t* __restrict__ slot_cnt, int32_t* __restrict__ vcnt,
-                                                    int32_t* __restrict__ vstart, long long* __restrict__ vsum) {
-  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+                                                    int32_t* __restrict__ vstart) {
   const int nv = ctr[CTR_NV];
   const int lane = threadIdx.x & 63;
-  if (__ballot(v < nv) == 0ull) return;
-  const int c = v < nv ? (int)slot_cnt[vslot[v]] : 0;
-  int incl = c;
+  const int stride = gridDim.x * blockDim.x;
+  for (int v0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63); v0 < nv; v0 += stride) {   // whole waves stay together
+    const int v = v0 + lane;
+    const int c = v < nv ? (int)slot_cnt[vslot[v]] : 0;
+    int incl = c;
 #pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int u = __shfl_up(incl, o, 64);
-    if (lane >= o) incl += u;
-  }
-  const int total = __shfl(incl, 63, 64);
-  int base = 0;
-  if (lane == 0 && total > 0) base = atomicAdd(&ctr[CTR_CURSOR], total);
-  base = __shfl(base, 0, 64);
-  if (v < nv) {
-    vcnt[v] = c;
-    vstart[v] = base + incl - c;
-    vsum[3 * v] = 0;
-    vsum[3 * v + 1] = 0;
-    vsum[3 * v + 2] = 0;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int u = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += u;
+    }
+    const int total = __shfl(incl, 63, 64);
+    int base = 0;
+    if (lane == 0 && total > 0) base = atomicAdd(&ctr[CTR_CURSOR], total);
+    base = __shfl(base, 0, 64);
+    if (v < nv) {
+      vcnt[v] = c;
+      vstart[v] = base + incl - c;
+    }
   }
 }
 
 __global__ void __launch_bounds__(256) k_bins_scatter(TableRef t, const int32_t* __restrict__ row_slot,
                                                       const int32_t* __restrict__ row_rank, int64_t rows,
                                                       const float* __restrict__ pos, const float* __restrict__ val,
-                                                      int val_dim, const float* __restrict__ weights, int subtract,
+                                                      int val_dim, const float* __restrict__ weights,
                                                       uint32_t* __restrict__ slot_cnt, const int32_t* __restrict__ vstart,
-                                                      long long* __restrict__ vsum, int32_t* __restrict__ indices,
+                                                      int32_t* __restrict__ indices,
                                                       float4* __restrict__ bin_xyzv, float* __restrict__ bin_w,
                                                       int32_t* __restrict__ bin_row, int32_t* __restrict__ bin_vtx) {
   const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1381,11 +1378,6 @@ __global__ void __launch_bounds__(256) k_bins_scatter(TableRef t, const int32_t*
   int dest;
   if (v >= 0) {
     dest = vstart[v] + rank;
-    if (subtract) {
-      atomicAdd(reinterpret_cast<unsigned long long*>(&vsum[3 * v]), (unsigned long long)tln_fix20(x));
-      atomicAdd(reinterpret_cast<unsigned long long*>(&vsum[3 * v + 1]), (unsigned long long)tln_fix20(y));
-      atomicAdd(reinterpret_cast<unsigned long long*>(&vsum[3 * v + 2]), (unsigned long long)tln_fix20(z));
-    }
   } else {
     atomicAdd(&t.ctr[CTR_OVERFLOW], 1);
     // behind all segments: CTR_CURSOR is final here (k_bins_alloc has completed)
@@ -1397,15 +1389,35 @@ __global__ void __launch_bounds__(256) k_bins_scatter(TableRef t, const int32_t*
   bin_vtx[dest] = v;
 }
 
+// one WAVE per vertex: its rows are contiguous in the bins; positions summed in fixed point (int64: exact, any order)
 __global__ void __launch_bounds__(256) k_bins_mean(const int32_t* __restrict__ ctr, const int32_t* __restrict__ vcnt,
-                                                   const long long* __restrict__ vsum, float* __restrict__ mean) {
-  const int v = blockIdx.x * blockDim.x + threadIdx.x;
-  if (v >= ctr[CTR_NV]) return;
-  const int c = vcnt[v];
-  const double cnt = (double)(c > 0 ? c : 1);
-  mean[3 * v] = tln_unfix20(vsum[3 * v], cnt);
-  mean[3 * v + 1] = tln_unfix20(vsum[3 * v + 1], cnt);
-  mean[3 * v + 2] = tln_unfix20(vsum[3 * v + 2], cnt);
+                                                   const int32_t* __restrict__ vstart,
+                                                   const float4* __restrict__ bin_xyzv, float* __restrict__ mean) {
+  const int nv = ctr[CTR_NV];
+  const int lane = threadIdx.x & 63;
+  const int nwaves = (int)((gridDim.x * blockDim.x) >> 6);
+  for (int v = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6); v < nv; v += nwaves) {   // the host only has a bound of nv
+    const int c = vcnt[v], st = vstart[v];
+    long long sx = 0, sy = 0, sz = 0;
+    for (int j = lane; j < c; j += 64) {
+      const float4 q = bin_xyzv[st + j];
+      sx += tln_fix20(q.x);
+      sy += tln_fix20(q.y);
+      sz += tln_fix20(q.z);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      sx += __shfl_xor(sx, o, 64);
+      sy += __shfl_xor(sy, o, 64);
+      sz += __shfl_xor(sz, o, 64);
+    }
+    if (lane == 0) {
+      const double cnt = (double)(c > 0 ? c : 1);
+      mean[3 * v] = tln_unfix20(sx, cnt);
+      mean[3 * v + 1] = tln_unfix20(sy, cnt);
+      mean[3 * v + 2] = tln_unfix20(sz, cnt);
+    }
+  }
 }
 
 // accessors for pool.hip: the bins of the last distribute, if they describe (d_distributed, rows)
@@ -1472,17 +1484,13 @@ extern "C" int tln_distribute_begin(tln_lattice_t* l, const float* d_positions, 
   TLN_HIP(hipMemcpyAsync(l->h_ctr, l->d_ctr, CTR_COUNT * sizeof(int32_t), hipMemcpyDeviceToHost, s));
   if (!l->ctr_event) TLN_HIP(hipEventCreateWithFlags(&l->ctr_event, hipEventDisableTiming));
   TLN_HIP(hipEventRecord(l->ctr_event, s));
-  // the bins: the host only knows an upper bound of the vertex count here, the kernels read the exact one
-  int64_t vbound = l->nr_vertices + rows;
-  if (vbound > l->capacity) vbound = l->capacity;
-  hipLaunchKernelGGL(k_bins_alloc, dim3((unsigned)tln_cdiv(vbound, 256)), dim3(256), 0, s, l->d_ctr, l->vslot,
-                     l->slot_cnt, l->vcnt, l->vstart, l->vsum);
+  // the bins: the host does not know the new vertex count yet; the kernels read it and stride over the vertices
+  hipLaunchKernelGGL(k_bins_alloc, dim3(256), dim3(256), 0, s, l->d_ctr, l->vslot, l->slot_cnt, l->vcnt, l->vstart);
   hipLaunchKernelGGL(k_bins_scatter, dim3((unsigned)tln_cdiv(rows, 256)), dim3(256), 0, s, t, l->row_slot, l->row_rank, rows,
-                     d_positions, d_values, val_dim, d_weights, subtract_mean, l->slot_cnt, l->vstart, l->vsum, d_indices,
-                     l->bin_xyzv, l->bin_w, l->bin_row, l->bin_vtx);
+                     d_positions, d_values, val_dim, d_weights, l->slot_cnt, l->vstart, d_indices, l->bin_xyzv, l->bin_w,
+                     l->bin_row, l->bin_vtx);
   if (subtract_mean)
-    hipLaunchKernelGGL(k_bins_mean, dim3((unsigned)tln_cdiv(vbound, 256)), dim3(256), 0, s, l->d_ctr, l->vcnt, l->vsum,
-                       l->mean);
+    hipLaunchKernelGGL(k_bins_mean, dim3(2048), dim3(256), 0, s, l->d_ctr, l->vcnt, l->vstart, l->bin_xyzv, l->mean);
   TLN_LAUNCH_CHECK();
   l->dist_pending = true;
   l->dist_pos = d_positions;

@@ -293,10 +293,9 @@ __global__ void __launch_bounds__(256) k_pool_bins(const TlnBins bn, int64_t row
     }
   };
   // a vertex's rows [js, je] of this chunk are done: its result goes straight to the output when they are ALL its rows
-  auto flush = [&](int v, int js, int je, float best, int bj) {
+  auto flush = [&](int v, int js, int je, float best, int bj, int arg) {
     const bool whole = (tf[js] & 1) && (tf[je] & 2);   // wave-uniform
     if (!active) return;
-    const int arg = tr[bj];
     if (whole) {
       const bool masked = (tf[js] & 4) != 0;
       const float bary = arg > nv ? w0 : tw[bj];
@@ -308,23 +307,26 @@ __global__ void __launch_bounds__(256) k_pool_bins(const TlnBins bn, int64_t row
       atomicMax(&packed[(int64_t)v * COUT + c], p);
     }
   };
-  int cur = tv[0], js = 0, bj = 0;
+  int cur = tv[0], js = 0, bj = 0, brow = tr[0];
   float best = value_of(0);
   for (int j = 1; j < cnt; ++j) {
     const int v = tv[j];
+    const int rj = tr[j];           // one address for the whole wave
     const float val = value_of(j);
     if (v != cur) {  // wave-uniform
-      flush(cur, js, j - 1, best, bj);
+      flush(cur, js, j - 1, best, bj, brow);
       cur = v;
       js = j;
       best = val;
       bj = j;
-    } else if (val > best || (val == best && tr[j] < tr[bj])) {   // ties: the smallest row id
+      brow = rj;
+    } else if (val > best || (val == best && rj < brow)) {   // ties: the smallest row id
       best = val;
       bj = j;
+      brow = rj;
     }
   }
-  flush(cur, js, cnt - 1, best, bj);
+  flush(cur, js, cnt - 1, best, bj, brow);
 }
 
 // what k_pool_bins left open: vertices without rows (zeros, torch_scatter's empty segment), vertices whose segment

@@ -150,6 +150,11 @@ struct tln_program {
   std::vector<SlotRt> rt;
   bool capture = false;
   std::vector<GemmCall> calls;
+  // stage timing (bench.py roofline_scatter): HIP events on the launch stream around K1 (every kernel of the
+  // distribute), K2 (the PointNet pool) and K8 (the slice kernels of the last frame)
+  bool timing = false;
+  hipEvent_t tev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  bool tset[3] = {false, false, false};
   // state of a walk that is split in two (prefix, rest)
   bool w_wrote[TLN_MAX_STATES] = {false};
   int64_t w_new_rows[TLN_MAX_STATES] = {0};
@@ -371,8 +376,13 @@ int walk(tln_program* p, bool dry, int early, float* d_out, int64_t out_rows, in
         const float* w[4] = {o.p[0], o.p[1], o.p[2], o.p[3]};
         const float* b[4] = {o.p[4], o.p[5], o.p[6], o.p[7]};
         int dims[6] = {o.i[1], o.i[2], o.i[3], o.i[4], o.i[5], 0};
+        if (p->timing) TLN_HIP(hipEventRecord(p->tev[2], s));
         rc = tln_pointnet_pool(p->lat, p->d_dist, 4 * p->N, p->dist_cols, nl, w, b, dims, o.i[6], fptr(o.out), s);
         if (rc) return rc;
+        if (p->timing) {
+          TLN_HIP(hipEventRecord(p->tev[3], s));
+          p->tset[1] = true;
+        }
         break;
       }
       case TLN_OP_GRU: {
@@ -383,6 +393,22 @@ int walk(tln_program* p, bool dry, int early, float* d_out, int64_t out_rows, in
         rc = tln_gru_cell(fptr(o.s0.slot), fptr(o.s1.slot), Vr, p->rt[o.s1.slot].rows, Cn, o.p[0], o.p[1], o.p[2], o.p[3],
                           fptr(o.out), reinterpret_cast<float*>(scratch[0]), Vr * 6 * Cn, s);
         if (rc) return rc;
+        if (p->capture && Vr > 0) {   // the cell's two products x @ W_ih^T, h @ W_hh^T as tln_gru_cell issues them
+          float* gi = reinterpret_cast<float*>(scratch[0]);
+          tln_gemm_src sx{};
+          sx.d_src = fptr(o.s0.slot);
+          sx.src_rows = Vr;
+          sx.ld = Cn;
+          sx.cin = Cn;
+          sx.taps = 1;
+          tln_gemm_src sh = sx;
+          sh.d_src = fptr(o.s1.slot);
+          sh.src_rows = p->rt[o.s1.slot].rows;
+          p->calls.push_back(GemmCall{Vr, 3 * Cn, {sx, tln_gemm_src{}}, false, o.p[0], 1, o.p[2], nullptr, 0, 0, gi,
+                                      3 * (int64_t)Cn, nullptr});
+          p->calls.push_back(GemmCall{Vr, 3 * Cn, {sh, tln_gemm_src{}}, false, o.p[1], 1, o.p[3], nullptr, 0, 0,
+                                      gi + Vr * 3 * (int64_t)Cn, 3 * (int64_t)Cn, nullptr});
+        }
         break;
       }
       case TLN_OP_AFLOW: {
@@ -403,24 +429,39 @@ int walk(tln_program* p, bool dry, int early, float* d_out, int64_t out_rows, in
       }
       case TLN_OP_SLICE_GATHER: {
         if (dry) break;
+        if (p->timing && !p->tset[2]) {
+          TLN_HIP(hipEventRecord(p->tev[4], s));
+          p->tset[2] = true;
+        }
         rc = tln_slice_gather(fptr(o.s0.slot), p->rt[o.s0.slot].rows, p->slots[o.s0.slot].cols, p->d_idx, p->d_w, p->N,
                               fptr(o.out), s);
         if (rc) return rc;
+        if (p->timing) TLN_HIP(hipEventRecord(p->tev[5], s));
         break;
       }
       case TLN_OP_SLICE: {
         if (dry) break;
+        if (p->timing && !p->tset[2]) {
+          TLN_HIP(hipEventRecord(p->tev[4], s));
+          p->tset[2] = true;
+        }
         rc = tln_slice(fptr(o.s0.slot), p->rt[o.s0.slot].rows, p->slots[o.s0.slot].cols, p->d_idx, p->d_w,
                        o.s1.slot >= 0 ? fptr(o.s1.slot) : nullptr, o.bias, p->N, fptr(o.out), s);
         if (rc) return rc;
+        if (p->timing) TLN_HIP(hipEventRecord(p->tev[5], s));
         break;
       }
       case TLN_OP_SLICE_DEFORM: {
         if (dry) break;
+        if (p->timing && !p->tset[2]) {
+          TLN_HIP(hipEventRecord(p->tev[4], s));
+          p->tset[2] = true;
+        }
         rc = tln_slice_deform(fptr(o.s0.slot), p->slots[o.s0.slot].cols, fptr(o.s1.slot), p->rt[o.s1.slot].rows,
                               p->slots[o.s1.slot].cols, p->d_idx, p->d_w, o.p[0], o.p[1], o.p[2], o.bias, p->N,
                               fptr(o.out), s);
         if (rc) return rc;
+        if (p->timing) TLN_HIP(hipEventRecord(p->tev[5], s));
         break;
       }
       case TLN_OP_LSTM_GATES: {
@@ -615,6 +656,8 @@ extern "C" int tln_program_destroy(tln_program_t* p) {
       if (p->state_buf[st][k].p) (void)hipFree(p->state_buf[st][k].p);
   if (p->k1.p) (void)hipFree(p->k1.p);
   if (p->arena.p) (void)hipFree(p->arena.p);
+  for (int i = 0; i < 6; ++i)
+    if (p->tev[i]) (void)hipEventDestroy(p->tev[i]);
   delete p;
   return TLN_OK;
 }
@@ -651,8 +694,16 @@ extern "C" int tln_program_begin_frame_start(tln_program_t* p, tln_lattice_t* l,
     rc = tln_lattice_clear(l, s);
     if (rc) return rc;
   }
+  if (p->timing) {
+    p->tset[0] = p->tset[1] = p->tset[2] = false;
+    TLN_HIP(hipEventRecord(p->tev[0], s));
+  }
   rc = tln_distribute_begin(l, d_positions, d_values, n, val_dim, subtract_mean, p->d_dist, p->d_idx, p->d_w, s);
   if (rc) return rc;
+  if (p->timing) {   // every kernel of K1 is enqueued by now (the second half only waits for the counters)
+    TLN_HIP(hipEventRecord(p->tev[1], s));
+    p->tset[0] = true;
+  }
   p->lat = l;
   p->N = n;
   p->dist_cols = cols;
@@ -823,6 +874,29 @@ extern "C" int tln_program_run_pair(tln_program_t* pa, tln_program_t* pb, int ea
   float* const outs[2] = {d_out_a, d_out_b};
   const int64_t rows[2] = {out_rows_a, out_rows_b};
   return tln_program_run_group(pp, 2, early, outs, rows, out_cols, stream_);
+}
+
+// ---- measurement: HIP events around K1 / K2 / K8 of a frame -----------------------------------------------------------
+extern "C" int tln_program_timing(tln_program_t* p, int enable) {
+  TLN_REQUIRE(p, "null program");
+  if (enable)
+    for (int i = 0; i < 6; ++i)
+      if (!p->tev[i]) TLN_HIP(hipEventCreate(&p->tev[i]));
+  p->timing = enable != 0;
+  p->tset[0] = p->tset[1] = p->tset[2] = false;
+  return TLN_OK;
+}
+
+// milliseconds of the last frame's K1 (distribute), K2 (pool), K8 (slice kernels); -1 where the frame had none
+extern "C" int tln_program_timing_read(tln_program_t* p, float* ms_out) {
+  TLN_REQUIRE(p && ms_out && p->timing, "stage timing is off");
+  for (int k = 0; k < 3; ++k) {
+    ms_out[k] = -1.f;
+    if (!p->tset[k]) continue;
+    TLN_HIP(hipEventSynchronize(p->tev[2 * k + 1]));
+    TLN_HIP(hipEventElapsedTime(&ms_out[k], p->tev[2 * k], p->tev[2 * k + 1]));
+  }
+  return TLN_OK;
 }
 
 // ---- measurement: the gather-GEMM launches of the last frame, replayed back to back between two HIP events ------

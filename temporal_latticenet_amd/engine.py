@@ -463,6 +463,15 @@ class FrameProgram:
     def capture_gemms(self, enable=True):
         _lib.check(_lib.lib().tln_program_capture_gemms(self._h, 1 if enable else 0), "tln_program_capture_gemms")
 
+    def stage_timing(self, enable=True):
+        _lib.check(_lib.lib().tln_program_timing(self._h, 1 if enable else 0), "tln_program_timing")
+
+    def stage_times_ms(self):
+        """(K1 distribute, K2 pool, K8 slice) of the last frame in ms; None where the frame had no such stage"""
+        ms = (C.c_float * 3)()
+        _lib.check(_lib.lib().tln_program_timing_read(self._h, ms), "tln_program_timing_read")
+        return [None if v < 0 else float(v) for v in ms]
+
     def replay_gemms(self, reps=5):
         """(ms, launches, flops, algorithmic bytes) of the last frame's gather-GEMM launches replayed `reps` times
         back to back between two HIP events on the current stream"""

@@ -39,7 +39,7 @@ def make_remap_lut(learning_map):
 
 
 def read_labels(path, remap_lut=None):
-    raw = np.fromfile(path, dtype=np.uint32)
+    raw = np.fromfile(path, dtype="<u4")            # little-endian u32 per point (kitti:281-291 reads it as u16 pairs)
     sem = (raw & 0xFFFF).astype(np.int64)           # low 16 bits: class, high 16: instance
     return remap_lut[sem].astype(np.int64) if remap_lut is not None else sem
 
@@ -112,9 +112,15 @@ def range_gate(xyz, cap_distance=60.0, min_distance=3.0):
 
 
 def load_sequence(data_dir, seq, index, frames_per_seq=4, cloud_scope=3, remap_lut=None, cap_distance=60.0,
-                  min_distance=3.0, rng=None, with_labels=True):
+                  min_distance=3.0, rng=None, with_labels=True, split="train"):
     """The loader's output contract (kitti:100-197): lists of positions [N_i,3] f32, values [N_i,1] f32,
-    labels [N_i] i64, paths, lengths — all frames in the first frame's coordinates."""
+    labels [N_i] i64, paths, lengths — all frames in the first frame's coordinates.
+    As in the reference, the range gate (kitti:142-154) and the point shuffle (kitti:172-177) apply to the "train" split
+    only: a valid / test cloud keeps every point in file order, so that the per-point prediction file written by
+    write_prediction_labels lines up with the .bin scan; the "test" split has no label files (kitti:135-136)."""
+    is_training = split == "train"
+    if split == "test":
+        with_labels = False
     sdir = os.path.join(data_dir, "sequences", "%02d" % seq)
     poses = parse_poses(os.path.join(sdir, "poses.txt"), parse_calibration(os.path.join(sdir, "calib.txt")))
     ids = window_indices(index, frames_per_seq, cloud_scope)
@@ -124,10 +130,11 @@ def load_sequence(data_dir, seq, index, frames_per_seq=4, cloud_scope=3, remap_l
         xyz, refl = read_scan(path)
         lab = read_labels(os.path.join(sdir, "labels", "%06d.label" % i), remap_lut) if with_labels \
             else np.zeros(xyz.shape[0], np.int64)
-        keep = range_gate(xyz, cap_distance, min_distance)
-        xyz, refl, lab = xyz[keep], refl[keep], lab[keep]
+        if is_training:
+            keep = range_gate(xyz, cap_distance, min_distance)
+            xyz, refl, lab = xyz[keep], refl[keep], lab[keep]
         pos = to_first_frame(xyz, poses[i], poses[ids[0]])
-        if rng is not None:                              # shuffle_points (kitti:172-177)
+        if rng is not None and is_training:              # shuffle_points (kitti:172-177)
             perm = rng.permutation(pos.shape[0])
             pos, refl, lab = pos[perm], refl[perm], lab[perm]
         out[0].append(pos)

@@ -119,6 +119,8 @@ class SequenceStreams:
                     rest, model, lat = sequences, self.models[i], self.lattices[i]
                 for seq in rest:
                     for t, (p, v) in enumerate(seq):
+                        if not p.is_cuda:      # frames waiting in (pinned) host memory: copied on this stream
+                            p, v = p.to("cuda", non_blocking=True), v.to("cuda", non_blocking=True)
                         out, raw, lat = model(lat, p, v, t != len(seq) - 1, False)
                     model.reset_sequence()
                     if keep_outputs:
