@@ -156,6 +156,14 @@ def main():
                 keys = runner.exchange_keys([mine] * n)
                 for i in range(n):
                     runner.run_sequence(mine, keys[i])
+
+            def one_sequence_latency():
+                # ONE sequence alone in the pipeline: from the first rank's start to the last rank's end
+                barrier()
+                t_ = time.perf_counter()
+                run_steps(1)
+                barrier()
+                return D.max_over_ranks(time.perf_counter() - t_, device=None if via_host else "cuda")
         else:
             # every stream gets its own synthetic drive (different seed => different vertex counts per stream)
             from temporal_latticenet_amd.streams import SequenceStreams
@@ -185,11 +193,15 @@ def main():
                 pool.run([per_stream[per * i:per * i + per] * n for i in range(S)])
 
         run_steps(args.warmup)
+        latency = min(one_sequence_latency() for _ in range(3)) if frames_mode else None
         barrier()
         t0 = time.perf_counter()
         run_steps(args.steps)
         barrier()
         elapsed = D.max_over_ranks(time.perf_counter() - t0, device=None if via_host else "cuda")
+
+        if frames_mode:
+            runner.close()      # hooks off, frame program back: the passes below run one sequence on this rank alone
 
         # ---- the same job with the frames waiting in pinned host memory (the reference's loop copies every frame to
         # the device, train_ln.py:164-166): a shorter second timed region, sequence mode only
@@ -349,6 +361,13 @@ def main():
             "value_h2d": None if value_h2d is None else round(value_h2d, 3),
             "roofline": roof, "roofline_scatter": scatter, "cpu_baseline": cpu,
         }
+        if frames_mode:
+            # the recurrence bounds what one sequence gains from more GPUs (latency); a stream of
+            # sequences keeps every rank busy with a different one (steady state = `value`)
+            line["frames_mode"] = {"latency_ms_per_sequence": round(latency * 1e3, 3),
+                                   "steady_state_clouds_per_s": round(value, 3),
+                                   "note": "latency: one %d-frame sequence alone through the %d-rank pipeline (best of 3); "
+                                           "steady state: the timed region, sequences back to back" % (args.frames, plan.group_size)}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

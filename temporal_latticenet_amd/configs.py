@@ -27,6 +27,21 @@ def make_config(rnn_modules=("gru", "gru", "aflow", "gru"), sequence_learning=Tr
     }
 
 
+def suggest_capacity(nr_points, sigma, frames=1):
+    """hash_table_capacity (cfg:71 makes it a hand-set knob: "100000 // good for semantic kitti which splat around 10k
+    with sigma of 1") from the cloud size and the lattice scale instead.  Calibration: a 120k-point 64-beam scan hashes
+    to ~19k vertices at sigma = 0.6 and ~8.6k at sigma = 1.0 (vertices ~ sigma^-1.6: surfaces, not volumes), a sensor
+    moving 1.5 m per frame adds ~20 % of that per further frame; a sparser sampling of the same scene still touches most
+    of its vertices (~N^0.2 below 120k points), more points add vertices sub-linearly (~N^0.8 above).  Three times that estimate, never more than the hard bound 4 * points * frames (every point touches at
+    most d+1 = 4 vertices; the bound is what very fine lattices reach), never less than 4096."""
+    n = float(nr_points)
+    rel = n / 120000.0
+    est = 19000.0 * rel ** (0.8 if rel > 1.0 else 0.2) * (0.6 / float(sigma)) ** 1.6 * (1.0 + 0.25 * (frames - 1))
+    hard = 4.0 * n * frames
+    cap = int(min(3.0 * est, hard))
+    return max(4096, (cap + 1023) // 1024 * 1024)
+
+
 def build_model(contents, nr_classes=26):
     from .cfg import cfgParser
     from .lattice import ModelParams
@@ -35,8 +50,16 @@ def build_model(contents, nr_classes=26):
     return LNN_SEQ(nr_classes, ModelParams(contents["model"]), parser).to("cuda")
 
 
-def make_lattice(contents):
+def make_lattice(contents, nr_points=None, frames=None):
+    """hash_table_capacity: a number, or "auto" -> suggest_capacity(nr_points per frame, sigma, frames of the sequence)"""
     from .lattice import Lattice
     lg = contents["lattice_gpu"]
     sigma = float(str(lg["sigma_0"]).split()[0])
-    return Lattice.from_params([sigma] * 3, int(lg["hash_table_capacity"]))
+    cap = lg["hash_table_capacity"]
+    if isinstance(cap, str) and cap.strip().lower() == "auto":
+        if nr_points is None:
+            raise ValueError('hash_table_capacity "auto" needs the number of points per frame')
+        if frames is None:
+            frames = int(contents.get("loader_semantic_kitti", {}).get("frames_per_seq", 1))
+        cap = suggest_capacity(nr_points, sigma, frames)
+    return Lattice.from_params([sigma] * 3, int(cap))

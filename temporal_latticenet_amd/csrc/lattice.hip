@@ -32,14 +32,21 @@ enum { CTR_NV = 0, CTR_NEW = 1, CTR_OVERFLOW = 2, CTR_PROBE_FAIL = 3, CTR_VOLD =
 #define TLN_MAX_PROBES 8192
 #define TLN_SCAN_BLOCK 1024
 
+// One hash-table slot: the packed key, the vertex index (-1 until numbered) and the smallest row id that touched the
+// slot while it was un-numbered.  16 bytes, read with ONE load per probe step (three arrays meant three dependent
+// cache lines per step).  Empty = all bits set.
+struct __attribute__((aligned(16))) TlnSlot {
+  unsigned long long key;
+  int32_t val;
+  uint32_t touch;
+};
+
 struct tln_lattice {
   int pos_dim = 3, level = 0;
   int64_t capacity = 0, nslots = 0;
   double sigmas[3] = {1, 1, 1};
   float scale[3] = {1, 1, 1};
-  uint64_t* slot_key = nullptr;
-  int32_t* slot_val = nullptr;
-  uint32_t* slot_touch = nullptr;
+  TlnSlot* slots = nullptr;   // [nslots] {key, vertex index, first-touch row}: one 16-byte record per probe step
   int32_t* vkeys = nullptr;  // [capacity][4]
   int32_t* d_ctr = nullptr;
   int32_t* h_ctr = nullptr;
@@ -200,9 +207,7 @@ static int lattice_alloc(tln_lattice** out, int pos_dim, const double* sigmas, i
     // (seq_config/lnn_train_semantic_kitti.cfg:71, ~10k vertices for a KITTI scan at sigma = 1); DESIGN.md §3.1
     l->scale[i] = (float)(4.0 * sqrt(2.0 / 3.0) / (sigmas[i] * sqrt((double)((i + 1) * (i + 2)))));
   }
-  TLN_HIP(hipMalloc(&l->slot_key, ns * sizeof(uint64_t)));
-  TLN_HIP(hipMalloc(&l->slot_val, ns * sizeof(int32_t)));
-  TLN_HIP(hipMalloc(&l->slot_touch, ns * sizeof(uint32_t)));
+  TLN_HIP(hipMalloc(&l->slots, ns * sizeof(TlnSlot)));
   TLN_HIP(hipMalloc(&l->vkeys, capacity * 4 * sizeof(int32_t)));
   TLN_HIP(hipMalloc(&l->d_ctr, CTR_COUNT * sizeof(int32_t)));
   TLN_HIP(hipHostMalloc(&l->h_ctr, CTR_COUNT * sizeof(int32_t)));
@@ -221,9 +226,7 @@ static int lattice_alloc(tln_lattice** out, int pos_dim, const double* sigmas, i
 // every level of a lattice emptied by ONE launch (slot tables to 0xFF.., counters to 0) instead of four memsets each
 struct ClearJobs {
   struct {
-    uint64_t* key;
-    int32_t* val;
-    uint32_t* touch;
+    TlnSlot* slots;
     uint32_t* cnt;   // per-slot row counts (level 0), may be NULL
     int32_t* ctr;
     int64_t nslots;
@@ -234,16 +237,13 @@ __global__ void __launch_bounds__(256) k_clear_levels(ClearJobs jobs) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   for (int k = 0; k < jobs.n; ++k) {
-    // 16 bytes of keys + 8 of values + 8 of touches per step and thread
-    ulonglong2* key2 = reinterpret_cast<ulonglong2*>(jobs.j[k].key);
-    int2* val2 = reinterpret_cast<int2*>(jobs.j[k].val);
-    uint2* touch2 = reinterpret_cast<uint2*>(jobs.j[k].touch);
+    // an empty slot is 16 bytes of ones (key, vertex index -1, touch); two slots per step and thread
+    ulonglong2* raw = reinterpret_cast<ulonglong2*>(jobs.j[k].slots);
     uint2* cnt2 = reinterpret_cast<uint2*>(jobs.j[k].cnt);
     const int64_t pairs = jobs.j[k].nslots >> 1;  // slot counts are powers of two
     for (int64_t i = id; i < pairs; i += stride) {
-      key2[i] = make_ulonglong2(~0ull, ~0ull);
-      val2[i] = make_int2(-1, -1);
-      touch2[i] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+      raw[2 * i] = make_ulonglong2(~0ull, ~0ull);
+      raw[2 * i + 1] = make_ulonglong2(~0ull, ~0ull);
       if (cnt2) cnt2[i] = make_uint2(0u, 0u);
     }
     if (id < CTR_COUNT) jobs.j[k].ctr[id] = 0;
@@ -262,9 +262,7 @@ extern "C" int tln_lattice_clear(tln_lattice_t* l, void* stream_) {
       hipLaunchKernelGGL(k_clear_levels, dim3(2048), dim3(256), 0, s, jobs);
       jobs.n = 0;
     }
-    jobs.j[jobs.n].key = p->slot_key;
-    jobs.j[jobs.n].val = p->slot_val;
-    jobs.j[jobs.n].touch = p->slot_touch;
+    jobs.j[jobs.n].slots = p->slots;
     jobs.j[jobs.n].cnt = p->slot_cnt;
     jobs.j[jobs.n].ctr = p->d_ctr;
     jobs.j[jobs.n].nslots = p->nslots;
@@ -304,7 +302,7 @@ extern "C" int tln_lattice_destroy(tln_lattice_t* l) {
   }
   if (!l) return TLN_OK;
   if (l->coarse) tln_lattice_destroy(l->coarse);
-  void* ptrs[] = {l->slot_key, l->slot_val, l->slot_touch, l->vkeys, l->d_ctr, l->nbr, l->c2f, l->f2c,
+  void* ptrs[] = {l->slots, l->vkeys, l->d_ctr, l->nbr, l->c2f, l->f2c,
                   l->row_slot, l->block_cnt, l->sk_in, l->sk_out, l->sv_in, l->sv_out, l->sort_temp,
                   l->seg_start, l->pool_packed, l->mean, l->pieces, l->slot_cnt, l->vslot, l->vcnt, l->vstart,
                   l->row_rank, l->bin_xyzv, l->bin_w, l->bin_row, l->bin_vtx};
@@ -336,32 +334,42 @@ extern "C" int64_t tln_lattice_overflow_rows(const tln_lattice_t* lc) {
 // device: table access
 // ---------------------------------------------------------------------------------------
 struct TableRef {
-  uint64_t* slot_key;
-  int32_t* slot_val;
-  uint32_t* slot_touch;
+  TlnSlot* slots;
   int32_t* ctr;
   uint64_t mask;
 };
 static TableRef table_ref(const tln_lattice* l) {
-  return TableRef{l->slot_key, l->slot_val, l->slot_touch, l->d_ctr, (uint64_t)(l->nslots - 1)};
+  return TableRef{l->slots, l->d_ctr, (uint64_t)(l->nslots - 1)};
+}
+
+// one probe step = ONE 16-byte load of the slot record
+__device__ __forceinline__ void load_slot(const TableRef& t, uint64_t slot, unsigned long long& key, int& val,
+                                          uint32_t& touch) {
+  const ulonglong2 raw = *reinterpret_cast<const ulonglong2*>(&t.slots[slot]);
+  key = raw.x;
+  val = (int)(uint32_t)(raw.y & 0xFFFFFFFFull);
+  touch = (uint32_t)(raw.y >> 32);
 }
 
 // find-or-claim the slot of key K; records the smallest row id touching a not-yet-numbered slot
 __device__ __forceinline__ int probe_insert(const TableRef& t, uint64_t K, uint32_t id) {
   uint64_t slot = tln_mix64(K) & t.mask;
   for (int probe = 0; probe < TLN_MAX_PROBES; ++probe) {
-    uint64_t cur = t.slot_key[slot];
+    unsigned long long cur;
+    int val;
+    uint32_t touch;
+    load_slot(t, slot, cur, val, touch);
     if (cur == TLN_KEY_EMPTY) {
-      cur = atomicCAS((unsigned long long*)&t.slot_key[slot], (unsigned long long)TLN_KEY_EMPTY, (unsigned long long)K);
+      cur = atomicCAS(&t.slots[slot].key, (unsigned long long)TLN_KEY_EMPTY, (unsigned long long)K);
       if (cur == TLN_KEY_EMPTY) {
         cur = K;
         atomicAdd(&t.ctr[CTR_OCCUPIED], 1);
       }
+      val = -1;            // a slot that was empty a moment ago is un-numbered, whoever claimed it
+      touch = 0xFFFFFFFFu; // (a stale larger value only costs an atomicMin)
     }
     if (cur == K) {
-      if (t.slot_val[slot] < 0) {
-        if (t.slot_touch[slot] > id) atomicMin(&t.slot_touch[slot], id);
-      }
+      if (val < 0 && touch > id) atomicMin(&t.slots[slot].touch, id);
       return (int)slot;
     }
     slot = (slot + 1) & t.mask;
@@ -374,8 +382,11 @@ __device__ __forceinline__ int probe_insert(const TableRef& t, uint64_t K, uint3
 __device__ __forceinline__ int probe_find(const TableRef& t, uint64_t K) {
   uint64_t slot = tln_mix64(K) & t.mask;
   for (int probe = 0; probe < TLN_MAX_PROBES; ++probe) {
-    uint64_t cur = t.slot_key[slot];
-    if (cur == K) return t.slot_val[slot];
+    unsigned long long cur;
+    int val;
+    uint32_t touch;
+    load_slot(t, slot, cur, val, touch);
+    if (cur == K) return val;
     if (cur == TLN_KEY_EMPTY) return -1;
     slot = (slot + 1) & t.mask;
   }
@@ -509,10 +520,10 @@ __global__ void __launch_bounds__(256) k_rehash(const int32_t* __restrict__ vkey
   const uint64_t K = tln_pack_key(vkeys[4 * v], vkeys[4 * v + 1], vkeys[4 * v + 2]);
   uint64_t slot = tln_mix64(K) & t.mask;
   for (int probe = 0; probe < TLN_MAX_PROBES; ++probe) {
-    const uint64_t old = atomicCAS((unsigned long long*)&t.slot_key[slot], (unsigned long long)TLN_KEY_EMPTY,
+    const uint64_t old = atomicCAS((unsigned long long*)&t.slots[slot].key, (unsigned long long)TLN_KEY_EMPTY,
                                    (unsigned long long)K);
     if (old == TLN_KEY_EMPTY) {
-      t.slot_val[slot] = (int32_t)v;
+      t.slots[slot].val = (int32_t)v;
       if (vslot) vslot[v] = (int32_t)slot;
       return;
     }
@@ -526,27 +537,17 @@ static int ensure_slots(tln_lattice* l, int64_t rows, hipStream_t s) {
   int64_t ns = l->nslots;
   while (ns < 2 * (l->nr_vertices + rows)) ns <<= 1;
   TLN_HIP(hipStreamSynchronize(s));
-  uint64_t* nk = nullptr;
-  int32_t* nv = nullptr;
-  uint32_t* nt = nullptr;
-  TLN_HIP(hipMalloc(&nk, ns * sizeof(uint64_t)));
-  TLN_HIP(hipMalloc(&nv, ns * sizeof(int32_t)));
-  TLN_HIP(hipMalloc(&nt, ns * sizeof(uint32_t)));
-  TLN_HIP(hipMemsetAsync(nk, 0xFF, ns * sizeof(uint64_t), s));
-  TLN_HIP(hipMemsetAsync(nv, 0xFF, ns * sizeof(int32_t), s));
-  TLN_HIP(hipMemsetAsync(nt, 0xFF, ns * sizeof(uint32_t), s));
+  TlnSlot* nk = nullptr;
+  TLN_HIP(hipMalloc(&nk, ns * sizeof(TlnSlot)));
+  TLN_HIP(hipMemsetAsync(nk, 0xFF, ns * sizeof(TlnSlot), s));
   if (l->slot_cnt) {   // between frames every count is zero: the new array just starts that way
     (void)hipFree(l->slot_cnt);
     l->slot_cnt = nullptr;
     TLN_HIP(hipMalloc(&l->slot_cnt, ns * sizeof(uint32_t)));
     TLN_HIP(hipMemsetAsync(l->slot_cnt, 0, ns * sizeof(uint32_t), s));
   }
-  (void)hipFree(l->slot_key);
-  (void)hipFree(l->slot_val);
-  (void)hipFree(l->slot_touch);
-  l->slot_key = nk;
-  l->slot_val = nv;
-  l->slot_touch = nt;
+  (void)hipFree(l->slots);
+  l->slots = nk;
   l->nslots = ns;
   if (l->nr_vertices > 0) {
     hipLaunchKernelGGL(k_rehash, dim3((unsigned)tln_cdiv(l->nr_vertices, 256)), dim3(256), 0, s, l->vkeys,
@@ -706,7 +707,7 @@ __device__ __forceinline__ bool is_first_touch(const TableRef& t, const int32_t*
   if (id >= rows) return false;
   slot = row_slot[id];
   if (slot < 0) return false;
-  return t.slot_val[slot] < 0 && t.slot_touch[slot] == (uint32_t)id;
+  return t.slots[slot].val < 0 && t.slots[slot].touch == (uint32_t)id;
 }
 
 __global__ void __launch_bounds__(TLN_SCAN_BLOCK) k_count_new(TableRef t, const int32_t* __restrict__ row_slot,
@@ -771,14 +772,14 @@ __global__ void __launch_bounds__(TLN_SCAN_BLOCK) k_assign_new(TableRef t, const
   const int rank = block_off + woff + __popcll(m & ((1ull << lane) - 1ull));
   const long long v = (long long)vold + rank;
   if (v < capacity) {
-    t.slot_val[slot] = (int)v;
+    t.slots[slot].val = (int)v;
     if (vslot) vslot[v] = slot;
     int k0, k1, k2;
-    tln_unpack_key(t.slot_key[slot], k0, k1, k2);
+    tln_unpack_key(t.slots[slot].key, k0, k1, k2);
     int4 kk = make_int4(k0, k1, k2, -(k0 + k1 + k2));
     *reinterpret_cast<int4*>(vkeys + 4 * v) = kk;
   } else {
-    t.slot_touch[slot] = 0xFFFFFFFFu;  // stays un-numbered; may be retried by a later insertion
+    t.slots[slot].touch = 0xFFFFFFFFu;  // stays un-numbered; may be retried by a later insertion
   }
 }
 
@@ -793,7 +794,7 @@ __global__ void __launch_bounds__(256) k_row_indices(TableRef t, const int32_t* 
   if (id >= rows) return;
   const int slot = row_slot[id];
   int idx = -1;
-  if (slot >= 0) idx = t.slot_val[slot];
+  if (slot >= 0) idx = t.slots[slot].val;
   if (indices) indices[id] = idx;
   if (idx < 0) atomicAdd(&ctr[CTR_OVERFLOW], 1);
   if (sk_in) {
@@ -834,13 +835,13 @@ __global__ void __launch_bounds__(TLN_SCAN_BLOCK) k_number_small(TableRef t, con
     if (f) {
       const long long v = (long long)vold + running + woff + __popcll(m & ((1ull << lane) - 1ull));
       if (v < capacity) {
-        t.slot_val[slot] = (int)v;
+        t.slots[slot].val = (int)v;
         if (vslot) vslot[v] = slot;
         int k0, k1, k2;
-        tln_unpack_key(t.slot_key[slot], k0, k1, k2);
+        tln_unpack_key(t.slots[slot].key, k0, k1, k2);
         *reinterpret_cast<int4*>(vkeys + 4 * v) = make_int4(k0, k1, k2, -(k0 + k1 + k2));
       } else {
-        t.slot_touch[slot] = 0xFFFFFFFFu;
+        t.slots[slot].touch = 0xFFFFFFFFu;
       }
     }
     __syncthreads();
@@ -1369,7 +1370,7 @@ __global__ void __launch_bounds__(256) k_bins_scatter(TableRef t, const int32_t*
   const int rank = row_rank[row];
   int v = -1;
   if (slot >= 0) {
-    v = t.slot_val[slot];
+    v = t.slots[slot].val;
     if (rank == 0) slot_cnt[slot] = 0;   // exactly one row per touched slot: the counts are zero again for the next frame
   }
   indices[row] = v;

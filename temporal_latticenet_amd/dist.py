@@ -128,6 +128,10 @@ class FrameShardRunner:
          sends it to the next rank right after it is produced (forward hooks, point-to-point), so rank g works on
          stage s of its frame while rank g-1 is already past it — over a stream of sequences this is a systolic
          pipeline in which every rank is busy with a different sequence.
+         Ordering: between a pair of neighbouring ranks the messages are matched by ORDER alone (the NCCL / RCCL
+         backend ignores tags): both sides walk the fusion slots in the model's fixed order early -> middle ->
+         bottleneck -> late, one (header, payload) pair per slot and frame, and a rank only ever receives from its
+         predecessor and sends to its successor — so the k-th send of rank g is the k-th receive of rank g+1.
 
     `via_host=True` stages tensors through host memory (gloo); otherwise tensors go GPU-to-GPU (RCCL over xGMI).
     """
@@ -140,9 +144,26 @@ class FrameShardRunner:
         self._recv_now = False
         self._send_now = False
         self._slots = []
-        # the hidden-state hand-off hangs on the fusion modules' forward hooks: stay on the operator-level route
+        # the hidden-state hand-off hangs on the fusion modules' forward hooks: stay on the operator-level route until
+        # close() (the frame program has no send / receive ops yet)
+        self._was_program = getattr(model, "use_frame_program", True)
         model.use_frame_program = False
+        self._hooks = []
         self._install_hooks()
+
+    def close(self):
+        """removes the hand-off hooks and gives the model its frame program back"""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        self.model.use_frame_program = self._was_program
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
 
     # ---- hidden-state hand-off ----------------------------------------------------------------
     def _fusion_modules(self):
@@ -157,8 +178,8 @@ class FrameShardRunner:
     def _install_hooks(self):
         for slot, mod in enumerate(self._fusion_modules()):
             self._slots.append(mod)
-            mod.register_forward_pre_hook(self._make_pre(slot))
-            mod.register_forward_hook(self._make_post(slot))
+            self._hooks.append(mod.register_forward_pre_hook(self._make_pre(slot)))
+            self._hooks.append(mod.register_forward_hook(self._make_post(slot)))
 
     def _make_pre(self, slot):
         def pre(mod, args):

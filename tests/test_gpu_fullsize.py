@@ -1,0 +1,168 @@
+"""GPU: the whole path at BASELINE's sizes against the oracle (north-star tolerance 1e-4 on the per-point logits):
+  * config 3 / 4 workloads: 4 frames x 120 000 points, sigma 0.6, [gru,gru,gru,gru] and the pretrained
+    [gru,gru,aflow,gru] — through the frame program, and once more through a lock-step group (models.forward_group)
+  * config 5, reduced in size: an accumulated cloud (accumulate_clouds, kitti_dataloader.py:198-201) with the capacity
+    taken from configs.suggest_capacity, `len_seq` tail selection through write_prediction_labels (test_ln.py:220), and
+    8 recurrent frames
+  * the vis_aflow=True forward (models.py:442-461)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ops as O
+from tests.helpers import build_model, make_config, make_lattice, oracle_from_model, randomize_parameters
+from temporal_latticenet_amd.synthetic import make_sequence
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _run(model, contents, seq, gpu, lattice=None, **kw):
+    lat = lattice if lattice is not None else make_lattice(contents)
+    outs = []
+    with torch.no_grad():
+        for t, (pos, val) in enumerate(seq):
+            a, b, lat = model(lat, torch.from_numpy(pos).to(gpu), torch.from_numpy(val).to(gpu), t != len(seq) - 1,
+                              False, **(kw if t == len(seq) - 1 else {}))
+            outs.append(b)
+    model.reset_sequence()
+    return outs, lat
+
+
+def _prepared(contents, seq, gpu, seed):
+    model = build_model(contents).eval()
+    warm = [(p[:4096], v[:4096]) for p, v in seq[:2]]          # the lazily created parameters only depend on widths
+    _run(model, contents, warm, gpu)
+    randomize_parameters(model, seed=seed)
+    return model
+
+
+def _check(got, want, what):
+    got = got.cpu()
+    assert got.shape == want.shape
+    scale = max(1.0, float(want.abs().max()))
+    err = float((got - want).abs().max())
+    assert err <= TOL * scale, "%s: max abs err %.3e (scale %.2f)" % (what, err, scale)
+
+
+@pytest.mark.parametrize("rnn", [("gru", "gru", "aflow", "gru"), ("gru", "gru", "gru", "gru")])
+def test_four_frames_of_120k_points_match_the_oracle(gpu, rnn):
+    contents = make_config(rnn_modules=rnn, frames=4, sigma=0.6)
+    seq = make_sequence(120000, 4)
+    model = _prepared(contents, seq, gpu, seed=5)
+    outs, lat = _run(model, contents, seq, gpu)
+    assert getattr(model, "_program", None) is not None, "the frame program was not used"
+    assert lat.nr_lattice_vertices() > 25000 and lat.overflow_rows() == 0
+    oracle = oracle_from_model(model, contents)
+    for t, (pos, val) in enumerate(seq):
+        want = oracle.forward(pos, val, early_return=(t != len(seq) - 1))
+        _check(outs[t], want, "%s frame %d" % (",".join(rnn), t))
+    assert outs[-1].shape == (120000, 26)
+    # the same sequence as one of two lock-stepped sequences of a stream (shared gather-GEMM launches where eligible)
+    from temporal_latticenet_amd.configs import build_model as bm
+    from temporal_latticenet_amd.models import forward_group
+    from temporal_latticenet_amd.streams import share_parameters
+    other = bm(contents).eval()
+    _run(other, contents, [(p[:4096], v[:4096]) for p, v in seq[:2]], gpu)
+    share_parameters(other, model)
+    seq_b = make_sequence(60000, 4, seed=7)
+    lats = [make_lattice(contents), make_lattice(contents)]
+    with torch.no_grad():
+        for t in range(4):
+            res = forward_group([model, other], lats, [torch.from_numpy(seq[t][0]).to(gpu), torch.from_numpy(seq_b[t][0]).to(gpu)],
+                                [torch.from_numpy(seq[t][1]).to(gpu), torch.from_numpy(seq_b[t][1]).to(gpu)], t != 3)
+            lats = [r[2] for r in res]
+    model.reset_sequence()
+    other.reset_sequence()
+    _check(res[0][1], want, "lock-step group, last frame")
+
+
+def test_accumulated_cloud_and_prediction_tail(gpu, tmp_path):
+    """accumulate_clouds: the loader hands the model ONE cloud = the concatenated frames (kitti:198-201); the prediction
+    file only holds the points of the last cloud (test_ln.py:220).  Capacity from N and sigma (configs.suggest_capacity)."""
+    from temporal_latticenet_amd import kitti_io as K
+    from temporal_latticenet_amd.configs import suggest_capacity
+    frames = make_sequence(40000, 8, seed=13)
+    pos = np.concatenate([p for p, _ in frames])
+    val = np.concatenate([v for _, v in frames])
+    lens = [p.shape[0] for p, _ in frames]
+    contents = make_config(rnn_modules=("gru", "gru", "aflow", "gru"), frames=1, sigma=0.6, capacity="auto")
+    cap = suggest_capacity(pos.shape[0], 0.6, 1)
+    model = _prepared(make_config(rnn_modules=("gru", "gru", "aflow", "gru"), frames=1, sigma=0.6), frames, gpu, seed=6)
+    with pytest.raises(ValueError):
+        make_lattice(contents)                                   # "auto" needs the cloud size
+    lat = make_lattice(contents, nr_points=pos.shape[0], frames=1)
+    assert lat.capacity() == cap
+    outs, lat = _run(model, contents, [(pos, val)], gpu, lattice=lat)
+    assert lat.overflow_rows() == 0 and lat.nr_lattice_vertices() < cap
+    contents_o = make_config(rnn_modules=("gru", "gru", "aflow", "gru"), frames=1, sigma=0.6, capacity=cap)
+    want = oracle_from_model(model, contents_o).forward(pos, val)
+    _check(outs[0], want, "accumulated cloud of %d points" % pos.shape[0])
+    pred = outs[0].argmax(1).cpu().numpy()
+    path = str(tmp_path / "sequences" / "08" / "predictions" / "000007.label")
+    K.write_prediction_labels(path, pred, len_last_cloud=lens[-1])
+    back = K.read_prediction_labels(path)
+    assert back.shape[0] == lens[-1] and np.array_equal(back, pred[-lens[-1]:])
+
+
+def test_eight_recurrent_frames_match_the_oracle(gpu):
+    contents = make_config(rnn_modules=("gru", "gru", "aflow", "gru"), frames=8, sigma=0.6)
+    seq = make_sequence(30000, 8, seed=21)
+    model = _prepared(contents, seq, gpu, seed=7)
+    outs, lat = _run(model, contents, seq, gpu)
+    oracle = oracle_from_model(model, contents)
+    for t, (pos, val) in enumerate(seq):
+        want = oracle.forward(pos, val, early_return=(t != len(seq) - 1))
+        _check(outs[t], want, "frame %d of 8" % t)
+
+
+def test_vis_aflow_forward(gpu, monkeypatch):
+    """models.py:442-461: with vis_aflow the last frame also leaves, for the AFlow module in use (lm:204-205, 219), the
+    [V2, 9] neighbour indices into the previous hidden state and the [V2, 9] correlation weights, plus the mean position
+    of every level-0 vertex; the logits are those of the plain forward"""
+    contents = make_config(rnn_modules=("gru", "gru", "aflow", "gru"), frames=3, sigma=0.6)
+    seq = make_sequence(20000, 3, seed=33)
+    model = _prepared(contents, seq, gpu, seed=8)
+    plain, _ = _run(model, contents, seq, gpu)
+    lat = make_lattice(contents)
+    outs = []
+    with torch.no_grad():
+        for t, (pos, val) in enumerate(seq):
+            last = t == len(seq) - 1
+            a, b, lat = model(lat, torch.from_numpy(pos).to(gpu), torch.from_numpy(val).to(gpu), not last, False,
+                              vis_aflow=last)
+            outs.append(b)
+    nbr_list, avg_list, w_list = model.visualize_the_aflow_module()      # before reset_sequence clears them
+    model.reset_sequence()
+    assert len(nbr_list) == len(avg_list) == len(w_list) == 1
+    np.testing.assert_allclose(outs[-1].cpu().numpy(), plain[-1].cpu().numpy(), rtol=0, atol=2e-5)
+    # oracle twin: capture the AFlow weights / table of the last frame
+    seen = {}
+    real = O.aflow_correlation
+
+    def spy(x, h_padded, table, *a, **k):
+        out, w, tab = real(x, h_padded, table, *a, **k)
+        seen["w"], seen["table"] = w, tab
+        return out, w, tab
+
+    monkeypatch.setattr(O, "aflow_correlation", spy)
+    oracle = oracle_from_model(model, contents)
+    for t, (pos, val) in enumerate(seq):
+        want = oracle.forward(pos, val, early_return=(t != len(seq) - 1))
+    _check(outs[-1], want, "vis_aflow logits")
+    w = w_list[0].cpu().numpy()
+    assert w.shape == tuple(seen["w"].shape) and w.shape[1] == 9
+    np.testing.assert_allclose(w, seen["w"].numpy(), rtol=1e-4, atol=1e-6)
+    assert np.array_equal(nbr_list[0].cpu().numpy().astype(np.int64), seen["table"].numpy())
+    # mean position per level-0 vertex of the last frame (models.py:450-455: scatter_mean of the repeated positions)
+    pos = seq[-1][0]
+    from oracle import permuto as P
+    rem0, rank, _ = P.simplex(P.elevate(pos, P.scale_factors([0.6] * 3)))
+    rows = oracle.levels[0].table.lookup(P.simplex_keys(rem0, rank).reshape(-1, 3))
+    v0 = oracle.levels[0].table.nr_vertices
+    s = np.zeros((v0, 3), np.float64)
+    np.add.at(s, rows, np.repeat(pos, 4, axis=0).astype(np.float64))
+    c = np.maximum(np.bincount(rows, minlength=v0), 1)[:, None]
+    avg = avg_list[0].cpu().numpy()
+    assert avg.shape == (v0, 3)
+    np.testing.assert_allclose(avg, (s / c).astype(np.float32), rtol=1e-4, atol=1e-4)

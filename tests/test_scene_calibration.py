@@ -37,3 +37,24 @@ def test_scene_is_kitti_shaped():
     assert 3.5 < p10 < 6 and 6 < p50 < 13 and 20 < p90 < 40, (p10, p50, p90)
     assert -4.5 < pos[:, 1].min() and pos[:, 1].max() < 4.0          # +y is up (kitti:166); the beams end at +2 deg
     assert 0.0 <= val.min() and val.max() < 1.0
+
+
+def test_suggested_capacity_holds_the_lattice():
+    """configs.suggest_capacity (capacity from N and sigma instead of the hand-set cfg:71 knob) against the oracle's
+    vertex counts: single frames, 4- and 8-frame sequences, the accumulated 8 x 120k cloud of BASELINE config 5, fine
+    and coarse lattices — never too small, never absurdly large for the headline"""
+    from temporal_latticenet_amd.configs import suggest_capacity
+    seq = make_sequence(120000, 8, seed=77)
+    acc = np.concatenate([p for p, _ in seq])
+    for sigma in (1.0, 0.6, 0.3):
+        v1 = _vertices(seq[0][0], sigma)
+        v4 = _vertices(np.concatenate([p for p, _ in seq[:4]]), sigma)
+        v8 = _vertices(acc, sigma)
+        assert v1 <= suggest_capacity(120000, sigma, 1) <= 8 * v1, (sigma, v1)
+        assert v4 <= suggest_capacity(120000, sigma, 4), (sigma, v4)
+        assert v8 <= suggest_capacity(120000, sigma, 8), (sigma, v8)
+        assert v8 <= suggest_capacity(960000, sigma, 1), (sigma, v8)            # accumulate_clouds: one 960k cloud
+    small = make_sequence(20000, 1, seed=5)[0][0]
+    assert _vertices(small, 1.0) <= suggest_capacity(20000, 1.0)
+    assert _vertices(acc, 0.07) <= suggest_capacity(960000, 0.07) <= 4 * 960000  # ~1M vertices: the hard bound rules
+    assert suggest_capacity(120000, 0.6, 4) <= 200000                            # the headline: same order as cfg:71
