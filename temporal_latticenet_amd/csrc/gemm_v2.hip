@@ -78,34 +78,45 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gather_gemm_v2(const GemmArgs 
   const float* zero = g_v2_zero;
 
   // issue the LDS-DMAs of chunk t into stage st: every thread PIECES x 16 bytes, lane-linear pieces of 1 KiB per wave
-  auto issue = [&](int t, int st) {
+  auto issue = [&](int t_raw, int st) {
+    // past the last chunk the DMAs repeat the last one into a stage nobody reads any more: no branch in the loop body
+    const int t = t_raw < nchunks ? t_raw : nchunks - 1;
     const int tap = t / cpt;
     const int c0 = (t - tap * cpt) << 5;
     const int kbase = tap * s.cin + c0;
     char* As = ring + st * STAGE;
     char* Bs = As + A_BYTES;
+    int idx[A_PIECES];
+#pragma unroll
+    for (int p = 0; p < A_PIECES; ++p) idx[p] = Is[((p * NT + tid) >> 3) * taps + tap];
 #pragma unroll
     for (int p = 0; p < A_PIECES; ++p) {
       const int e = p * NT + tid;
       const int r = e >> 3, q = e & 7;
-      const int idx = Is[r * taps + tap];
-      const float* src = idx >= 0 ? s.src + (int64_t)idx * s.ld + c0 + 4 * (q ^ ((r >> 1) & 7)) : zero;
+      // both addresses are computed, one is selected: a branch around the multiply would split the loop body
+      const int ic = idx[p] > 0 ? idx[p] : 0;
+      const float* data = s.src + (int64_t)ic * s.ld + c0 + 4 * (q ^ ((r >> 1) & 7));
+      const float* src = idx[p] >= 0 ? data : zero;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(As + (p * NT + wv * 64) * 16), 16, 0, 0);
     }
 #pragma unroll
     for (int p = 0; p < B_PIECES; ++p) {
       const int e = p * NT + tid;
-      const float* src;
+      const float* data;
+      bool ok;
       if (!W_NK) {
         const int k = e / (BN / 4), nq = e - k * (BN / 4);
         const int n = n0 + 4 * nq;
-        src = n < g.N ? g.W + (int64_t)(kbase + k) * g.ldw + n : zero;
+        ok = n < g.N;
+        data = g.W + (int64_t)(kbase + k) * g.ldw + (ok ? n : 0);
       } else {
         const int r = e >> 3, q = e & 7;
         const int n = n0 + r;
-        src = n < g.N ? g.W + (int64_t)n * g.ldw + kbase + 4 * (q ^ ((r >> 1) & 7)) : zero;
+        ok = n < g.N;
+        data = g.W + (int64_t)(ok ? n : 0) * g.ldw + kbase + 4 * (q ^ ((r >> 1) & 7));
       }
+      const float* src = ok ? data : zero;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(Bs + (p * NT + wv * 64) * 16), 16, 0, 0);
     }
@@ -177,13 +188,12 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gather_gemm_v2(const GemmArgs 
 
   // ---- main loop: ring of three stages, DMAs two chunks ahead, one barrier per chunk
   issue(0, 0);
-  if (nchunks > 1) issue(1, 1);
+  issue(1, 1);
   int st = 0;
   for (int t = 0; t < nchunks; ++t) {
     // this thread's DMAs of chunk t have landed (those of chunk t+1 may still fly); after the barrier everybody's
     // have, and everybody has finished reading the stage that chunk t+2 is about to overwrite
-    if (t + 1 < nchunks) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PIECES) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PIECES) : "memory");
     const int tap = t / cpt;
     const int c0 = (t - tap * cpt) << 5;
     const char* As = ring + st * STAGE;
@@ -195,14 +205,25 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gather_gemm_v2(const GemmArgs 
     frag_load(0, As, Bs, f0);
     frag_load(1, As, Bs, f1);
     frag_mma(0, c0, live, f0);
-    if (t + 2 < nchunks) issue(t + 2, st == 0 ? 2 : st - 1);
+    issue(t + 2, st == 0 ? 2 : st - 1);
     frag_load(2, As, Bs, f0);
     frag_mma(1, c0, live, f1);
     frag_load(3, As, Bs, f1);
     frag_mma(2, c0, live, f0);
     frag_mma(3, c0, live, f1);
+    // scheduling hint for the whole (branch-free) chunk body: one MFMA, then a little of everything else — an MFMA
+    // occupies the matrix pipe for 16 issue slots, and what a wave issues between two MFMAs is free, what it issues
+    // in a lump between two runs of MFMAs is not (with one wave per SIMD nobody else fills the pipe meanwhile)
+#pragma unroll
+    for (int k = 0; k < 16 * TM * TN; ++k) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+      __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);   // VALU
+      if ((k & 7) == 7) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read (the LDS-DMAs)
+    }
     st = st == V2_STAGES - 1 ? 0 : st + 1;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the repeated DMAs of the last two rounds
 
   // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).  The residual is loaded for a whole
   // 32x32 tile at once from clamped (always valid) addresses: a per-element "load or not" makes the compiler branch

@@ -33,7 +33,9 @@ def main():
     # (tm, tn, groups, direct)
     variants = [("v2", 0, 0, 0, 0), ("v2+gn", 0, 0, 0, 0), ("old heur", 0, 0, 0, 0), ("64x64", 1, 1, 0, -1),
                 ("direct", 0, 0, 0, 1), ("direct+gn", 0, 0, 0, 1)]
-    extra = os.environ.get("TLN_VARIANTS")
+    keep = os.environ.get("TLN_VARIANTS")
+    if keep:
+        variants = [v for v in variants if v[0] in keep.split(",")]
     lib = _lib.lib()
     for lvl, cin, cout, taps, nk in shapes:
         L = levels[lvl]
