@@ -20,6 +20,7 @@
 //   * epilogue as in gemm.hip: bias, residual, ReLU, per-32-row (sum, sum^2) in fp64 for the next GroupNorm.
 // One source only (the two-source products live on small levels); rows past the source read as zeros (pad = 0).
 #include "gemm_args.h"
+#include <stdlib.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -309,6 +310,15 @@ static int launch_v2(GemmArgs& g, hipStream_t s) {
 template <bool W_NK, bool PRO>
 static int dispatch_v2(GemmArgs& g, hipStream_t s) {
   const int n = g.N;
+  // eight waves per block (two per SIMD: one issues MFMAs while the other waits for LDS or the barrier) measured 3-8 %
+  // faster than four waves of twice the tile on every shape of the workload (TLN_V2_WAVES=4 brings those back)
+  static const int waves = getenv("TLN_V2_WAVES") ? atoi(getenv("TLN_V2_WAVES")) : 8;
+  if (waves == 8) {
+    if (n % 192 == 0) return launch_v2<4, 2, 1, 3, W_NK, PRO>(g, s);   // 128 x 192, 8 waves of 32 x 96
+    if (n % 128 == 0) return launch_v2<4, 2, 1, 2, W_NK, PRO>(g, s);   // 128 x 128, 8 waves of 32 x 64
+    if (n == 64 && !PRO) return launch_v2<4, 2, 1, 1, W_NK, PRO>(g, s);   // 128 x 64, 8 waves of 32 x 32 (with the GroupNorm
+                                                                          // prologue both column waves would repeat it)
+  }
   if (n % 192 == 0) return launch_v2<2, 2, 2, 3, W_NK, PRO>(g, s);   // 128 x 192, waves 64 x 96
   if (n % 128 == 0) return launch_v2<2, 2, 2, 2, W_NK, PRO>(g, s);   // 128 x 128, waves 64 x 64
   if (n == 96) return launch_v2<4, 1, 1, 3, W_NK, PRO>(g, s);        // 128 x 96, waves 32 x 96
