@@ -598,11 +598,22 @@ __global__ void __launch_bounds__(256) k_distribute_insert(const float* __restri
     const int lane = threadIdx.x & 63;
     int leader = lane;
     unsigned long long group = 1ull << lane;
-    unsigned long long todo = __ballot(valid);
-    while (todo) {                                        // one round per distinct key, no memory traffic
+    // Which lanes MAY share their key: the lanes that agree on 12 hash bits (12 ballots).  With shuffled points (the
+    // training loader, cfg shuffle_points) the 64 rows of a wave almost never collide and the exact grouping below has
+    // nothing to do; with points in scan order (valid / test) neighbouring rows share most of their vertices.
+    const uint32_t hbits = (uint32_t)(tln_mix64(K) >> 40);
+    unsigned long long peers = __ballot(valid);
+#pragma unroll
+    for (int bit = 0; bit < 12; ++bit) {
+      const bool one = (hbits >> bit) & 1u;
+      const unsigned long long m = __ballot(one);
+      peers &= one ? m : ~m;
+    }
+    unsigned long long todo = __ballot(valid && __popcll(peers) > 1);
+    while (todo) {                                        // one round per distinct key among the candidates
       const int first = __builtin_ctzll(todo);
       const uint64_t kf = __shfl(K, first, 64);
-      const unsigned long long same = __ballot(valid && K == kf);
+      const unsigned long long same = __ballot(valid && K == kf);   // equal keys agree on the hash bits: all in `todo`
       if (valid && K == kf) {
         leader = first;
         group = same;
@@ -1491,7 +1502,7 @@ extern "C" int tln_distribute_begin(tln_lattice_t* l, const float* d_positions, 
                      d_positions, d_values, val_dim, d_weights, l->slot_cnt, l->vstart, d_indices, l->bin_xyzv, l->bin_w,
                      l->bin_row, l->bin_vtx);
   if (subtract_mean)
-    hipLaunchKernelGGL(k_bins_mean, dim3(2048), dim3(256), 0, s, l->d_ctr, l->vcnt, l->vstart, l->bin_xyzv, l->mean);
+    hipLaunchKernelGGL(k_bins_mean, dim3(8192), dim3(256), 0, s, l->d_ctr, l->vcnt, l->vstart, l->bin_xyzv, l->mean);
   TLN_LAUNCH_CHECK();
   l->dist_pending = true;
   l->dist_pos = d_positions;
