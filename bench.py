@@ -239,6 +239,7 @@ def main():
         #     K2 (PointNet pool) and K8 (slice kernels) of every frame (tln_program_timing), algorithmic bytes of
         #     K1 128 N, K2 96 N + 512 V0, K8 768 V0 + 148 N (26 classes, C = 192).
         roof, scatter = None, None
+        default_workload = (args.points, args.frames, args.sigma, args.rnn) == (120000, 4, 0.6, "gru,gru,aflow,gru")
         if rank == 0:
             reps = 5
             tot_ms, tot_n, tot_fl, tot_by = 0.0, 0, 0.0, 0.0
@@ -286,7 +287,6 @@ def main():
                 # HBM-side traffic per launch cannot be read from inside the process: it comes from the two rocprofv3
                 # --pmc passes of this same workload (FETCH_SIZE, WRITE_SIZE) summarised by tools/pmc_summary.py
                 pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-                default_workload = (args.points, args.frames, args.sigma, args.rnn) == (120000, 4, 0.6, "gru,gru,aflow,gru")
                 if os.path.exists(pmc) and default_workload:
                     with open(pmc) as f:
                         tr = json.load(f)
@@ -302,6 +302,13 @@ def main():
                         stages[nm] = {"algorithmic_bytes": round(st_by[k] / st_n[k]), "us": round(st_ms[k] * 1e3 / st_n[k], 2),
                                       "GBps": round(gbps, 1), "frac": round(gbps / HBM_PEAK_GBPS, 4), "frames": st_n[k]}
                 # "splat -> conv -> slice" scatter + gather fraction of one (last) frame: K1 + K2 + K8 bytes over their time
+                pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+                if os.path.exists(pmc) and default_workload:
+                    with open(pmc) as f:
+                        per_frame_traffic = json.load(f).get("scatter_hbm_bytes_per_frame", {})
+                    for nm, v in per_frame_traffic.items():
+                        if nm in stages:
+                            stages[nm]["traffic"] = round(v)
                 tot_b = sum(st_by[k] / st_n[k] for k in range(3) if st_n[k])
                 tot_t = sum(st_ms[k] / st_n[k] for k in range(3) if st_n[k]) * 1e-3
                 scatter = {"bound": "hbm", "achieved": round(tot_b / tot_t / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -869,11 +869,22 @@ struct SplitKWs {
   size_t counter_ints = 0;
 };
 static std::mutex g_ws_mutex;
-static std::unordered_map<hipStream_t, SplitKWs> g_ws;
+// keyed by (device, stream): the null stream of two devices is the same handle value, its slab is not
+struct WsKey {
+  int dev;
+  hipStream_t s;
+  bool operator==(const WsKey& o) const { return dev == o.dev && s == o.s; }
+};
+struct WsKeyHash {
+  size_t operator()(const WsKey& k) const { return std::hash<const void*>()(k.s) * 31u + (size_t)k.dev; }
+};
+static std::unordered_map<WsKey, SplitKWs, WsKeyHash> g_ws;
 
 static int ensure_splitk_ws(size_t slab_floats, size_t counters, hipStream_t s, SplitKWs* out) {
   std::lock_guard<std::mutex> lock(g_ws_mutex);
-  SplitKWs& w = g_ws[s];
+  int dev = 0;
+  TLN_HIP(hipGetDevice(&dev));
+  SplitKWs& w = g_ws[WsKey{dev, s}];
   if (slab_floats > w.slab_floats) {
     TLN_HIP(hipStreamSynchronize(s));
     if (w.slab) (void)hipFree(w.slab);
@@ -913,13 +924,8 @@ static int launch_gemm(GemmArgs& g, int splits, hipStream_t s) {
   const int ntab = (g.nsrc > 1 && g.s[1].table != nullptr) ? 2 : 1;
   const size_t lds = (size_t)(REGION + ntab * BM * TLN_TAPS + 4 + gn_floats) * sizeof(float);
   auto kern = k_gather_gemm<WM, TM, TN, BK, G, W_NK, VEC>;
-  if (lds > 48 * 1024) {
-    static size_t attr_bytes = 0;  // per instantiation
-    if (lds > attr_bytes) {
-      TLN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      attr_bytes = lds;
-    }
-  }
+  if (lds > 48 * 1024)   // the attribute is per device: set whenever it is needed (a host-side table write)
+    TLN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   dim3 grid((unsigned)tln_cdiv(g.M, BM), (unsigned)tln_cdiv(g.N, BN), (unsigned)splits);
   g.splits = splits;
   if (splits > 1) {
@@ -973,14 +979,9 @@ static int launch_direct(GemmArgs& g, int nchunks, int groups, hipStream_t s) {
   const int T = 64 * G;
   const size_t lds = direct_lds_bytes(g, G);
   TLN_REQUIRE(lds <= 96 * 1024, "direct gemm: LDS %zu B", lds);
-  if (lds > 48 * 1024) {
-    static size_t attr_bytes = 0;  // per instantiation
-    if (lds > attr_bytes) {
-      TLN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gather_gemm_direct<W_NK>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-      attr_bytes = 96 * 1024;
-    }
-  }
+  if (lds > 48 * 1024)
+    TLN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gather_gemm_direct<W_NK>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
   dim3 grid((unsigned)tln_cdiv(g.M, 32), (unsigned)tln_cdiv(g.N, 32), 1);
   g.splits = 1;
   hipLaunchKernelGGL(k_gather_gemm_direct<W_NK>, grid, dim3(T), lds, s, g);
@@ -1208,14 +1209,9 @@ template <bool W_NK, int NP>
 static int launch_multi(const Prep* q, int n, int G, size_t lds, int64_t mt, hipStream_t s) {
   GemmArgsN<NP> gg;
   for (int i = 0; i < NP; ++i) gg.a[i] = q[i < n ? i : 0].g;
-  if (lds > 48 * 1024) {
-    static bool attr = false;  // per instantiation
-    if (!attr) {
-      TLN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gather_gemm_direct_multi<W_NK, NP>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-      attr = true;
-    }
-  }
+  if (lds > 48 * 1024)
+    TLN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gather_gemm_direct_multi<W_NK, NP>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
   dim3 grid((unsigned)mt, (unsigned)tln_cdiv(q[0].g.N, 32), (unsigned)n);
   hipLaunchKernelGGL((k_gather_gemm_direct_multi<W_NK, NP>), grid, dim3(64 * G), lds, s, gg);
   return TLN_OK;
