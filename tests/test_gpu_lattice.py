@@ -197,3 +197,31 @@ def test_coarse_levels_and_tables_fuzz(gpu, n, spread, sigma):
             assert np.array_equal(g[l].coarse_to_fine_table().cpu().numpy(), want), (t, l)
             want = tabs[l].lookup(P.neighbour_keys(P.finefy_centres(tabs[l - 1].keys)))
             assert np.array_equal(g[l].fine_to_coarse_table(tabs[l - 1].nr_vertices).cpu().numpy(), want), (t, l)
+
+
+def test_scan_ordered_cloud_and_the_bins(gpu):
+    """Points in SCAN order (valid / test clouds are not shuffled, kitti_dataloader.py:172): neighbouring rows share their
+    vertices, so the wave-level key groups of k_distribute_insert are large (one probe and one row-count atomic per
+    group).  Indices and weights bit-exact; the vertex bins hold every row exactly once, grouped by vertex; the pool on
+    them equals the oracle bit for bit."""
+    from temporal_latticenet_amd import ops
+    from temporal_latticenet_amd.lattice import Lattice
+    seq = make_sequence(60000, 2, seed=91)
+    lat = Lattice.from_params([0.8] * 3, 12000)                       # the second frame overflows the capacity
+    tab = P.VertexTable(3, 12000)
+    g = torch.Generator().manual_seed(2)
+    Ws = [torch.randn(16, 4, generator=g) * 0.5, torch.randn(32, 16, generator=g) * 0.3, torch.randn(64, 32, generator=g) * 0.3]
+    Bs = [torch.randn(16, generator=g) * 0.1, torch.randn(32, generator=g) * 0.1, torch.randn(64, generator=g) * 0.1]
+    for t, (pos, val) in enumerate(seq):
+        order = np.lexsort((pos[:, 2], pos[:, 1], np.round(np.arctan2(pos[:, 2], pos[:, 0]), 2)))   # by azimuth, then height
+        pos, val = np.ascontiguousarray(pos[order]), np.ascontiguousarray(val[order])
+        d, i, w = lat.distribute(torch.from_numpy(pos).to(gpu), torch.from_numpy(val).to(gpu), reset_hashmap=(t == 0))
+        od, oi, ow = O.distribute(tab, pos, val, [0.8] * 3)
+        assert lat.nr_lattice_vertices() == tab.nr_vertices
+        assert np.array_equal(i.cpu().numpy(), oi) and np.array_equal(w.cpu().numpy(), ow)
+        assert np.array_equal(d.cpu().numpy(), od), "fixed-point means: the distributed rows are bit-exact too"
+        assert lat.overflow_rows() == int((oi < 0).sum())
+        out = ops.pointnet_pool(lat, d, i, [x.to(gpu) for x in Ws], [x.to(gpu) for x in Bs], 4)
+        want = O.pointnet_pool(od, oi, tab.nr_vertices, Ws, Bs, 4)
+        assert np.array_equal(out.cpu().numpy(), want.numpy())
+    assert (oi < 0).sum() > 0, "the fixture is meant to overflow on the second frame"
