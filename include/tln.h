@@ -393,6 +393,21 @@ int tln_program_timing(tln_program_t* p, int enable);
 int tln_program_timing_read(tln_program_t* p, float* ms_out /* [3] */);
 int tln_program_replay_gemms(tln_program_t* p, int reps, double* ms_total, int64_t* launches, double* flops,
                              double* bytes, void* stream);
+/* The frame in segments, for the frame-sharded multi-GPU path (temporal_latticenet_amd/dist.py): the rank that owns
+ * frame t receives every fusion module's hidden state from the rank of frame t-1 right before the first op that reads
+ * it and sends the new one on right after the last op that writes it.  Per frame: tln_program_begin_frame, every state
+ * the frame will read announced with its row count (tln_program_state_expect: the sizing walk must see them; the row
+ * count of a state is the vertex count of its level before this frame), tln_program_run_begin, then alternately
+ * tln_program_run_until(first_read_op) + tln_program_state_set and tln_program_run_until(last_write_op + 1) +
+ * tln_program_state_get_new, finally tln_program_run_end.  Same kernels in the same order as tln_program_run. */
+int tln_program_nr_ops(const tln_program_t* p);
+int tln_program_state_ops(const tln_program_t* p, int id, int* first_read_op, int* last_write_op, int* level);
+int tln_program_state_expect(tln_program_t* p, int id, int64_t rows, void* stream);
+int tln_program_run_begin(tln_program_t* p, int early, float* d_out, int64_t out_rows, int out_cols, void* stream);
+int tln_program_run_until(tln_program_t* p, int op_end, void* stream);
+int tln_program_run_end(tln_program_t* p, void* stream);
+int tln_program_state_new_info(const tln_program_t* p, int id, int64_t* rows, int* cols, int* written);
+int tln_program_state_get_new(tln_program_t* p, int id, float* d_out, void* stream);
 /* Pair mode: two programs compiled from the same model (same weights), each with its own open frame
  * (tln_program_begin_frame on its own lattice), stepped in lock-step on ONE stream: every op runs per program, except
  * that the gather-GEMM ops of the two are issued pairwise through tln_gather_gemm_pair.  Results per program as from

@@ -138,6 +138,14 @@ _PROTOS = {
     "tln_program_state_info": (_i, [_vp, _i, C.POINTER(_i64), C.POINTER(_i), C.POINTER(_i)]),
     "tln_program_state_get": (_i, [_vp, _i, _vp, _vp]),
     "tln_program_state_set": (_i, [_vp, _i, _vp, _i64, _vp]),
+    "tln_program_nr_ops": (_i, [_vp]),
+    "tln_program_state_ops": (_i, [_vp, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "tln_program_state_expect": (_i, [_vp, _i, _i64, _vp]),
+    "tln_program_run_begin": (_i, [_vp, _i, _vp, _i64, _i, _vp]),
+    "tln_program_run_until": (_i, [_vp, _i, _vp]),
+    "tln_program_run_end": (_i, [_vp, _vp]),
+    "tln_program_state_new_info": (_i, [_vp, _i, C.POINTER(_i64), C.POINTER(_i), C.POINTER(_i)]),
+    "tln_program_state_get_new": (_i, [_vp, _i, _vp, _vp]),
 }
 
 _lib = None

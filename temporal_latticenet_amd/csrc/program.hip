@@ -163,6 +163,12 @@ struct tln_program {
   bool defer = false, has_pending = false;
   GemmCall pending{};
   int w_next = 0;  // where the next walk continues
+  // segmented run (tln_program_run_begin / _until / _end: frame-sharded multi-GPU, dist.py)
+  int state_level[TLN_MAX_STATES] = {0};
+  bool seg_open = false, seg_levels_done = false;
+  int seg_cursor = 0, seg_early = 0, seg_out_cols = 0;
+  float* seg_out = nullptr;
+  int64_t seg_out_rows = 0;
 };
 
 namespace {
@@ -617,7 +623,7 @@ extern "C" int tln_program_create(tln_program_t** out, const tln_slot* slots, in
   // ops [0, split) touch level 0 only (slots, hidden states and tables): they can be launched before the coarse levels'
   // vertex counts are known on the host
   {
-    int state_level[TLN_MAX_STATES];
+    int* state_level = p->state_level;
     for (int st = 0; st < TLN_MAX_STATES; ++st) state_level[st] = 0;
     for (const tln_slot& sl : p->slots)
       if (sl.kind == TLN_SLOT_STATE_NEW && sl.rows >= 0) state_level[sl.state] = sl.rows;
@@ -773,6 +779,144 @@ extern "C" int tln_program_run(tln_program_t* p, int early, float* d_out, int64_
   if (rc == TLN_OK) commit_states(p);
   p->frame_open = false;
   return rc;
+}
+
+// ---- the frame in segments (frame-sharded multi-GPU: a hidden state arrives from the rank that owns the previous
+// frame right before the first op that reads it, and leaves for the next rank right after the last op that writes it;
+// temporal_latticenet_amd/dist.py).  Same walk as tln_program_run, cut at caller-chosen op indices.
+extern "C" int tln_program_nr_ops(const tln_program_t* p) { return p ? (int)p->ops.size() : -1; }
+
+// op range of hidden state `id`: first op that reads the stored state, last op that writes the new one (-1: none),
+// and the lattice level the state lives on
+extern "C" int tln_program_state_ops(const tln_program_t* p, int id, int* first_read_op, int* last_write_op, int* level) {
+  TLN_REQUIRE(p && id >= 0 && id < p->n_states, "bad state id");
+  int fr = -1, lw = -1;
+  for (int oi = 0; oi < (int)p->ops.size(); ++oi) {
+    const tln_op& o = p->ops[oi];
+    bool reads = o.cond_state == id;     // an op conditional on the state is decided when the walk reaches it
+    for_inputs(o, [&](int sid) {
+      const tln_slot& sl = p->slots[sid];
+      if (sl.kind == TLN_SLOT_STATE_PREV && sl.state == id) reads = true;
+      if (sl.rows <= TLN_ROWS_STATE && TLN_ROWS_STATE - sl.rows == id) reads = true;
+    });
+    bool writes = false;
+    for_outputs(o, [&](int sid) {
+      const tln_slot& sl = p->slots[sid];
+      if (sl.kind == TLN_SLOT_STATE_NEW && sl.state == id) writes = true;
+      if (sl.rows <= TLN_ROWS_STATE && TLN_ROWS_STATE - sl.rows == id) reads = true;
+    });
+    if (o.kind == TLN_OP_CGA_GATE && o.i[0] == id) reads = true;
+    if (reads && fr < 0) fr = oi;
+    if (writes) lw = oi;
+  }
+  if (first_read_op) *first_read_op = fr;
+  if (last_write_op) *last_write_op = lw;
+  if (level) *level = p->state_level[id];
+  return TLN_OK;
+}
+
+// announces a stored hidden state of `rows` rows whose contents follow later (tln_program_state_set with the same row
+// count): the sizing walk of tln_program_run_begin must see every state the frame will read
+extern "C" int tln_program_state_expect(tln_program_t* p, int id, int64_t rows, void* stream_) {
+  TLN_REQUIRE(p && id >= 0 && id < p->n_states && rows >= 0, "bad state id");
+  int cols = p->state_cols[id];
+  if (cols == 0)
+    for (const tln_slot& s : p->slots)
+      if (s.kind == TLN_SLOT_STATE_NEW && s.state == id) cols = s.cols;
+  TLN_REQUIRE(cols > 0, "hidden state %d has no width", id);
+  DevBuf& b = p->state_buf[id][p->state_cur[id]];
+  const size_t bytes = (size_t)rows * cols * sizeof(float);
+  int rc = ensure_buf(b, bytes ? bytes : kAlign, (hipStream_t)stream_);
+  if (rc) return rc;
+  p->state_rows[id] = rows;
+  p->state_cols[id] = cols;
+  p->state_has[id] = true;
+  return TLN_OK;
+}
+
+static int seg_walk_to(tln_program* p, int op_end, hipStream_t s) {
+  const int n_ops = (int)p->ops.size();
+  if (op_end > n_ops) op_end = n_ops;
+  int rc = TLN_OK;
+  if (p->seg_cursor < p->split && op_end > p->seg_cursor) {
+    const int e = op_end < p->split ? op_end : p->split;
+    rc = walk(p, false, p->seg_early, p->seg_out, p->seg_out_rows, p->seg_out_cols, s, p->seg_cursor, e, false);
+    if (rc) return rc;
+    p->seg_cursor = e;
+  }
+  if (op_end > p->split && !p->seg_levels_done) {
+    rc = tln_lattice_prepare_levels_finish(p->lat, s);
+    if (rc) return rc;
+    for (int i = 1; i <= p->n_coarse; ++i) {
+      p->V[i] = tln_lattice_nr_vertices(p->levels[i]);
+      TLN_REQUIRE(p->V[i] <= p->Vb[i], "level %d has %lld vertices, more than the bound %lld", i, (long long)p->V[i],
+                  (long long)p->Vb[i]);
+    }
+    p->exact_known = true;
+    p->seg_levels_done = true;
+  }
+  if (op_end > p->seg_cursor && !p->w_finished) {
+    rc = walk(p, false, p->seg_early, p->seg_out, p->seg_out_rows, p->seg_out_cols, s, p->seg_cursor, op_end, false);
+    if (rc) return rc;
+  }
+  if (op_end > p->seg_cursor) p->seg_cursor = op_end;
+  return TLN_OK;
+}
+
+extern "C" int tln_program_run_begin(tln_program_t* p, int early, float* d_out, int64_t out_rows, int out_cols,
+                                     void* stream_) {
+  TLN_REQUIRE(p && p->frame_open && !p->seg_open, "tln_program_run_begin without an open frame");
+  hipStream_t s = (hipStream_t)stream_;
+  const int n_ops = (int)p->ops.size();
+  int rc = walk(p, true, early, nullptr, out_rows, out_cols, s, 0, n_ops, true);   // sizing (resets the walk state)
+  if (rc) return rc;
+  rc = ensure_buf(p->arena, p->alloc.high + kAlign, s);
+  if (rc) return rc;
+  p->calls.clear();
+  // the launching walk starts from a fresh allocator too: an empty range with fresh = true
+  rc = walk(p, false, early, d_out, out_rows, out_cols, s, 0, 0, true);
+  if (rc) return rc;
+  p->seg_open = true;
+  p->seg_levels_done = p->n_coarse == 0;
+  p->seg_cursor = 0;
+  p->seg_early = early;
+  p->seg_out = d_out;
+  p->seg_out_rows = out_rows;
+  p->seg_out_cols = out_cols;
+  return TLN_OK;
+}
+
+extern "C" int tln_program_run_until(tln_program_t* p, int op_end, void* stream_) {
+  TLN_REQUIRE(p && p->seg_open && op_end >= 0, "tln_program_run_until without tln_program_run_begin");
+  return seg_walk_to(p, op_end, (hipStream_t)stream_);
+}
+
+extern "C" int tln_program_run_end(tln_program_t* p, void* stream_) {
+  TLN_REQUIRE(p && p->seg_open, "tln_program_run_end without tln_program_run_begin");
+  int rc = seg_walk_to(p, (int)p->ops.size(), (hipStream_t)stream_);
+  if (rc == TLN_OK) commit_states(p);
+  p->seg_open = false;
+  p->frame_open = false;
+  return rc;
+}
+
+// the hidden state this frame has written so far (before the frame ends and it becomes the stored one)
+extern "C" int tln_program_state_new_info(const tln_program_t* p, int id, int64_t* rows, int* cols, int* written) {
+  TLN_REQUIRE(p && id >= 0 && id < p->n_states, "bad state id");
+  if (rows) *rows = p->w_wrote[id] ? p->w_new_rows[id] : 0;
+  if (cols) *cols = p->state_cols[id];
+  if (written) *written = p->w_wrote[id] ? 1 : 0;
+  return TLN_OK;
+}
+
+extern "C" int tln_program_state_get_new(tln_program_t* p, int id, float* d_out, void* stream_) {
+  TLN_REQUIRE(p && id >= 0 && id < p->n_states && d_out, "bad state id");
+  TLN_REQUIRE(p->w_wrote[id], "hidden state %d has not been written by this frame yet", id);
+  const size_t bytes = (size_t)p->w_new_rows[id] * p->state_cols[id] * sizeof(float);
+  if (bytes)
+    TLN_HIP(hipMemcpyAsync(d_out, p->state_buf[id][1 - p->state_cur[id]].p, bytes, hipMemcpyDeviceToDevice,
+                           (hipStream_t)stream_));
+  return TLN_OK;
 }
 
 // ---- group mode: 2..8 sequences stepped in lock-step on one stream, their gather-GEMM ops sharing launches --------
@@ -1025,6 +1169,9 @@ extern "C" int tln_program_state_set(tln_program_t* p, int id, const float* d_in
       if (s.kind == TLN_SLOT_STATE_NEW && s.state == id) cols = s.cols;
   TLN_REQUIRE(cols > 0, "hidden state %d has no width", id);
   hipStream_t s = (hipStream_t)stream_;
+  TLN_REQUIRE(!p->seg_open || (p->state_has[id] && p->state_rows[id] == rows),
+              "hidden state %d arrives with %lld rows inside a segmented run that was sized for %lld", id, (long long)rows,
+              (long long)p->state_rows[id]);
   const size_t bytes = (size_t)rows * cols * sizeof(float);
   DevBuf& b = p->state_buf[id][p->state_cur[id]];
   int rc = ensure_buf(b, bytes ? bytes : kAlign, s);

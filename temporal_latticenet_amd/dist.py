@@ -136,26 +136,35 @@ class FrameShardRunner:
     `via_host=True` stages tensors through host memory (gloo); otherwise tensors go GPU-to-GPU (RCCL over xGMI).
     """
 
-    def __init__(self, model, make_lattice, plan, group=None, via_host=False):
+    def __init__(self, model, make_lattice, plan, group=None, via_host=False, use_program=True):
         self.model, self.make_lattice, self.plan = model, make_lattice, plan
         self.group, self.via_host = group, via_host
+        # use_program: drive the native frame program in segments (engine.FrameProgram.run_frame_sharded: the hidden
+        # states enter and leave between ops); else, or when the model has no program (training mode, an unsupported
+        # configuration), the operator-level route with the hand-off on forward hooks
+        self.use_program = use_program
         self.scratch = make_lattice()
         self.lattice = make_lattice()
         self._recv_now = False
         self._send_now = False
         self._slots = []
-        # the hidden-state hand-off hangs on the fusion modules' forward hooks: stay on the operator-level route until
-        # close() (the frame program has no send / receive ops yet)
         self._was_program = getattr(model, "use_frame_program", True)
-        model.use_frame_program = False
         self._hooks = []
-        self._install_hooks()
+        self._hooked = False
+
+    def _hook_route(self):
+        """the operator-level route: hand-off on the fusion modules' forward hooks (until close())"""
+        if not self._hooked:
+            self.model.use_frame_program = False
+            self._install_hooks()
+            self._hooked = True
 
     def close(self):
         """removes the hand-off hooks and gives the model its frame program back"""
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        self._hooked = False
         self.model.use_frame_program = self._was_program
 
     def __enter__(self):
@@ -235,13 +244,57 @@ class FrameShardRunner:
             k = all_keys[f]
             if k.shape[0]:
                 lat.insert_keys(k.to("cuda") if k.device.type != "cuda" else k)
+        prog = None
+        if self.use_program and not self._hooked:
+            model.first_sequence = True
+            model.use_frame_program = True
+            prog = model._program_for_this_frame(False)      # compiles / validates the program and resets its states
+            if prog is None:
+                self._hook_route()
+        else:
+            self._hook_route()
         out = None
         for j, f in enumerate(self.plan.frames):
             pos, val = frames[f]
+            recv_now = (j == 0 and f > 0)
+            send_now = (j == len(self.plan.frames) - 1 and f < self.plan.nr_frames - 1)
+            early = f != self.plan.nr_frames - 1
+            if prog is not None:
+                out = self._program_frame(prog, lat, pos, val, f, early, recv_now, send_now)
+                lat = out[2]
+                continue
             if f > 0:
                 model.first_sequence = False          # the lattice already holds the earlier frames (models.py:287-289)
-            self._recv_now = (j == 0 and f > 0)
-            self._send_now = (j == len(self.plan.frames) - 1 and f < self.plan.nr_frames - 1)
-            out = model(lat, pos, val, f != self.plan.nr_frames - 1, False)
+            self._recv_now, self._send_now = recv_now, send_now
+            out = model(lat, pos, val, early, False)
             self._recv_now = self._send_now = False
         return out
+
+    def _program_frame(self, prog, lat, pos, val, f, early, recv_now, send_now):
+        """one owned frame through the native frame program, the hidden states entering / leaving between its ops"""
+        model = self.model
+        expect = None
+        if recv_now:
+            # rows of the arriving states = vertex counts of their levels before this frame (prefix-stable numbering:
+            # the keys of the earlier frames are already in, the coarse levels follow from them)
+            expect = [lat.nr_lattice_vertices()]
+            lvl = lat
+            for _ in range(model.nr_downsamples):
+                lvl = lvl.coarsen()
+                expect.append(lvl.nr_lattice_vertices())
+
+        def recv(sid):
+            dev = "cpu" if self.via_host else "cuda"
+            h = recv_tensor(self.plan.prev_rank, dev, tag=sid, group=self.group)
+            return h.to("cuda") if h.numel() else None
+
+        def send(sid, t):
+            send_tensor(t.cpu() if self.via_host else t, self.plan.next_rank, tag=sid, group=self.group)
+
+        raw, lat = prog.run_frame_sharded(lat, pos, val, f == 0, early, recv if recv_now else None,
+                                          send if send_now else None, expect)
+        model.first_sequence = False
+        model._program_active = True
+        if early and prog.stop_shape is not None:
+            return raw, raw, lat
+        return model.logsoftmax(raw), raw, lat

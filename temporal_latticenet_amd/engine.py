@@ -480,6 +480,71 @@ class FrameProgram:
                                                        C.byref(by), stream_ptr()), "tln_program_replay_gemms")
         return ms.value, n.value, fl.value, by.value
 
+    # ---- the frame in segments (frame-sharded multi-GPU, dist.FrameShardRunner) -----------------------------------
+    def state_ops(self, sid):
+        """(first op that reads stored state `sid`, last op that writes the new one, lattice level of the state)"""
+        fr, lw, lvl = C.c_int(), C.c_int(), C.c_int()
+        _lib.check(_lib.lib().tln_program_state_ops(self._h, sid, C.byref(fr), C.byref(lw), C.byref(lvl)),
+                   "tln_program_state_ops")
+        return fr.value, lw.value, lvl.value
+
+    def run_frame_sharded(self, ls, positions, values, reset_hashmap, early_return, recv_state=None, send_state=None,
+                          expect_rows=None):
+        """One frame like run_frame, but cut at the fusion slots: `recv_state(sid) -> tensor [rows, C]` is called right
+        before the first op that reads hidden state `sid` (the rank of the previous frame sends it),
+        `send_state(sid, tensor)` right after the last op that writes the new one.  `expect_rows[level]` = vertex count
+        of every level BEFORE this frame (= the row counts of the states that will arrive)."""
+        positions = positions.contiguous().float()
+        n = positions.shape[0]
+        if values is None or values.numel() == 0:
+            values, val_dim = None, 0
+        else:
+            values = values.contiguous().float()
+            val_dim = values.shape[1]
+        lib, s = _lib.lib(), stream_ptr()
+        _lib.check(lib.tln_program_begin_frame(self._h, ls._h, positions.data_ptr(),
+                                               values.data_ptr() if values is not None else None, n, val_dim,
+                                               1 if reset_hashmap else 0, 1 if self.subtract_mean else 0, self._v, s),
+                   "tln_program_begin_frame")
+        ls._csr_key = None
+        ls._bins_key = None
+        ls._last_indices = None
+        plan = sorted((self.state_ops(sid) + (sid,)) for sid in range(self.n_states))     # by first-read op
+        if recv_state is not None:
+            for fr, lw, lvl, sid in plan:
+                if fr >= 0:
+                    _lib.check(lib.tln_program_state_expect(self._h, sid, int(expect_rows[lvl]), s),
+                               "tln_program_state_expect")
+        early = bool(early_return) and self.stop_shape is not None
+        rows_code, cols = self.stop_shape if early else self.out_shape
+        rows = self._rows(rows_code, n)
+        out = torch.empty((rows, cols), dtype=torch.float32, device="cuda")
+        _lib.check(lib.tln_program_run_begin(self._h, 1 if early else 0, out.data_ptr(), rows, cols, s),
+                   "tln_program_run_begin")
+        for fr, lw, lvl, sid in plan:
+            if recv_state is not None and fr >= 0:
+                _lib.check(lib.tln_program_run_until(self._h, fr, s), "tln_program_run_until")
+                h = recv_state(sid)
+                if h is not None and h.numel():
+                    h = h.contiguous().float()
+                    _lib.check(lib.tln_program_state_set(self._h, sid, h.data_ptr(), h.shape[0], s),
+                               "tln_program_state_set")
+                    self._keep_recv = h        # alive until the copy on the stream has been enqueued
+            if send_state is not None and lw >= 0:
+                _lib.check(lib.tln_program_run_until(self._h, lw + 1, s), "tln_program_run_until")
+                r, c, w = C.c_int64(), C.c_int(), C.c_int()
+                _lib.check(lib.tln_program_state_new_info(self._h, sid, C.byref(r), C.byref(c), C.byref(w)),
+                           "tln_program_state_new_info")
+                if w.value:
+                    t = torch.empty((r.value, c.value), dtype=torch.float32, device="cuda")
+                    _lib.check(lib.tln_program_state_get_new(self._h, sid, t.data_ptr(), s), "tln_program_state_get_new")
+                else:
+                    t = torch.zeros((0,), dtype=torch.float32, device="cuda")
+                send_state(sid, t)
+        _lib.check(lib.tln_program_run_end(self._h, s), "tln_program_run_end")
+        ls.set_values(out)
+        return out, ls
+
     def state(self, sid):
         """copy of hidden state `sid` (None if it does not exist yet)"""
         rows, cols, has = C.c_int64(), C.c_int(), C.c_int()

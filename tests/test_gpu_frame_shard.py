@@ -23,7 +23,8 @@ from tests.helpers import randomize_parameters
 
 rank, world = D.init_from_env("gloo")
 torch.cuda.set_device(0)
-T = 2
+T = int(os.environ["TLN_TEST_FRAMES"])
+use_program = os.environ["TLN_TEST_ROUTE"] == "program"
 contents = make_config(frames=T, sigma=0.7)
 seqs_np = [make_sequence(9000, T, seed=50 + s) for s in range(2)]
 seqs = [[(torch.from_numpy(p).cuda(), torch.from_numpy(v).cuda()) for p, v in s] for s in seqs_np]
@@ -48,7 +49,7 @@ def sequential(seq):
 
 want = [sequential(s) for s in seqs]
 plan = D.FrameShardPlan(T, rank, world)
-runner = D.FrameShardRunner(model, lambda: make_lattice(contents), plan, via_host=True)
+runner = D.FrameShardRunner(model, lambda: make_lattice(contents), plan, via_host=True, use_program=use_program)
 mine = [{f: s[f] for f in plan.frames} for s in seqs]
 with torch.no_grad():
     keys = runner.exchange_keys(mine)
@@ -56,13 +57,22 @@ with torch.no_grad():
         out = runner.run_sequence(frames, keys[i])
         if plan.owns_last_frame():
             assert torch.equal(out[1], want[i]), "frame-sharded logits differ from the sequential run (seq %%d)" %% i
+if use_program:
+    assert not runner._hooked and getattr(model, "_program", None) is not None, "the frame program was not used"
+else:
+    assert runner._hooked
+runner.close()
+assert model.use_frame_program
 dist.barrier()
 print("RANK %%d OK" %% rank)
 dist.destroy_process_group()
 '''
 
 
-def test_frame_sharded_model_equals_sequential(gpu, tmp_path):
+@pytest.mark.parametrize("world,frames,route", [(2, 2, "program"), (4, 4, "program"), (2, 4, "program"), (2, 2, "hooks")])
+def test_frame_sharded_model_equals_sequential(gpu, tmp_path, world, frames, route):
+    """world == frames: one frame per rank; world < frames: a block of frames per rank (states stay native inside a
+    block); route: the native frame program run in segments, or the operator route with forward hooks"""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -70,8 +80,9 @@ def test_frame_sharded_model_equals_sequential(gpu, tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER % {"root": ROOT})
     procs = []
-    for r in range(2):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   TLN_TEST_FRAMES=str(frames), TLN_TEST_ROUTE=route)
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
     outs = []
