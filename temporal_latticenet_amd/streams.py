@@ -106,8 +106,9 @@ class SequenceStreams:
                     while k + g <= len(sequences) and all(len(sequences[k + j]) == len(sequences[k]) for j in range(g)):
                         grp = sequences[k:k + g]
                         for t in range(len(grp[0])):
-                            res = forward_group(models, lats, [sq[t][0] for sq in grp], [sq[t][1] for sq in grp],
-                                                t != len(grp[0]) - 1)
+                            ps = [sq[t][0] if sq[t][0].is_cuda else sq[t][0].to("cuda", non_blocking=True) for sq in grp]
+                            vs = [sq[t][1] if sq[t][1].is_cuda else sq[t][1].to("cuda", non_blocking=True) for sq in grp]
+                            res = forward_group(models, lats, ps, vs, t != len(grp[0]) - 1)
                             lats = [r[2] for r in res]
                         for mod in models:
                             mod.reset_sequence()
