@@ -441,10 +441,10 @@ __global__ void __launch_bounds__(128 * WM * G) k_gather_gemm(const GemmArgs g) 
 // Small-M variant ("direct"): a lattice level of a few thousand vertices gives ~75 row tiles, far too few to fill
 // 256 CUs with LDS-staged tiles, and nothing is shared between waves at that size anyway.  Here one WAVE owns a
 // 32x32 output tile for a subset of the K chunks and feeds the matrix cores straight from global memory:
-//   * A: lane (row = lane&31, half = lane>>5) loads the 16 channels c0 + 16*half .. +15 of its gathered row as
+//   * A: lane (row = lane&31, half = lane>>5) loads the 16 channels c0 + 8j + 4*half + e (j, e = 0..3) of its gathered row as
 //        4 x dwordx4 — exactly its operands of the 16 MFMAs of the chunk (the k order inside a chunk is permuted,
 //        identically for A and B, which the product does not see); no LDS round trip, no transposition, no barrier
-//   * B: [K,N] weights: 16 coalesced dword loads (row c0+16*half+s, column n0 + lane&31); [N,K] weights: 4 x dwordx4
+//   * B: [K,N] weights: 16 coalesced dword loads (rows in the same k order, column n0 + lane&31); [N,K] weights: 4 x dwordx4
 //   * G waves per block interleave over the chunk list (G = blockDim/64, up to 12) and are summed through LDS in
 //     fixed order; chunk loads run DEPTH chunks ahead in registers
 //     (`step`: a slot is refilled while its chunk is being multiplied -- the A registers are free once the operands
@@ -561,7 +561,10 @@ __device__ __forceinline__ void direct_body(const GemmArgs& g) {
                                             // clamped and its A operand zeroed (adds exact zeros)
   const unsigned nc = (unsigned)(ncol ? n : g.N - 1);  // columns past N are computed on column N-1, never stored
 
-  const unsigned b_loff = 4u * ((unsigned)(16 * half) * (unsigned)g.ldw + nc);  // [K,N] weights: the lane's fixed byte offset
+  // k order inside a chunk: lane half h holds k = 8j + 4h + e (j = 0..3, e = 0..3), identically for A and B.  The two
+  // lanes of a row then read ADJACENT 16-byte pieces in every load instruction (32 contiguous bytes per row: 32
+  // sector requests per wave-instruction instead of 64 with the halves 64 bytes apart)
+  const unsigned b_loff = 4u * ((unsigned)(4 * half) * (unsigned)g.ldw + nc);  // [K,N] weights: the lane's fixed byte offset
   f32x4 a[TLN_DIRECT_DEPTH][4];
   float b[TLN_DIRECT_DEPTH][16];
   int mode_r[TLN_DIRECT_DEPTH];   // per lane: 0 zero row, 1 data, 2 pad
@@ -601,28 +604,28 @@ __device__ __forceinline__ void direct_body(const GemmArgs& g) {
     c.mode = (!live || srow < 0) ? 0 : (srow >= src_rows ? 2 : 1);
     c.sm = si | (c0 << 1);
     const unsigned sr = c.mode == 1 ? (unsigned)srow : 0u;
-    c.ap = reinterpret_cast<const f32x4*>(src + (uint64_t)sr * ld + (unsigned)(c0 + 16 * half));
+    c.ap = reinterpret_cast<const f32x4*>(src + (uint64_t)sr * ld + (unsigned)(c0 + 4 * half));
     c.wq = reinterpret_cast<const char*>(g.W + (int64_t)kb * g.ldw);
-    c.wp = reinterpret_cast<const f32x4*>(g.W + (int64_t)nc * g.ldw + kb + 16 * half);
+    c.wp = reinterpret_cast<const f32x4*>(g.W + (int64_t)nc * g.ldw + kb + 4 * half);
     return c;
   };
   // [K,N] weights: K row q of the chunk; the lane's part is a fixed 32-bit byte offset on a wave-uniform row pointer
   auto load_b_kn = [&](const Chunk& c, int q) {
-    return *reinterpret_cast<const float*>(c.wq + (int64_t)q * g.ldw * 4 + b_loff);
+    return *reinterpret_cast<const float*>(c.wq + (int64_t)(8 * (q >> 2) + (q & 3)) * g.ldw * 4 + b_loff);   // k = 8j + 4h + e
   };
   auto load = [&](int t_raw, f32x4 (&av)[4], float (&bv)[16], int& md, int& sm) {
     const Chunk c = locate(t_raw);
     md = c.mode;
     sm = c.sm;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) av[q] = c.ap[q];
+    for (int q = 0; q < 4; ++q) av[q] = c.ap[2 * q];
     if (!W_NK) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) bv[q] = load_b_kn(c, q);
     } else {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const f32x4 v = c.wp[q];
+        const f32x4 v = c.wp[2 * q];
         bv[4 * q] = v[0];
         bv[4 * q + 1] = v[1];
         bv[4 * q + 2] = v[2];
@@ -640,7 +643,7 @@ __device__ __forceinline__ void direct_body(const GemmArgs& g) {
   // the chunk's A operands: prologue (GroupNorm affine, ReLU) and the zero / pad rows
   auto prepare = [&](const f32x4 (&av)[4], int mode, int sm, float (&x)[16]) {
     const int si = sm & 1, c0 = sm >> 1;
-    const int cb = c0 + 16 * half;
+    const int cb = c0 + 4 * half;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       x[4 * q] = av[q][0];
@@ -651,8 +654,8 @@ __device__ __forceinline__ void direct_body(const GemmArgs& g) {
     if (si == 0 && pro_lds) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const f32x4 sc = *reinterpret_cast<const f32x4*>(Gsc + cb + 4 * q);
-        const f32x4 sh = *reinterpret_cast<const f32x4*>(Gsh + cb + 4 * q);
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(Gsc + cb + 8 * q);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(Gsh + cb + 8 * q);
 #pragma unroll
         for (int e = 0; e < 4; ++e) x[4 * q + e] = fmaf(x[4 * q + e], sc[e], sh[e]);
       }
@@ -683,14 +686,14 @@ __device__ __forceinline__ void direct_body(const GemmArgs& g) {
     prepare(av, md, sm, x);
     const Chunk c = locate(t_next);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) av[q] = c.ap[q];
+    for (int q = 0; q < 4; ++q) av[q] = c.ap[2 * q];
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x[q], bv[q], acc, 0, 0, 0);
       if (!W_NK) {
         bv[q] = load_b_kn(c, q);
       } else if ((q & 3) == 3) {
-        const f32x4 v = c.wp[q >> 2];
+        const f32x4 v = c.wp[2 * (q >> 2)];
         bv[q - 3] = v[0];
         bv[q - 2] = v[1];
         bv[q - 1] = v[2];
