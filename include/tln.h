@@ -269,6 +269,11 @@ int tln_slice(const float* d_lv, int64_t V, int C, const int32_t* d_indices, con
 int tln_slice_deform(const float* d_b, int cb, const float* d_scores, int64_t V, int C, const int32_t* d_indices,
                      const float* d_weights, const float* d_w_pre, const float* d_w_dw, const float* d_b_dw,
                      const float* d_bias, int64_t n, float* d_out, void* stream);
+/* the same, and d_logsm [n, C] = log_softmax(d_out) over the classes (what LNN_SEQ.forward returns beside the raw
+ * scores, models.py:466-468); d_logsm may be NULL; C <= 64 */
+int tln_slice_deform_ls(const float* d_b, int cb, const float* d_scores, int64_t V, int C, const int32_t* d_indices,
+                     const float* d_weights, const float* d_w_pre, const float* d_w_dw, const float* d_b_dw,
+                     const float* d_bias, int64_t n, float* d_out, float* d_logsm, void* stream);
 
 /* ---- K11 plain splat (SplatLatticeModule) ---------------------------------------------- */
 /* out [V, val_dim+1] = sum over rows of w * [values, 1]  (uses the CSR of the last distribute) */
@@ -385,6 +390,8 @@ int tln_program_run(tln_program_t* p, int early, float* d_out, int64_t out_rows,
  * and returns the elapsed milliseconds, the number of launches and their algorithmic flops / bytes.
  * The GRU cell's two projections are on the list too.  The frame's buffers are still in place, so the replays
  * recompute the same values. */
+/* one-shot: the slice head of the next tln_program_run also writes log_softmax(scores) to d_logsm [N, classes] */
+int tln_program_set_aux_out(tln_program_t* p, float* d_logsm);
 int tln_program_capture_gemms(tln_program_t* p, int enable);
 /* measurement (bench.py roofline_scatter): with timing on, every frame records HIP events on its launch stream around
  * K1 (all kernels of the distribute), K2 (the PointNet pool) and K8 (the slice kernels); _read waits for them and

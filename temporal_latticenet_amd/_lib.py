@@ -116,6 +116,8 @@ _PROTOS = {
     "tln_slice_gather": (_i, [_vp, _i64, _i, _vp, _vp, _i64, _vp, _vp]),
     "tln_slice": (_i, [_vp, _i64, _i, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "tln_slice_deform": (_i, [_vp, _i, _vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "tln_slice_deform_ls": (_i, [_vp, _i, _vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "tln_program_set_aux_out": (_i, [_vp, _vp]),
     "tln_splat": (_i, [_vp, _vp, _i, _vp, _i64, _vp, _vp]),
     "tln_scatter_max": (_i, [_vp, _vp, _i64, _i, _i64, _vp, _vp, _vp, _i64, _vp]),
     "tln_scatter_add": (_i, [_vp, _vp, _i64, _i, _i64, _vp, _vp]),

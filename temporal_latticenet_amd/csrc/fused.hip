@@ -454,13 +454,14 @@ extern "C" int tln_slice(const float* d_lv, int64_t V, int C, const int32_t* d_i
 // instead of gather -> two per-point products over [N, 36] -> blend (three [N, 36] round trips through HBM and four
 // launches).  One thread per point, the 36 x 36 + 4 x 36 weights are wave-uniform (scalar loads).
 // ---------------------------------------------------------------------------------------
+#define TLN_SLICE_MAX_C 64
 template <int CB>
 __global__ void __launch_bounds__(256) k_slice_deform(const float* __restrict__ b, const float* __restrict__ scores,
                                                       int64_t V, int C, const int32_t* __restrict__ indices,
                                                       const float* __restrict__ weights,
                                                       const float* __restrict__ w_pre, const float* __restrict__ w_dw,
                                                       const float* __restrict__ b_dw, const float* __restrict__ bias,
-                                                      int64_t n, float* __restrict__ out) {
+                                                      int64_t n, float* __restrict__ out, float* __restrict__ logsm) {
   constexpr int G = 4 * (CB + 1);            // 36 gathered features
   constexpr int GP = (G + 3) / 4 * 4;        // LDS rows padded to 16-byte multiples
   constexpr int PPB = 64;                    // points per block: FOUR lanes per point, each owns G/4 hidden units
@@ -470,6 +471,8 @@ __global__ void __launch_bounds__(256) k_slice_deform(const float* __restrict__ 
   __shared__ float wd_s[4 * G];
   __shared__ float wr_s[PPB][4];
   __shared__ int idx_s[PPB][4];
+  __shared__ float lg_s[PPB][TLN_SLICE_MAX_C + 1];   // the block's logits, for the fused log-softmax (models.py:467)
+  __shared__ float mx_s[PPB], lse_s[PPB];
   for (int i = threadIdx.x; i < G * GP; i += blockDim.x) {
     const int j = i / GP, k = i - j * GP;
     wp_s[i] = k < G ? w_pre[j * G + k] : 0.0f;
@@ -548,22 +551,51 @@ __global__ void __launch_bounds__(256) k_slice_deform(const float* __restrict__ 
       const int ix = idx_s[pt][r];
       if (ix >= 0) acc = fmaf(wr_s[pt][r], scores[(int64_t)ix * C + c], acc);
     }
-    out[(p0 + pt) * C + c] = bias ? acc + bias[c] : acc;
+    const float v = bias ? acc + bias[c] : acc;
+    out[(p0 + pt) * C + c] = v;
+    if (logsm) lg_s[pt][c] = v;
   }
+  if (logsm == nullptr) return;   // uniform
+  // log-softmax over the classes of every point (what LNN_SEQ.forward returns beside the raw scores, models.py:466-468):
+  // x - max - log(sum exp(x - max)), one thread per point for the statistics, then coalesced rows again
+  __syncthreads();
+  if (threadIdx.x < live) {
+    float mx = lg_s[threadIdx.x][0];
+    for (int c = 1; c < C; ++c) mx = fmaxf(mx, lg_s[threadIdx.x][c]);
+    float sum = 0.0f;
+    for (int c = 0; c < C; ++c) sum += expf(lg_s[threadIdx.x][c] - mx);
+    mx_s[threadIdx.x] = mx;
+    lse_s[threadIdx.x] = logf(sum);
+  }
+  __syncthreads();
+  for (int64_t e = threadIdx.x; e < live * C; e += blockDim.x) {
+    const int pt = (int)(e / C), c = (int)(e - (int64_t)pt * C);
+    logsm[(p0 + pt) * C + c] = (lg_s[pt][c] - mx_s[pt]) - lse_s[pt];
+  }
+}
+
+extern "C" int tln_slice_deform_ls(const float* d_b, int cb, const float* d_scores, int64_t V, int C,
+                                   const int32_t* d_indices, const float* d_weights, const float* d_w_pre,
+                                   const float* d_w_dw, const float* d_b_dw, const float* d_bias, int64_t n, float* d_out,
+                                   float* d_logsm, void* stream_) {
+  TLN_REQUIRE(d_b && d_scores && d_indices && d_weights && d_w_pre && d_w_dw && d_b_dw && d_out && C > 0,
+              "null argument");
+  TLN_REQUIRE(cb == 8, "the deform head is built for the 8-channel bottleneck (got %d)", cb);
+  TLN_REQUIRE(d_logsm == nullptr || C <= TLN_SLICE_MAX_C, "fused log-softmax: at most %d classes (got %d)",
+              TLN_SLICE_MAX_C, C);
+  if (n <= 0) return TLN_OK;
+  hipLaunchKernelGGL(k_slice_deform<8>, dim3((unsigned)tln_cdiv(n, 64)), dim3(256), 0, (hipStream_t)stream_, d_b,
+                     d_scores, V, C, d_indices, d_weights, d_w_pre, d_w_dw, d_b_dw, d_bias, n, d_out, d_logsm);
+  TLN_LAUNCH_CHECK();
+  return TLN_OK;
 }
 
 extern "C" int tln_slice_deform(const float* d_b, int cb, const float* d_scores, int64_t V, int C,
                                 const int32_t* d_indices, const float* d_weights, const float* d_w_pre,
                                 const float* d_w_dw, const float* d_b_dw, const float* d_bias, int64_t n, float* d_out,
                                 void* stream_) {
-  TLN_REQUIRE(d_b && d_scores && d_indices && d_weights && d_w_pre && d_w_dw && d_b_dw && d_out && C > 0,
-              "null argument");
-  TLN_REQUIRE(cb == 8, "the deform head is built for the 8-channel bottleneck (got %d)", cb);
-  if (n <= 0) return TLN_OK;
-  hipLaunchKernelGGL(k_slice_deform<8>, dim3((unsigned)tln_cdiv(n, 64)), dim3(256), 0, (hipStream_t)stream_, d_b,
-                     d_scores, V, C, d_indices, d_weights, d_w_pre, d_w_dw, d_b_dw, d_bias, n, d_out);
-  TLN_LAUNCH_CHECK();
-  return TLN_OK;
+  return tln_slice_deform_ls(d_b, cb, d_scores, V, C, d_indices, d_weights, d_w_pre, d_w_dw, d_b_dw, d_bias, n, d_out,
+                             nullptr, stream_);
 }
 
 // =======================================================================================

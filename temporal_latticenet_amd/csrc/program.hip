@@ -163,6 +163,7 @@ struct tln_program {
   bool defer = false, has_pending = false;
   GemmCall pending{};
   int w_next = 0;  // where the next walk continues
+  float* aux_out = nullptr;   // where the slice head of the NEXT run also writes log-softmax(scores) (tln_program_set_aux_out)
   // segmented run (tln_program_run_begin / _until / _end: frame-sharded multi-GPU, dist.py)
   int state_level[TLN_MAX_STATES] = {0};
   bool seg_open = false, seg_levels_done = false;
@@ -463,10 +464,11 @@ int walk(tln_program* p, bool dry, int early, float* d_out, int64_t out_rows, in
           TLN_HIP(hipEventRecord(p->tev[4], s));
           p->tset[2] = true;
         }
-        rc = tln_slice_deform(fptr(o.s0.slot), p->slots[o.s0.slot].cols, fptr(o.s1.slot), p->rt[o.s1.slot].rows,
-                              p->slots[o.s1.slot].cols, p->d_idx, p->d_w, o.p[0], o.p[1], o.p[2], o.bias, p->N,
-                              fptr(o.out), s);
+        rc = tln_slice_deform_ls(fptr(o.s0.slot), p->slots[o.s0.slot].cols, fptr(o.s1.slot), p->rt[o.s1.slot].rows,
+                                 p->slots[o.s1.slot].cols, p->d_idx, p->d_w, o.p[0], o.p[1], o.p[2], o.bias, p->N,
+                                 fptr(o.out), p->slots[o.s1.slot].cols <= 64 ? p->aux_out : nullptr, s);
         if (rc) return rc;
+        p->aux_out = nullptr;
         if (p->timing) TLN_HIP(hipEventRecord(p->tev[5], s));
         break;
       }
@@ -1018,6 +1020,14 @@ extern "C" int tln_program_run_pair(tln_program_t* pa, tln_program_t* pb, int ea
   float* const outs[2] = {d_out_a, d_out_b};
   const int64_t rows[2] = {out_rows_a, out_rows_b};
   return tln_program_run_group(pp, 2, early, outs, rows, out_cols, stream_);
+}
+
+// the slice head (TLN_OP_SLICE_DEFORM) of the next frame also writes log_softmax(scores) to d_logsm [N, classes]
+// (models.py:466-468 returns both); one-shot: cleared by the op that used it
+extern "C" int tln_program_set_aux_out(tln_program_t* p, float* d_logsm) {
+  TLN_REQUIRE(p, "null program");
+  p->aux_out = d_logsm;
+  return TLN_OK;
 }
 
 // ---- measurement: HIP events around K1 / K2 / K8 of a frame -----------------------------------------------------------

@@ -297,4 +297,5 @@ class FrameShardRunner:
         model._program_active = True
         if early and prog.stop_shape is not None:
             return raw, raw, lat
-        return model.logsoftmax(raw), raw, lat
+        fused = prog.take_logsm()
+        return (fused if fused is not None else model.logsoftmax(raw)), raw, lat

@@ -320,6 +320,7 @@ def _walk_model(model):
     out = b.slot(ROWS_POINTS, clasify.weight.shape[0], SLOT_OUT)
     b.keep += [clasify.bias, sl.linear_pre_deltaW.weight, sl.linear_deltaW.weight, sl.linear_deltaW.bias]
     if t is not None:
+        b.fused_logsm = clasify.weight.shape[0] <= 64      # the slice head can write log_softmax(scores) as well
         b.op(OP_SLICE_DEFORM, out=out, s0=b.src(t), s1=b.src(scores), bias=_p(clasify.bias),
              p=[_p(sl.linear_pre_deltaW.weight), _p(sl.linear_deltaW.weight), _p(sl.linear_deltaW.bias)] + [None] * 5)
     else:
@@ -350,6 +351,8 @@ class FrameProgram:
         self.uses_dropout = builder.uses_dropout
         self._keep = builder.keep
         self.n_ops, self.n_slots, self.n_states = len(builder.ops), len(builder.slots), builder.n_states
+        self.fused_logsm = bool(getattr(builder, "fused_logsm", False))
+        self.last_logsm = None
         slots = (_lib.Slot * len(builder.slots))()
         for k, (rows, cols, kind, state) in enumerate(builder.slots):
             slots[k].rows, slots[k].cols, slots[k].kind, slots[k].state = rows, cols, kind, state
@@ -408,9 +411,18 @@ class FrameProgram:
         rows_code, cols = self.stop_shape if early else self.out_shape
         rows = self._rows(rows_code, n)
         out = torch.empty((rows, cols), dtype=torch.float32, device="cuda")
+        self.last_logsm = None
+        if not early and self.fused_logsm:
+            self.last_logsm = torch.empty_like(out)
+            _lib.check(lib.tln_program_set_aux_out(self._h, self.last_logsm.data_ptr()), "tln_program_set_aux_out")
         _lib.check(lib.tln_program_run(self._h, 1 if early else 0, out.data_ptr(), rows, cols, s), "tln_program_run")
         ls.set_values(out)
         return out, ls
+
+    def take_logsm(self):
+        """log_softmax(scores) of the frame just run, when the slice head produced it (else None)"""
+        t, self.last_logsm = self.last_logsm, None
+        return t
 
     def _start(self, ls, positions, values, reset_hashmap):
         """first half of a frame's K1 (the vertex counters start their way to the host)"""
@@ -448,6 +460,11 @@ class FrameProgram:
         begun = [p._finish(st[0], early_return) for p, st in zip(progs, started)]
         early, outs = begun[0][0], [x[1] for x in begun]
         assert all(x[0] == early for x in begun) and all(o.shape[1] == outs[0].shape[1] for o in outs)
+        for p, o in zip(progs, outs):
+            p.last_logsm = None
+            if not early and p.fused_logsm:
+                p.last_logsm = torch.empty_like(o)
+                _lib.check(_lib.lib().tln_program_set_aux_out(p._h, p.last_logsm.data_ptr()), "tln_program_set_aux_out")
         hs = (C.c_void_p * n)(*[p._h for p in progs])
         ptrs = (C.c_void_p * n)(*[o.data_ptr() for o in outs])
         rows = (C.c_int64 * n)(*[o.shape[0] for o in outs])
@@ -519,6 +536,10 @@ class FrameProgram:
         rows_code, cols = self.stop_shape if early else self.out_shape
         rows = self._rows(rows_code, n)
         out = torch.empty((rows, cols), dtype=torch.float32, device="cuda")
+        self.last_logsm = None
+        if not early and self.fused_logsm:
+            self.last_logsm = torch.empty_like(out)
+            _lib.check(lib.tln_program_set_aux_out(self._h, self.last_logsm.data_ptr()), "tln_program_set_aux_out")
         _lib.check(lib.tln_program_run_begin(self._h, 1 if early else 0, out.data_ptr(), rows, cols, s),
                    "tln_program_run_begin")
         for fr, lw, lvl, sid in plan:

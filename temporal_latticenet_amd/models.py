@@ -219,7 +219,8 @@ class LNN_SEQ(torch.nn.Module):
             self.first_sequence = False
             if early_return and prog.stop_shape is not None:
                 return out, out, ls
-            return self.logsoftmax(out), out, ls
+            fused = prog.take_logsm()          # the slice head wrote log_softmax(scores) beside the scores
+            return (fused if fused is not None else self.logsoftmax(out)), out, ls
         with torch.set_grad_enabled(False):
             ls, distributed, indices, weights = self.distribute(ls, positions, values, reset_hashmap)   # :298
             if hasattr(ls, "prepare_levels"):      # all coarse levels + neighbour tables of the frame in one go
@@ -366,7 +367,8 @@ def forward_group(models, lattices, positions, values, early_return=False):
         if early_return and prog.stop_shape is not None:
             out.append((o, o, ls))
         else:
-            out.append((mod.logsoftmax(o), o, ls))
+            fused = prog.take_logsm()
+            out.append((fused if fused is not None else mod.logsoftmax(o), o, ls))
     return out
 
 

@@ -56,6 +56,11 @@ def test_program_equals_operator_route(gpu, rnn, seq_learning, frames):
         for t in range(frames):
             for k in range(2):
                 assert got[t][k].shape == ref[t][k].shape
+                if k == 0 and t == frames - 1 and got[t][0].shape[1] == 26:
+                    # log_softmax(scores): written by the slice head on the program route, torch.nn.LogSoftmax on the
+                    # operator route (same formula, not the same instruction sequence)
+                    np.testing.assert_allclose(got[t][0].cpu().numpy(), ref[t][0].cpu().numpy(), rtol=2e-6, atol=2e-6)
+                    continue
                 assert torch.equal(got[t][k], ref[t][k]), "frame %d output %d differs (max %.3e)" % (
                     t, k, float((got[t][k] - ref[t][k]).abs().max()))
 
@@ -183,3 +188,22 @@ def test_lockstep_pair_equals_the_solo_frames(gpu, rnn, seq_learning, frames):
                 m.reset_sequence()
     finally:
         lib.tln_gemm_pair_disable(0)
+
+
+def test_slice_head_writes_log_softmax(gpu):
+    """models.py:466-468 returns (log_softmax(scores), scores): on the frame-program route the slice head writes both
+    (no torch kernel in the frame); the operator route applies torch.nn.LogSoftmax as the reference does"""
+    contents = make_config(rnn_modules=("gru", "gru", "aflow", "gru"), frames=2, sigma=0.8)
+    seq = make_sequence(9000, 2, seed=12)
+    model = _prepared(contents, seq, gpu)
+    model.use_frame_program = True
+    lat = make_lattice(contents)
+    with torch.no_grad():
+        for t, (pos, val) in enumerate(seq):
+            logsm, raw, lat = model(lat, torch.from_numpy(pos).to(gpu), torch.from_numpy(val).to(gpu), t != len(seq) - 1, False)
+    assert model._program.fused_logsm and model._program_active
+    model.reset_sequence()
+    want = torch.log_softmax(raw, 1)
+    assert logsm.shape == raw.shape == (9000, 26)
+    np.testing.assert_allclose(logsm.cpu().numpy(), want.cpu().numpy(), rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(torch.exp(logsm).sum(1).cpu().numpy(), 1.0, rtol=0, atol=1e-5)
