@@ -65,6 +65,10 @@ int tln_distribute_finish(tln_lattice_t* l, void* stream);
 
 /* forget the bins of the last distribute (the caller edited d_distributed in place): the next pool goes through a CSR */
 int tln_lattice_drop_bins(tln_lattice_t* l);
+/* K1 variant for the distributes that follow (process-wide): 0 = partitioned (rows split by key hash into buckets owned
+ * by one workgroup each, LDS atomics only; the default), 1 = one global atomic per row (also env TLN_K1_LEGACY=1; always
+ * taken for val_dim > 1).  Same results bit for bit; a test / measurement switch. */
+int tln_distribute_config(int legacy);
 
 /* build the vertex-sorted row list (CSR) from caller-supplied indices (R rows, -1 folded into the tail bucket) */
 int tln_build_csr(tln_lattice_t* l, const int32_t* d_indices, int64_t rows, void* stream);

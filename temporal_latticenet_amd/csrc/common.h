@@ -86,6 +86,8 @@ struct TlnBins {
   const int32_t* ctr;      // device counters: [0] = V, [6] = rows placed in vertex segments
   const float* weights;    // [rows] barycentric weights in row order
   int subtract;
+  const int32_t* vstamp;   // partitioned K1: vcnt[v] / vstart[v] / mean[v] belong to this frame iff vstamp[v] == stamp
+  int stamp;               // (NULL: every vertex was visited)
 };
 bool tln_lat_bins(const tln_lattice* l, const float* d_distributed, int64_t rows, TlnBins* out);
 

@@ -28,8 +28,16 @@ extern "C" int tln_version(void) { return 1; }
 // handle
 // ---------------------------------------------------------------------------------------
 enum { CTR_NV = 0, CTR_NEW = 1, CTR_OVERFLOW = 2, CTR_PROBE_FAIL = 3, CTR_VOLD = 4, CTR_OCCUPIED = 5,
-       CTR_CURSOR = 6 /* rows placed in vertex bins */, CTR_TAIL = 7 /* rows without a vertex */, CTR_COUNT = 8 };
-#define TLN_MAX_PROBES 8192
+       CTR_CURSOR = 6 /* rows placed in vertex bins */, CTR_TAIL = 7 /* rows without a vertex */,
+       CTR_COUNT = 8 };
+// Probing stays inside the aligned group of TLN_SLOT_GROUP slots the key hashes into (wraps there).  The table is
+// sized for a load of at most 1/2, so a group never fills; what the grouping buys: the buckets of the partitioned K1
+// (top bits of the home slot) own disjoint slot ranges, so a bucket's workgroup inserts its keys with plain stores.
+#define TLN_SLOT_GROUP 256
+#define TLN_MAX_PROBES TLN_SLOT_GROUP
+__host__ __device__ __forceinline__ uint64_t tln_next_slot(uint64_t slot) {
+  return (slot & ~(uint64_t)(TLN_SLOT_GROUP - 1)) | ((slot + 1) & (uint64_t)(TLN_SLOT_GROUP - 1));
+}
 #define TLN_SCAN_BLOCK 1024
 
 // One hash-table slot: the packed key, the vertex index (-1 until numbered) and the smallest row id that touched the
@@ -39,6 +47,19 @@ struct __attribute__((aligned(16))) TlnSlot {
   unsigned long long key;
   int32_t val;
   uint32_t touch;
+};
+
+// partitioned K1 (k_bk_*, below): bucket geometry and the 32-byte row record
+#define TLN_BK_HT 1024            // entries of a bucket's LDS hash table (distinct keys of one bucket and frame)
+#define TLN_BK_ROWS 512           // rows per bucket aimed at: small enough that a vertex with hundreds of rows (the
+                                  // heaviest bucket is ~2000 rows on a KITTI-like frame) does not set the kernel's tail
+#define TLN_BK_THREADS 512        // workgroup of a bucket: one run (= one split block's records of the bucket) per thread
+#define TLN_BK_MINB 16
+#define TLN_BK_MAXB 8192
+#define TLN_BK_SPLIT_BLOCKS TLN_BK_THREADS   // at most this many split blocks (columns of the bucket-offset table)
+struct __attribute__((aligned(16))) TlnRec {
+  float4 a;   // x, y, z, value
+  uint4 b;    // barycentric weight (bits), row id, then the packed key (lo, hi) -> (LDS hash entry, rank inside the vertex)
 };
 
 struct tln_lattice {
@@ -99,6 +120,17 @@ struct tln_lattice {
   int32_t* bin_row = nullptr;     // [rows_cap] row id
   int32_t* bin_vtx = nullptr;     // [rows_cap] vertex (-1: none)
   int64_t bins_rows = -1;         // rows of the frame the bins hold (-1: none)
+  // ---- partitioned K1 (k_bk_*): the rows of a frame split by key hash into buckets, one workgroup per bucket
+  struct TlnRec* rec = nullptr;   // [rec_cap] 32-byte row records, grouped by (split block, bucket)
+  int64_t rec_cap = 0;
+  uint32_t* bk_off = nullptr;     // [bk_maxb + 1][split blocks] first record of a bucket inside a split block's region
+  int bk_maxb = 0;
+  uint32_t* first_flag = nullptr; // [rows_cap / 32] bit per row: first-touch row of a key without a vertex (this frame)
+  uint32_t* bucket_rows = nullptr;   // [bk_maxb] rows of the frame in a bucket
+  uint32_t* bits_pre = nullptr;      // [rows_cap / 128 + 8] set bits of first_flag before every uint4 of it
+  int32_t* vstamp = nullptr;      // [capacity] bins_stamp of the last frame that put rows on vertex v
+  int bins_stamp = 0;
+  bool bins_stamped = false;      // the bins of the last distribute come from the partitioned path (vcnt valid where stamped)
   const float* bins_dist = nullptr;
   const float* bins_weights = nullptr;
   int bins_subtract = 0;
@@ -153,13 +185,18 @@ static int ensure_rows(tln_lattice* l, int64_t rows) {
   int64_t cap = 1;
   while (cap < rows) cap <<= 1;
   void* ptrs[] = {l->row_slot, l->block_cnt, l->sk_in, l->sk_out, l->sv_in, l->sv_out, l->sort_temp, l->pieces,
-                  l->row_rank, l->bin_xyzv, l->bin_w, l->bin_row, l->bin_vtx};
+                  l->row_rank, l->bin_xyzv, l->bin_w, l->bin_row, l->bin_vtx, l->rec, l->bk_off, l->first_flag,
+                  l->bucket_rows, l->bits_pre};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   l->row_slot = l->block_cnt = l->sk_in = l->sk_out = l->sv_in = l->sv_out = nullptr;
   l->row_rank = l->bin_row = l->bin_vtx = nullptr;
   l->bin_xyzv = nullptr;
   l->bin_w = nullptr;
+  l->rec = nullptr;
+  l->bk_off = l->first_flag = l->bucket_rows = l->bits_pre = nullptr;
+  l->rec_cap = 0;
+  l->bk_maxb = 0;
   l->bins_rows = -1;
   l->sort_temp = nullptr;
   l->pieces = nullptr;
@@ -177,6 +214,16 @@ static int ensure_rows(tln_lattice* l, int64_t rows) {
     TLN_HIP(hipMalloc(&l->bin_w, cap * sizeof(float)));
     TLN_HIP(hipMalloc(&l->bin_row, cap * sizeof(int32_t)));
     TLN_HIP(hipMalloc(&l->bin_vtx, cap * sizeof(int32_t)));
+    // partitioned K1: the split blocks' record regions (each rounded up to whole blocks of points), the bucket offsets
+    // of every split block, the first-touch flags (zero between frames) and the bucket directories
+    l->rec_cap = cap + cap / 128 + 2048;
+    l->bk_maxb = (int)(cap / 128 < TLN_BK_MINB ? TLN_BK_MINB : (cap / 128 > TLN_BK_MAXB ? TLN_BK_MAXB : cap / 128));
+    TLN_HIP(hipMalloc(&l->rec, (size_t)l->rec_cap * sizeof(TlnRec)));
+    TLN_HIP(hipMalloc(&l->bk_off, (size_t)TLN_BK_SPLIT_BLOCKS * (l->bk_maxb + 1) * sizeof(uint32_t)));
+    TLN_HIP(hipMalloc(&l->first_flag, cap * sizeof(uint32_t)));
+    TLN_HIP(hipMemset(l->first_flag, 0, cap * sizeof(uint32_t)));
+    TLN_HIP(hipMalloc(&l->bucket_rows, (size_t)l->bk_maxb * sizeof(uint32_t)));
+    TLN_HIP(hipMalloc(&l->bits_pre, (size_t)(cap / 128 + 8) * sizeof(uint32_t)));
   }
   // radix-sort scratch: ping-pong keys + values and the [256][blocks] digit histogram
   // + the 256 digit bases and the arrival counter of the fused table scan (counter starts, and is left, at zero)
@@ -218,6 +265,8 @@ static int lattice_alloc(tln_lattice** out, int pos_dim, const double* sigmas, i
     TLN_HIP(hipMalloc(&l->vslot, capacity * sizeof(int32_t)));
     TLN_HIP(hipMalloc(&l->vcnt, capacity * sizeof(int32_t)));
     TLN_HIP(hipMalloc(&l->vstart, capacity * sizeof(int32_t)));
+    TLN_HIP(hipMalloc(&l->vstamp, capacity * sizeof(int32_t)));
+    TLN_HIP(hipMemset(l->vstamp, 0, capacity * sizeof(int32_t)));
   }
   *out = l;
   return TLN_OK;
@@ -305,7 +354,8 @@ extern "C" int tln_lattice_destroy(tln_lattice_t* l) {
   void* ptrs[] = {l->slots, l->vkeys, l->d_ctr, l->nbr, l->c2f, l->f2c,
                   l->row_slot, l->block_cnt, l->sk_in, l->sk_out, l->sv_in, l->sv_out, l->sort_temp,
                   l->seg_start, l->pool_packed, l->mean, l->pieces, l->slot_cnt, l->vslot, l->vcnt, l->vstart,
-                  l->row_rank, l->bin_xyzv, l->bin_w, l->bin_row, l->bin_vtx};
+                  l->row_rank, l->bin_xyzv, l->bin_w, l->bin_row, l->bin_vtx, l->rec, l->bk_off, l->first_flag,
+                  l->bucket_rows, l->bits_pre, l->vstamp};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (l->h_ctr) (void)hipHostFree(l->h_ctr);
@@ -352,7 +402,8 @@ __device__ __forceinline__ void load_slot(const TableRef& t, uint64_t slot, unsi
 }
 
 // find-or-claim the slot of key K; records the smallest row id touching a not-yet-numbered slot
-__device__ __forceinline__ int probe_insert(const TableRef& t, uint64_t K, uint32_t id) {
+// (*numbered = the slot already carries a vertex index)
+__device__ __forceinline__ int probe_insert(const TableRef& t, uint64_t K, uint32_t id, bool* numbered = nullptr) {
   uint64_t slot = tln_mix64(K) & t.mask;
   for (int probe = 0; probe < TLN_MAX_PROBES; ++probe) {
     unsigned long long cur;
@@ -370,11 +421,13 @@ __device__ __forceinline__ int probe_insert(const TableRef& t, uint64_t K, uint3
     }
     if (cur == K) {
       if (val < 0 && touch > id) atomicMin(&t.slots[slot].touch, id);
+      if (numbered) *numbered = val >= 0;
       return (int)slot;
     }
-    slot = (slot + 1) & t.mask;
+    slot = tln_next_slot(slot);
   }
   atomicAdd(&t.ctr[CTR_PROBE_FAIL], 1);
+  if (numbered) *numbered = false;
   return -1;
 }
 
@@ -388,7 +441,7 @@ __device__ __forceinline__ int probe_find(const TableRef& t, uint64_t K) {
     load_slot(t, slot, cur, val, touch);
     if (cur == K) return val;
     if (cur == TLN_KEY_EMPTY) return -1;
-    slot = (slot + 1) & t.mask;
+    slot = tln_next_slot(slot);
   }
   return -1;
 }
@@ -527,7 +580,7 @@ __global__ void __launch_bounds__(256) k_rehash(const int32_t* __restrict__ vkey
       if (vslot) vslot[v] = (int32_t)slot;
       return;
     }
-    slot = (slot + 1) & t.mask;
+    slot = tln_next_slot(slot);
   }
   atomicAdd(&t.ctr[CTR_PROBE_FAIL], 1);
 }
@@ -1432,6 +1485,464 @@ __global__ void __launch_bounds__(256) k_bins_mean(const int32_t* __restrict__ c
   }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// K1, partitioned: the same distribute WITHOUT a global atomic per row.
+// A scattered device-scope atomic costs ~43 ps of chip time whatever its scope (tools/micro/atomics.hip: 480k of them
+// = 21 us; every add to ONE word another ~11 ns), and k_distribute_insert + k_bins_scatter need three per row when the
+// points arrive shuffled.  Here the rows are first split by 8-13 bits of their key's hash into buckets of ~500 rows, and
+// ONE workgroup owns a bucket: every per-row atomic (find-or-insert, row count, first touch, fixed-point position sums)
+// is an LDS atomic on the bucket's own 1024-entry table; the global table sees one probe per DISTINCT key of the frame.
+//   k_bk_split   block = a range of points: simplex arithmetic, LDS histogram of the buckets, then the 32-byte records
+//                {x, y, z, value, weight, row, key} written bucket by bucket into the block's own region (+ the block's
+//                bucket offsets, stored bucket-major); also the per-row weights and, when asked for, the [4N,5] rows
+//   k_bk_insert  block = a bucket: walks its runs (one per split block, ~1 row each), LDS find-or-insert with the
+//                smallest row per key; then one global probe_insert per distinct key, the first-touch flag of the keys
+//                without a vertex (and their count per 1024 rows, for the numbering), the bucket's row count
+//   k_assign_flags   first-touch numbering from the flag array (no per-row table reads)
+//   k_bk_place   block = a bucket: LDS table again, now with row counts and position sums; one global lookup per
+//                distinct key -> vertex; the bucket's rows go to the bin range [rows of the buckets before, +own rows),
+//                one segment per vertex (the layout k_pool_bins reads), rows without a vertex behind them; indices[row]
+// The order of the rows inside a segment is arbitrary, as before; every result computed from the bins is
+// order-independent.  Vertices without rows in this frame are told apart by vstamp (nobody visits them).
+// ---------------------------------------------------------------------------------------
+// bucket of a key = the top bits of its home slot: the slot ranges of the buckets are disjoint (group-local probing)
+__device__ __forceinline__ uint32_t bk_bucket(uint64_t K, uint64_t slot_mask, int shift) {
+  return K == TLN_KEY_EMPTY ? 0u : (uint32_t)((tln_mix64(K) & slot_mask) >> shift);
+}
+
+// exclusive prefix sum over the threads of a block (whole waves, at most 16); *total = sum of all (valid after the call
+// for every thread)
+__device__ __forceinline__ uint32_t bk_block_scan(uint32_t v, uint32_t* wtmp /* [16] shared */, uint32_t* total) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  uint32_t incl = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t u = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += u;
+  }
+  __syncthreads();   // wtmp may still be read from an earlier scan
+  if (lane == 63) wtmp[wid] = incl;
+  __syncthreads();
+  uint32_t pre = 0, tot = 0;
+  for (int w = 0; w < nw; ++w) {
+    if (w < wid) pre += wtmp[w];
+    tot += wtmp[w];
+  }
+  *total = tot;
+  return pre + incl - v;
+}
+
+__global__ void __launch_bounds__(256) k_bk_split(const float* __restrict__ pos, const float* __restrict__ val, int64_t n,
+                                                  int val_dim, float s0, float s1, float s2, int ppb, int B,
+                                                  TlnRec* __restrict__ rec, uint32_t* __restrict__ off,
+                                                  float* __restrict__ weights, float* __restrict__ dist,
+                                                  uint64_t slot_mask, int shift, int nr_words,
+                                                  uint32_t* __restrict__ first_bits, int32_t* __restrict__ ctr) {
+  extern __shared__ uint32_t bk_hist[];   // [B] bucket counts of this block, then the write cursors
+  __shared__ uint32_t wtmp[16];
+  const int tid = threadIdx.x;
+  const int nblk = gridDim.x;
+  // what k_bk_insert accumulates into: the bit mask of the first-touch rows, their number
+  for (int i = blockIdx.x * 256 + tid; i < nr_words; i += nblk * 256) first_bits[i] = 0u;
+  if (blockIdx.x == 0 && tid == 0) ctr[CTR_OVERFLOW] = 0;   // accumulated by k_bk_place
+  for (int i = tid; i < B; i += 256) bk_hist[i] = 0;
+  __syncthreads();
+  const int64_t p0 = (int64_t)blockIdx.x * ppb;
+  const int64_t p1 = p0 + ppb < n ? p0 + ppb : n;
+  for (int64_t p = p0 + tid; p < p1; p += 256) {
+    const float x = pos[3 * p], y = pos[3 * p + 1], z = pos[3 * p + 2];
+    int rem0[4], rank[4];
+    float bary[4];
+    point_simplex(x, y, z, s0, s1, s2, rem0, rank, bary);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int k0, k1, k2;
+      vertex_key(rem0, rank, r, k0, k1, k2);
+      const uint64_t K = tln_key_in_range(k0, k1, k2) ? tln_pack_key(k0, k1, k2) : TLN_KEY_EMPTY;
+      atomicAdd(&bk_hist[bk_bucket(K, slot_mask, shift)], 1u);
+    }
+    *reinterpret_cast<float4*>(weights + 4 * p) = make_float4(bary[0], bary[1], bary[2], bary[3]);
+    if (dist) {   // the [4N, 3 + val_dim + 1] rows (val_dim <= 1 on this path): raw position, value, weight
+      const int cols = 3 + val_dim + 1;
+      float* d = dist + 4 * p * cols;
+      const float v = val_dim ? val[p] : 0.0f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        d[r * cols] = x;
+        d[r * cols + 1] = y;
+        d[r * cols + 2] = z;
+        if (val_dim) d[r * cols + 3] = v;
+        d[r * cols + 3 + val_dim] = bary[r];
+      }
+    }
+  }
+  __syncthreads();
+  // exclusive scan of the B counts: a thread owns B/256 consecutive buckets (one, for fewer than 256).  off is bucket-major ([B + 1][nblk]) so that
+  // a bucket's workgroup reads its runs with contiguous loads.
+  const int per = B >= 256 ? B >> 8 : (tid < B ? 1 : 0);
+  uint32_t mine = 0;
+  for (int k = 0; k < per; ++k) mine += bk_hist[tid * per + k];
+  uint32_t total;
+  uint32_t run = bk_block_scan(mine, wtmp, &total);
+  for (int k = 0; k < per; ++k) {
+    const uint32_t c = bk_hist[tid * per + k];
+    bk_hist[tid * per + k] = run;
+    off[(size_t)(tid * per + k) * nblk + blockIdx.x] = run;
+    run += c;
+  }
+  if (tid == 255) off[(size_t)B * nblk + blockIdx.x] = total;
+  __syncthreads();
+  TlnRec* region = rec + (size_t)blockIdx.x * (4 * (size_t)ppb);
+  for (int64_t p = p0 + tid; p < p1; p += 256) {
+    const float x = pos[3 * p], y = pos[3 * p + 1], z = pos[3 * p + 2];
+    int rem0[4], rank[4];
+    float bary[4];
+    point_simplex(x, y, z, s0, s1, s2, rem0, rank, bary);
+    const float4 a = make_float4(x, y, z, val_dim ? val[p] : 0.0f);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int k0, k1, k2;
+      vertex_key(rem0, rank, r, k0, k1, k2);
+      const uint64_t K = tln_key_in_range(k0, k1, k2) ? tln_pack_key(k0, k1, k2) : TLN_KEY_EMPTY;
+      const uint32_t at = atomicAdd(&bk_hist[bk_bucket(K, slot_mask, shift)], 1u);
+      region[at].a = a;
+      region[at].b = make_uint4(__float_as_uint(bary[r]), (uint32_t)(4 * p + r), (uint32_t)K, (uint32_t)(K >> 32));
+    }
+  }
+}
+
+// LDS find-or-insert of key K in a bucket's table: entry, or -1 when the table is full
+__device__ __forceinline__ int bk_lds_insert(unsigned long long* hk, uint64_t K) {
+  uint32_t h = (uint32_t)(tln_mix64(K) >> 24) & (TLN_BK_HT - 1);
+  for (int probe = 0; probe < TLN_BK_HT; ++probe) {
+    unsigned long long cur = hk[h];
+    if (cur == TLN_KEY_EMPTY) {
+      cur = atomicCAS(&hk[h], (unsigned long long)TLN_KEY_EMPTY, (unsigned long long)K);
+      if (cur == TLN_KEY_EMPTY) cur = K;
+    }
+    if (cur == K) return (int)h;
+    h = (h + 1) & (TLN_BK_HT - 1);
+  }
+  return -1;
+}
+__device__ __forceinline__ int bk_lds_find(const unsigned long long* hk, uint64_t K) {
+  uint32_t h = (uint32_t)(tln_mix64(K) >> 24) & (TLN_BK_HT - 1);
+  for (int probe = 0; probe < TLN_BK_HT; ++probe) {
+    const unsigned long long cur = hk[h];
+    if (cur == K) return (int)h;
+    if (cur == TLN_KEY_EMPTY) return -1;
+    h = (h + 1) & (TLN_BK_HT - 1);
+  }
+  return -1;
+}
+
+// the rows of bucket b that thread tid walks: run tid of the bucket (run j = the bucket's records inside split block j's
+// region, contiguous; there are at most TLN_BK_THREADS split blocks)
+#define BK_KEEP 3   // rows a thread keeps in registers between its two sweeps
+struct BkRuns {
+  const TlnRec* at;
+  int total;
+};
+__device__ __forceinline__ void bk_runs_of(const uint32_t* __restrict__ off, const TlnRec* __restrict__ rec, int nblk,
+                                           int64_t rpb, int b, BkRuns& rn) {
+  const int j = threadIdx.x;
+  uint32_t s0 = 0, e0 = 0;
+  if (j < nblk) {
+    s0 = off[(size_t)b * nblk + j];
+    e0 = off[(size_t)(b + 1) * nblk + j];
+  }
+  rn.at = rec + (size_t)j * rpb + s0;
+  rn.total = (int)(e0 - s0);
+}
+__device__ __forceinline__ const TlnRec* bk_rec_of(const BkRuns& rn, int k) { return rn.at + k; }
+
+__global__ void __launch_bounds__(TLN_BK_THREADS) k_bk_insert(const TlnRec* __restrict__ rec, const uint32_t* __restrict__ off,
+                                                              int nblk, int64_t rpb, TableRef t,
+                                                              uint32_t* __restrict__ first_bits,
+                                                              uint32_t* __restrict__ bucket_rows) {
+  __shared__ unsigned long long hk[TLN_BK_HT];
+  __shared__ uint32_t htouch[TLN_BK_HT];
+  __shared__ uint32_t claimed[TLN_BK_HT];   // slots this workgroup has taken in this launch (open addressing, 0 = free)
+  __shared__ uint32_t wtmp[16];
+  const int tid = threadIdx.x, b = blockIdx.x;
+  for (int i = tid; i < TLN_BK_HT; i += TLN_BK_THREADS) {
+    hk[i] = TLN_KEY_EMPTY;
+    htouch[i] = 0xFFFFFFFFu;
+    claimed[i] = 0u;
+  }
+  // the thread's run (~4 rows): every offset load is issued before the first record load, every
+  // record load before the first LDS operation — the kernel is a chain of dependent memory round trips otherwise
+  BkRuns rn;
+  bk_runs_of(off, rec, nblk, rpb, b, rn);
+  uint4 kb[BK_KEEP];
+#pragma unroll
+  for (int k = 0; k < BK_KEEP; ++k)
+    if (k < rn.total) kb[k] = bk_rec_of(rn, k)->b;
+  __syncthreads();
+  auto touch_row = [&](const uint4& bb) {
+    const uint64_t K = ((uint64_t)bb.w << 32) | bb.z;
+    if (K == TLN_KEY_EMPTY) return;
+    const int he = bk_lds_insert(hk, K);
+    if (he < 0) atomicAdd(&t.ctr[CTR_PROBE_FAIL], 1);   // more distinct keys in one bucket than its table holds
+    else atomicMin(&htouch[he], bb.y);
+  };
+#pragma unroll
+  for (int k = 0; k < BK_KEEP; ++k)
+    if (k < rn.total) touch_row(kb[k]);
+  for (int k = BK_KEEP; k < rn.total; ++k) touch_row(bk_rec_of(rn, k)->b);
+  const uint32_t nrows = (uint32_t)rn.total;
+  uint32_t R;
+  bk_block_scan(nrows, wtmp, &R);   // (barriers: the table is complete behind it)
+  if (tid == 0) bucket_rows[b] = R;
+  // The distinct keys of the bucket, one global probe each.  Only this workgroup writes the bucket's slot range in
+  // this launch, so a key is entered with ONE plain 16-byte store; two of its threads heading for the same empty
+  // slot settle it in LDS (`claimed`), the loser moves on along its group.
+  for (int e = tid; e < TLN_BK_HT; e += TLN_BK_THREADS) {
+    const unsigned long long K = hk[e];
+    if (K == TLN_KEY_EMPTY) continue;
+    const uint32_t touch = htouch[e];
+    uint64_t slot = tln_mix64(K) & t.mask;
+    bool found = false, numbered = false;
+    for (int probe = 0; probe < TLN_MAX_PROBES && !found; ++probe) {
+      unsigned long long cur;
+      int val;
+      uint32_t tch;
+      load_slot(t, slot, cur, val, tch);
+      if (cur == K) {            // there from an earlier frame (keys are unique inside the frame's table)
+        numbered = val >= 0;
+        if (!numbered) t.slots[slot].touch = touch;   // was rejected by the capacity before: tried again
+        found = true;
+        break;
+      }
+      if (cur == TLN_KEY_EMPTY) {
+        // free in memory; free among this launch's claims too?
+        const uint32_t tag = (uint32_t)slot + 1u;
+        uint32_t h = (uint32_t)(slot * 0x9E3779B1u) & (TLN_BK_HT - 1);
+        bool mine = false;
+        for (int q = 0; q < TLN_BK_HT; ++q) {
+          uint32_t c = claimed[h];
+          if (c == 0u) {
+            c = atomicCAS(&claimed[h], 0u, tag);
+            if (c == 0u) {
+              mine = true;
+              break;
+            }
+          }
+          if (c == tag) break;   // another key of this bucket took the slot a moment ago
+          h = (h + 1) & (TLN_BK_HT - 1);
+        }
+        if (mine) {
+          ulonglong2 rec16;
+          rec16.x = K;
+          rec16.y = 0x00000000FFFFFFFFull | ((unsigned long long)touch << 32);   // vertex -1, first-touch row
+          *reinterpret_cast<ulonglong2*>(&t.slots[slot]) = rec16;
+          found = true;
+          break;
+        }
+      }
+      slot = tln_next_slot(slot);
+    }
+    if (!found) {
+      atomicAdd(&t.ctr[CTR_PROBE_FAIL], 1);
+    } else if (!numbered) {
+      atomicOr(&first_bits[touch >> 5], 1u << (touch & 31));   // k_bk_place numbers the keys by these bits
+    }
+  }
+}
+
+// The first-touch rows of the frame as a bit mask -> for every uint4 of the mask the number of set bits before it (one
+// workgroup: 15k words on a 120k-point frame), and the counters the host fetches while k_bk_place runs.  A key's
+// vertex index is then: vertices before the frame + set bits before its own first-touch row (what a scan over the rows
+// in order would hand out).  The occupancy count takes every key without a vertex as newly entered: keys turned away by
+// the capacity in an earlier frame count again, which only brings the next table rebuild (exact again) forward.
+__global__ void __launch_bounds__(TLN_BK_THREADS) k_bk_prefix(const uint32_t* __restrict__ first_bits, int nr_words,
+                                                              uint32_t* __restrict__ bits_pre, int32_t* __restrict__ ctr,
+                                                              int vold, int capacity) {
+  __shared__ uint32_t wtmp[16];
+  // a thread owns `per` consecutive uint4s of the mask: one pass over them for the sum, one block scan, one pass to write
+  const int nq = nr_words >> 2;
+  const int per = (nq + TLN_BK_THREADS - 1) / TLN_BK_THREADS;
+  const uint4* q4 = reinterpret_cast<const uint4*>(first_bits);
+  const int i0 = threadIdx.x * per, i1 = i0 + per < nq ? i0 + per : nq;
+  uint32_t mine = 0;
+  for (int i = i0; i < i1; ++i) {
+    const uint4 q = q4[i];
+    mine += (uint32_t)(__popc(q.x) + __popc(q.y) + __popc(q.z) + __popc(q.w));
+  }
+  uint32_t carry;
+  uint32_t run = bk_block_scan(mine, wtmp, &carry);
+  for (int i = i0; i < i1; ++i) {
+    const uint4 q = q4[i];
+    bits_pre[i] = run;
+    run += (uint32_t)(__popc(q.x) + __popc(q.y) + __popc(q.z) + __popc(q.w));
+  }
+  if (threadIdx.x == 0) {
+    const long long vnew = (long long)vold + carry;
+    ctr[CTR_VOLD] = vold;
+    ctr[CTR_NEW] = (int)carry;
+    ctr[CTR_NV] = (int)(vnew < capacity ? vnew : capacity);
+    ctr[CTR_OCCUPIED] += (int)carry;
+  }
+}
+
+__global__ void __launch_bounds__(TLN_BK_THREADS) k_bk_place(const TlnRec* __restrict__ rec, const uint32_t* __restrict__ off, int nblk,
+                                                  int B, int64_t rpb, TableRef t, const uint32_t* __restrict__ bucket_rows,
+                                                  int64_t rows, int32_t* __restrict__ vstart, int32_t* __restrict__ vcnt,
+                                                  int32_t* __restrict__ vstamp, int stamp, float* __restrict__ mean,
+                                                  int32_t* __restrict__ indices, float4* __restrict__ bin_xyzv,
+                                                  float* __restrict__ bin_w, int32_t* __restrict__ bin_row,
+                                                  int32_t* __restrict__ bin_vtx, const uint32_t* __restrict__ first_bits,
+                                                  const uint32_t* __restrict__ bits_pre, int vold, int capacity,
+                                                  int32_t* __restrict__ vkeys, int32_t* __restrict__ vslot) {
+  __shared__ unsigned long long hk[TLN_BK_HT];
+  __shared__ uint32_t hcnt[TLN_BK_HT];                 // rows per entry, then the entry's write cursor
+  extern __shared__ unsigned long long bk_dyn[];       // (dynamic: the block needs more than 64 KB of LDS in all)
+  unsigned long long (*hsum)[TLN_BK_HT] = reinterpret_cast<unsigned long long (*)[TLN_BK_HT]>(bk_dyn);   // [3][HT] fixed-point position sums; afterwards reused:
+  int* hstart = reinterpret_cast<int*>(&hsum[0][0]);   //   [HT] first bin position of the entry's vertex
+  int* hv = hstart + TLN_BK_HT;                        //   [HT] vertex of the entry (-1: none)
+  __shared__ uint32_t wtmp[16];
+  __shared__ uint32_t s_tail;
+  const int tid = threadIdx.x, b = blockIdx.x;
+  for (int i = tid; i < TLN_BK_HT; i += TLN_BK_THREADS) {
+    hk[i] = TLN_KEY_EMPTY;
+    hcnt[i] = 0;
+    hsum[0][i] = hsum[1][i] = hsum[2][i] = 0ull;
+  }
+  if (tid == 0) s_tail = 0;
+  // the thread's rows (bk_runs_of: offsets first, then every record, then the LDS work) and, meanwhile, the bins of this
+  // bucket: behind the rows of all buckets before it
+  BkRuns rn;
+  bk_runs_of(off, rec, nblk, rpb, b, rn);
+  uint32_t before = 0;
+  for (int i = tid; i < b; i += TLN_BK_THREADS) before += bucket_rows[i];
+  float4 ka[BK_KEEP];
+  uint4 kb[BK_KEEP];
+#pragma unroll
+  for (int k = 0; k < BK_KEEP; ++k)
+    if (k < rn.total) {
+      ka[k] = bk_rec_of(rn, k)->a;
+      kb[k] = bk_rec_of(rn, k)->b;
+    }
+  uint32_t bin0;
+  bk_block_scan(before, wtmp, &bin0);   // (barriers: the table is initialised behind it)
+  const uint32_t R = bucket_rows[b];
+  // sweep 1: rows per key, position sums
+  auto count_row = [&](const float4& a, const uint4& bb) {
+    const uint64_t K = ((uint64_t)bb.w << 32) | bb.z;
+    if (K == TLN_KEY_EMPTY) return;
+    const int he = bk_lds_insert(hk, K);
+    if (he < 0) return;   // (reported by k_bk_insert)
+    atomicAdd(&hcnt[he], 1u);
+    atomicAdd(&hsum[0][he], (unsigned long long)tln_fix20(a.x));
+    atomicAdd(&hsum[1][he], (unsigned long long)tln_fix20(a.y));
+    atomicAdd(&hsum[2][he], (unsigned long long)tln_fix20(a.z));
+  };
+#pragma unroll
+  for (int k = 0; k < BK_KEEP; ++k)
+    if (k < rn.total) count_row(ka[k], kb[k]);
+  for (int k = BK_KEEP; k < rn.total; ++k) count_row(bk_rec_of(rn, k)->a, bk_rec_of(rn, k)->b);
+  __syncthreads();
+  // the distinct keys: vertex (one global lookup), segment
+  constexpr int EPT = TLN_BK_HT / TLN_BK_THREADS;
+  int v[EPT];
+  uint32_t c[EPT];
+  long long sx[EPT], sy[EPT], sz[EPT];
+  uint32_t placed = 0;
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) {
+    const int e = tid * EPT + k;
+    c[k] = hcnt[e];
+    v[k] = -1;
+    sx[k] = (long long)hsum[0][e];
+    sy[k] = (long long)hsum[1][e];
+    sz[k] = (long long)hsum[2][e];
+    if (c[k]) {
+      const unsigned long long K = hk[e];
+      uint64_t slot = tln_mix64(K) & t.mask;
+      bool found = false;
+      uint32_t tch = 0;
+      for (int probe = 0; probe < TLN_MAX_PROBES; ++probe) {
+        unsigned long long cur;
+        load_slot(t, slot, cur, v[k], tch);
+        if (cur == K) {
+          found = true;
+          break;
+        }
+        if (cur == TLN_KEY_EMPTY) break;
+        slot = tln_next_slot(slot);
+      }
+      if (!found) v[k] = -1;
+      if (found && v[k] < 0) {
+        // a key without a vertex: its number = vertices before + first-touch rows before its own first-touch row
+        const uint32_t w = tch >> 5;
+        const uint4 q = reinterpret_cast<const uint4*>(first_bits)[w >> 2];
+        const uint32_t qw[4] = {q.x, q.y, q.z, q.w};
+        uint32_t rank = bits_pre[w >> 2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if ((uint32_t)i < (w & 3u)) rank += (uint32_t)__popc(qw[i]);
+          if ((uint32_t)i == (w & 3u)) rank += (uint32_t)__popc(qw[i] & ((1u << (tch & 31)) - 1u));
+        }
+        const long long vn = (long long)vold + rank;
+        if (vn < capacity) {
+          v[k] = (int)vn;
+          t.slots[slot].val = v[k];
+          vslot[vn] = (int32_t)slot;
+          int k0, k1, k2;
+          tln_unpack_key(K, k0, k1, k2);
+          *reinterpret_cast<int4*>(vkeys + 4 * vn) = make_int4(k0, k1, k2, -(k0 + k1 + k2));
+        } else {
+          t.slots[slot].touch = 0xFFFFFFFFu;  // stays un-numbered; may be retried by a later insertion
+        }
+      }
+    }
+    if (v[k] >= 0) placed += c[k];
+  }
+  uint32_t P;
+  uint32_t st = bk_block_scan(placed, wtmp, &P);   // (barriers: every sum has been read, hsum may be overwritten)
+  if (tid == 0 && R > P) atomicAdd(&t.ctr[CTR_OVERFLOW], (int)(R - P));
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) {
+    const int e = tid * EPT + k;
+    hcnt[e] = 0;
+    hv[e] = v[k];
+    hstart[e] = (int)(bin0 + st);
+    if (v[k] >= 0) {
+      const int vv = v[k];
+      vstart[vv] = (int)(bin0 + st);
+      vcnt[vv] = (int)c[k];
+      vstamp[vv] = stamp;
+      const double cnt = (double)c[k];
+      mean[3 * vv] = tln_unfix20(sx[k], cnt);
+      mean[3 * vv + 1] = tln_unfix20(sy[k], cnt);
+      mean[3 * vv + 2] = tln_unfix20(sz[k], cnt);
+      st += c[k];
+    }
+  }
+  __syncthreads();
+  // sweep 2: the rows move to their segments (any order inside), rows without a vertex behind the bucket's segments
+  auto place_row = [&](const float4& a, const uint4& bb) {
+    const uint64_t K = ((uint64_t)bb.w << 32) | bb.z;
+    int he = -1, vv = -1;
+    if (K != TLN_KEY_EMPTY) he = bk_lds_find(hk, K);
+    if (he >= 0) vv = hv[he];
+    uint32_t dest;
+    if (vv >= 0) dest = (uint32_t)hstart[he] + atomicAdd(&hcnt[he], 1u);
+    else dest = bin0 + P + atomicAdd(&s_tail, 1u);
+    bin_xyzv[dest] = a;
+    bin_w[dest] = __uint_as_float(bb.x);
+    bin_row[dest] = (int32_t)bb.y;
+    bin_vtx[dest] = vv;
+    indices[bb.y] = vv;
+  };
+#pragma unroll
+  for (int k = 0; k < BK_KEEP; ++k)
+    if (k < rn.total) place_row(ka[k], kb[k]);
+  for (int k = BK_KEEP; k < rn.total; ++k) place_row(bk_rec_of(rn, k)->a, bk_rec_of(rn, k)->b);
+  __syncthreads();
+}
+
 // accessors for pool.hip: the bins of the last distribute, if they describe (d_distributed, rows)
 bool tln_lat_bins(const tln_lattice* l, const float* d_distributed, int64_t rows, TlnBins* out) {
   if (!l || l->bins_rows != rows || rows <= 0 || l->bins_dist != d_distributed || l->dist_val_dim != 1) return false;
@@ -1445,6 +1956,8 @@ bool tln_lat_bins(const tln_lattice* l, const float* d_distributed, int64_t rows
   out->ctr = l->d_ctr;
   out->weights = l->bins_weights;
   out->subtract = l->bins_subtract;
+  out->vstamp = l->bins_stamped ? l->vstamp : nullptr;
+  out->stamp = l->bins_stamp;
   return true;
 }
 
@@ -1459,8 +1972,22 @@ static void publish_counts(tln_lattice* l) {
   l->occupied = l->h_ctr[CTR_OCCUPIED];
 }
 
-// first half: hash insertion + per-slot row counts, numbering; the vertex counters start their way to the host; then
-// (already behind that fetch) the bins.  d_distributed may be NULL: the [4N, 3+val_dim+1] rows are then not produced
+// which K1: the partitioned kernels (default) or the per-row-atomic ones (TLN_K1_LEGACY=1 / tln_distribute_config; also
+// taken for val_dim > 1 and for frames beyond 4M rows)
+static int g_k1_legacy = -1;
+static bool k1_partitioned() {
+  if (g_k1_legacy < 0) {
+    const char* e = getenv("TLN_K1_LEGACY");
+    g_k1_legacy = (e && e[0] == '1') ? 1 : 0;
+  }
+  return g_k1_legacy == 0;
+}
+extern "C" int tln_distribute_config(int legacy) {
+  g_k1_legacy = legacy ? 1 : 0;
+  return TLN_OK;
+}
+
+// first half: hash insertion, numbering, the bins; the vertex counters start their way to the host.  d_distributed may be NULL: the [4N, 3+val_dim+1] rows are then not produced
 // (the pool of the same frame reads the bins).
 extern "C" int tln_distribute_begin(tln_lattice_t* l, const float* d_positions, const float* d_values, int64_t n,
                                     int val_dim, int subtract_mean, float* d_distributed, int32_t* d_indices,
@@ -1487,23 +2014,65 @@ extern "C" int tln_distribute_begin(tln_lattice_t* l, const float* d_positions, 
   l->bins_rows = -1;
   l->csr_rows = -1;
   TableRef t = table_ref(l);
-  hipLaunchKernelGGL(k_distribute_insert, dim3((unsigned)tln_cdiv(4 * n, 256)), dim3(256), 0, s, d_positions, d_values, n,
-                     val_dim, l->scale[0], l->scale[1], l->scale[2], t, l->row_slot, d_weights, d_distributed,
-                     l->slot_cnt, l->row_rank);
-  TLN_LAUNCH_CHECK();
-  rc = number_new(l, rows, s);
-  if (rc) return rc;
-  TLN_HIP(hipMemcpyAsync(l->h_ctr, l->d_ctr, CTR_COUNT * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-  if (!l->ctr_event) TLN_HIP(hipEventCreateWithFlags(&l->ctr_event, hipEventDisableTiming));
-  TLN_HIP(hipEventRecord(l->ctr_event, s));
-  // the bins: the host does not know the new vertex count yet; the kernels read it and stride over the vertices
-  hipLaunchKernelGGL(k_bins_alloc, dim3(256), dim3(256), 0, s, l->d_ctr, l->vslot, l->slot_cnt, l->vcnt, l->vstart);
-  hipLaunchKernelGGL(k_bins_scatter, dim3((unsigned)tln_cdiv(rows, 256)), dim3(256), 0, s, t, l->row_slot, l->row_rank, rows,
-                     d_positions, d_values, val_dim, d_weights, l->slot_cnt, l->vstart, d_indices, l->bin_xyzv, l->bin_w,
-                     l->bin_row, l->bin_vtx);
-  if (subtract_mean)
-    hipLaunchKernelGGL(k_bins_mean, dim3(8192), dim3(256), 0, s, l->d_ctr, l->vcnt, l->vstart, l->bin_xyzv, l->mean);
-  TLN_LAUNCH_CHECK();
+  if (k1_partitioned() && val_dim <= 1 && rows <= (int64_t)TLN_BK_MAXB * TLN_BK_ROWS) {
+    // partitioned K1 (k_bk_*): four launches, no global atomic per row
+    static const int env_rows = getenv("TLN_BK_ROWS") ? atoi(getenv("TLN_BK_ROWS")) : 0;   // measurement overrides
+    static const int env_ppb = getenv("TLN_BK_PPB") ? atoi(getenv("TLN_BK_PPB")) : 0;
+    const int bucket_rows = env_rows >= 128 && env_rows <= 8192 ? env_rows : TLN_BK_ROWS;
+    int B = TLN_BK_MINB;
+    while ((int64_t)B * bucket_rows < rows && B < l->bk_maxb) B <<= 1;
+    int64_t ppb = env_ppb >= 256 && env_ppb <= 4096 ? (env_ppb & ~255) : 256;
+    if (tln_cdiv(n, ppb) > TLN_BK_SPLIT_BLOCKS) ppb = (tln_cdiv(n, TLN_BK_SPLIT_BLOCKS) + 255) & ~(int64_t)255;
+    const int nblk = (int)tln_cdiv(n, ppb);
+    const int64_t rpb = 4 * ppb;
+    TLN_REQUIRE(B <= l->bk_maxb && (int64_t)nblk * rpb <= l->rec_cap && nblk <= TLN_BK_SPLIT_BLOCKS,
+                "bucket geometry out of range (B %d, %d split blocks)", B, nblk);
+    const int nr_words = (int)(tln_cdiv(rows, 128) * 4);   // bit mask of the rows, whole uint4s
+    int slot_bits = 0, b_bits = 0;
+    while ((1ll << slot_bits) < l->nslots) ++slot_bits;
+    while ((1 << b_bits) < B) ++b_bits;
+    TLN_REQUIRE((int64_t)B * TLN_SLOT_GROUP <= l->nslots, "more buckets (%d) than slot groups", B);
+    hipLaunchKernelGGL(k_bk_split, dim3((unsigned)nblk), dim3(256), (size_t)B * sizeof(uint32_t), s, d_positions, d_values, n,
+                       val_dim, l->scale[0], l->scale[1], l->scale[2], (int)ppb, B, l->rec, l->bk_off, d_weights,
+                       d_distributed, t.mask, slot_bits - b_bits, nr_words, l->first_flag, l->d_ctr);
+    hipLaunchKernelGGL(k_bk_insert, dim3((unsigned)B), dim3(TLN_BK_THREADS), 0, s, l->rec, l->bk_off, nblk, rpb, t, l->first_flag,
+                       l->bucket_rows);
+    hipLaunchKernelGGL(k_bk_prefix, dim3(1), dim3(TLN_BK_THREADS), 0, s, l->first_flag, nr_words, l->bits_pre, l->d_ctr,
+                       (int)l->nr_vertices, (int)l->capacity);
+    TLN_LAUNCH_CHECK();
+    TLN_HIP(hipMemcpyAsync(l->h_ctr, l->d_ctr, CTR_COUNT * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (!l->ctr_event) TLN_HIP(hipEventCreateWithFlags(&l->ctr_event, hipEventDisableTiming));
+    TLN_HIP(hipEventRecord(l->ctr_event, s));
+    ++l->bins_stamp;
+    l->bins_stamped = true;
+    const size_t place_lds = (size_t)3 * TLN_BK_HT * sizeof(unsigned long long);
+    TLN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bk_place), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)place_lds));
+    hipLaunchKernelGGL(k_bk_place, dim3((unsigned)B), dim3(TLN_BK_THREADS), place_lds, s, l->rec, l->bk_off, nblk, B, rpb, t,
+                       l->bucket_rows, rows, l->vstart, l->vcnt, l->vstamp, l->bins_stamp, l->mean, d_indices, l->bin_xyzv,
+                       l->bin_w, l->bin_row, l->bin_vtx, l->first_flag, l->bits_pre, (int)l->nr_vertices, (int)l->capacity,
+                       l->vkeys, l->vslot);
+    TLN_LAUNCH_CHECK();
+  } else {
+    l->bins_stamped = false;
+    hipLaunchKernelGGL(k_distribute_insert, dim3((unsigned)tln_cdiv(4 * n, 256)), dim3(256), 0, s, d_positions, d_values, n,
+                       val_dim, l->scale[0], l->scale[1], l->scale[2], t, l->row_slot, d_weights, d_distributed,
+                       l->slot_cnt, l->row_rank);
+    TLN_LAUNCH_CHECK();
+    rc = number_new(l, rows, s);
+    if (rc) return rc;
+    TLN_HIP(hipMemcpyAsync(l->h_ctr, l->d_ctr, CTR_COUNT * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (!l->ctr_event) TLN_HIP(hipEventCreateWithFlags(&l->ctr_event, hipEventDisableTiming));
+    TLN_HIP(hipEventRecord(l->ctr_event, s));
+    // the bins: the host does not know the new vertex count yet; the kernels read it and stride over the vertices
+    hipLaunchKernelGGL(k_bins_alloc, dim3(256), dim3(256), 0, s, l->d_ctr, l->vslot, l->slot_cnt, l->vcnt, l->vstart);
+    hipLaunchKernelGGL(k_bins_scatter, dim3((unsigned)tln_cdiv(rows, 256)), dim3(256), 0, s, t, l->row_slot, l->row_rank, rows,
+                       d_positions, d_values, val_dim, d_weights, l->slot_cnt, l->vstart, d_indices, l->bin_xyzv, l->bin_w,
+                       l->bin_row, l->bin_vtx);
+    if (subtract_mean)
+      hipLaunchKernelGGL(k_bins_mean, dim3(8192), dim3(256), 0, s, l->d_ctr, l->vcnt, l->vstart, l->bin_xyzv, l->mean);
+    TLN_LAUNCH_CHECK();
+  }
   l->dist_pending = true;
   l->dist_pos = d_positions;
   l->dist_out = d_distributed;

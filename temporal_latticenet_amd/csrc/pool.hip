@@ -338,10 +338,11 @@ __global__ void __launch_bounds__(256) k_pool_bins_finalize(unsigned long long* 
   const int64_t v = gid / cout;
   const int c = (int)(gid - v * cout);
   if (v >= nv) return;
-  const int st = bn.vstart[v];
-  int count = bn.vcnt[v];
+  const bool visited = bn.vstamp == nullptr || bn.vstamp[v] == bn.stamp;
+  const int st = visited ? bn.vstart[v] : 0;
+  int count = visited ? bn.vcnt[v] : 0;
   const bool crossing = v == 0 || (count > 0 && (st >> 6) != ((st + count - 1) >> 6));
-  if (v == 0) count += (int)(rows - bn.ctr[6]);   // the rows without a vertex fold into vertex 0
+  if (v == 0) count += bn.ctr[2];                  // the rows without a vertex (counted by K1) fold into vertex 0
   if (count > 0 && !crossing) return;              // written by k_pool_bins
   float val = 0.0f, bary = 0.0f;
   int32_t argout = -1;

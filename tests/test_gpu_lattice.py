@@ -225,3 +225,66 @@ def test_scan_ordered_cloud_and_the_bins(gpu):
         want = O.pointnet_pool(od, oi, tab.nr_vertices, Ws, Bs, 4)
         assert np.array_equal(out.cpu().numpy(), want.numpy())
     assert (oi < 0).sum() > 0, "the fixture is meant to overflow on the second frame"
+
+
+@pytest.fixture
+def k1_legacy():
+    """the per-row-atomic K1 kernels for the duration of a test (the partitioned ones are the default)"""
+    from temporal_latticenet_amd import _lib
+    lib = _lib.lib()
+    lib.tln_distribute_config(1)
+    yield lib
+    lib.tln_distribute_config(0)
+
+
+@pytest.mark.parametrize("n,sigma", [(20000, 1.0), (120000, 0.6)])
+def test_legacy_k1_matches_oracle(gpu, k1_legacy, n, sigma):
+    """tln_distribute_config(1): k_distribute_insert + the k_bins_* kernels (also what val_dim > 1 takes)"""
+    seq = make_sequence(n, 3, seed=7)
+    lat, tab, outs = _run_sequence(gpu, seq, sigma, 1 << 18)
+    for d, i, w, od, oi, ow in outs:
+        assert np.array_equal(i, oi) and np.array_equal(w, ow)
+        np.testing.assert_allclose(d, od, rtol=0, atol=2e-5)
+    assert np.array_equal(lat.keys().cpu().numpy(), tab.keys)
+
+
+@pytest.mark.parametrize("n,sigma,capacity,val_dim", [
+    (50, 0.6, 1 << 12, 1),          # fewer rows than one bucket workgroup has threads
+    (9000, 0.3, 1 << 16, 1),
+    (60000, 0.8, 12000, 1),         # the capacity turns keys away (retried, and turned away again, by the next frame)
+    (30000, 0.5, 1 << 16, 0),       # positions only
+    (300000, 0.05, 1 << 20, 1),     # nearly every row its own vertex: the buckets' LDS tables at their fullest
+])
+def test_partitioned_and_legacy_k1_agree(gpu, n, sigma, capacity, val_dim):
+    """The two K1 variants on the same three frames: indices, weights, rows, keys, overflow count, neighbour table and
+    the PointNet pool on their bins are equal bit for bit (the partitioned kernels order the rows inside a vertex's bin
+    differently on every run; nothing may depend on it)."""
+    from temporal_latticenet_amd import _lib, ops
+    from temporal_latticenet_amd.lattice import Lattice
+    lib = _lib.lib()
+    seq = make_sequence(n, 3, seed=n % 97)
+    g = torch.Generator().manual_seed(5)
+    Ws = [torch.randn(16, 4, generator=g) * 0.5, torch.randn(32, 16, generator=g) * 0.3, torch.randn(64, 32, generator=g) * 0.3]
+    Bs = [torch.randn(16, generator=g) * 0.1, torch.randn(32, generator=g) * 0.1, torch.randn(64, generator=g) * 0.1]
+    got = {}
+    for legacy in (0, 1):
+        lib.tln_distribute_config(legacy)
+        try:
+            lat = Lattice.from_params([sigma] * 3, capacity)
+            res = []
+            for t, (pos, val) in enumerate(seq):
+                v = torch.from_numpy(val).to(gpu) if val_dim else None
+                d, i, w = lat.distribute(torch.from_numpy(pos).to(gpu), v, reset_hashmap=(t == 0))
+                item = [d.cpu().numpy(), i.cpu().numpy(), w.cpu().numpy(), lat.nr_lattice_vertices(), lat.overflow_rows()]
+                if val_dim:
+                    item.append(ops.pointnet_pool(lat, d, i, [x.to(gpu) for x in Ws], [x.to(gpu) for x in Bs], 4).cpu().numpy())
+                res.append(item)
+            got[legacy] = (res, lat.keys().cpu().numpy(), lat.neighbour_table().cpu().numpy())
+        finally:
+            lib.tln_distribute_config(0)
+    for a, b in zip(got[0][0], got[1][0]):
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+    assert np.array_equal(got[0][1], got[1][1]) and np.array_equal(got[0][2], got[1][2])
+    if capacity == 12000:
+        assert got[0][0][-1][4] > 0, "the fixture is meant to overflow"
