@@ -80,6 +80,11 @@ int tln_lattice_csr(tln_lattice_t* l, int32_t* d_order, int32_t* d_sorted_vertex
                     int64_t* rows_out, void* stream);
 
 /* ---- K2 PointNet pool: PointNetSeqModule.forward lm:448-530 --------------------------- */
+/* Kernel choice for the 4-16-32-64 PointNet MLP pooled from the bins of the frame's distribute (process-wide):
+ * 0 = all-VALU fma chains (default), 1 = layers 2 and 3 on the matrix cores (v_mfma_f32_32x32x2_f32 accumulates as the
+ * same ascending fma chain: identical bits; also env TLN_POOL_MFMA=1).  A test / measurement switch. */
+int tln_pool_config(int mfma);
+
 /* per-row MLP (nr_layers linears, ReLU between) on distributed[:, :cin] then segment-max by
  * vertex with argmax, barycentric-of-argmax (with the lm:514 clamp quirk), <min_points mask.
  * d_w[i] is torch Linear weight [cout_i, cin_i], d_b[i] bias.  nr_layers == 0 => no MLP.

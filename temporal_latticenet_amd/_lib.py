@@ -73,6 +73,7 @@ _PROTOS = {
     "tln_lattice_overflow_rows": (_i64, [_vp]),
     "tln_lattice_drop_bins": (_i, [_vp]),
     "tln_distribute_config": (_i, [_i]),
+    "tln_pool_config": (_i, [_i]),
     "tln_lattice_keys": (_i, [_vp, _vp, _i64, _vp]),
     "tln_lattice_insert_keys": (_i, [_vp, _vp, _i64, _vp, _vp]),
     "tln_distribute": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp]),

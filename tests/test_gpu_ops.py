@@ -354,3 +354,41 @@ def test_direct_and_tiled_gemm_agree_on_random_shapes(gpu):
             case, cin, N, taps, M, two, nk, groups, err)
         sa, sb = a._tln_stats.cpu().numpy(), b._tln_stats.cpu().numpy()
         np.testing.assert_allclose(sa, sb, rtol=1e-4, atol=1e-3 * scale * scale)
+
+
+@pytest.mark.parametrize("cin", [4, 3])
+def test_pool_on_the_matrix_cores_is_bitwise_the_fma_chain(gpu, cin):
+    """tln_pool_config(1): layers 2 and 3 of the 16-32-64 PointNet MLP as v_mfma_f32_32x32x2_f32 products.  The MFMA adds
+    its k terms as one ascending chain of fp32 fmas, so the pooled tensor (values, arg-max rows' barycentric weights,
+    min_points mask) equals the all-VALU kernel's and the oracle's bit for bit — on two frames, the second one with
+    vertices that have no rows, rows without a vertex (capacity overflow) and runs crossing 64-row chunks."""
+    from temporal_latticenet_amd import _lib, ops
+    from temporal_latticenet_amd.lattice import Lattice
+    from temporal_latticenet_amd.synthetic import make_sequence
+    from oracle import permuto as P
+    lib = _lib.lib()
+    seq = make_sequence(50000, 2, seed=17)
+    g = torch.Generator().manual_seed(cin)
+    Ws = [torch.randn(16, cin, generator=g) * 0.5, torch.randn(32, 16, generator=g) * 0.3, torch.randn(64, 32, generator=g) * 0.3]
+    Bs = [torch.randn(16, generator=g) * 0.1, torch.randn(32, generator=g) * 0.1, torch.randn(64, generator=g) * 0.1]
+    got = {}
+    for mfma in (1, 0):
+        lib.tln_pool_config(mfma)
+        try:
+            lat = Lattice.from_params([0.7] * 3, 9000)
+            tab = P.VertexTable(3, 9000)
+            outs = []
+            for t, (pos, val) in enumerate(seq):
+                d, i, w = lat.distribute(torch.from_numpy(pos).to(gpu), torch.from_numpy(val).to(gpu), reset_hashmap=(t == 0))
+                outs.append(ops.pointnet_pool(lat, d, i, [x.to(gpu) for x in Ws], [x.to(gpu) for x in Bs], 4).cpu().numpy())
+                if mfma:
+                    od, oi, ow = O.distribute(tab, pos, val, [0.7] * 3)
+                    if cin == 4:     # (the oracle's MLP takes every column but the weight; 3 inputs: the two kernels only)
+                        want = O.pointnet_pool(od, oi, tab.nr_vertices, Ws, Bs, 4)
+                        assert np.array_equal(outs[-1], want.numpy()), "frame %d" % t
+            got[mfma] = outs
+        finally:
+            lib.tln_pool_config(0)
+    assert (oi < 0).sum() > 0, "the fixture is meant to overflow on the second frame"
+    for a, b in zip(got[0], got[1]):
+        assert np.array_equal(a, b)
