@@ -77,9 +77,7 @@ __device__ __forceinline__ float tln_unfix20(long long sum, double cnt) {
 struct tln_lattice;
 struct TlnBins {
   const float4* xyzv;      // [rows] position, value — grouped by vertex, rows without a vertex last
-  const float* w;          // [rows] barycentric weight
-  const int32_t* row;      // [rows] row id (4 * point + simplex vertex)
-  const int32_t* vtx;      // [rows] vertex index, -1 = none
+  const uint4* meta;       // [rows] {barycentric weight (bits), row id (4 * point + simplex vertex), vertex index or -1, 0}
   const int32_t* vstart;   // [V] first bin position of a vertex
   const int32_t* vcnt;     // [V] rows of the frame on a vertex
   const float* mean;       // [V][3] local mean of the frame (valid when subtract)

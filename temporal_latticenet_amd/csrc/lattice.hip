@@ -71,6 +71,7 @@ struct tln_lattice {
   int32_t* vkeys = nullptr;  // [capacity][4]
   int32_t* d_ctr = nullptr;
   int32_t* h_ctr = nullptr;
+  int32_t* h_ctr_dev = nullptr;   // the same pinned words as the device addresses them
   int64_t nr_vertices = 0, overflow_rows = 0;
   int64_t occupied = 0;  // claimed slots (numbered vertices + keys rejected by the capacity)
   // tables (owned)
@@ -116,9 +117,7 @@ struct tln_lattice {
   int32_t* vcnt = nullptr;        // [capacity] rows of the frame on vertex v
   int32_t* vstart = nullptr;      // [capacity] first bin position of vertex v
   float4* bin_xyzv = nullptr;     // [rows_cap] position, value
-  float* bin_w = nullptr;         // [rows_cap] barycentric weight
-  int32_t* bin_row = nullptr;     // [rows_cap] row id
-  int32_t* bin_vtx = nullptr;     // [rows_cap] vertex (-1: none)
+  uint4* bin_meta = nullptr;      // [rows_cap] {barycentric weight (bits), row id, vertex (-1: none), 0}
   int64_t bins_rows = -1;         // rows of the frame the bins hold (-1: none)
   // ---- partitioned K1 (k_bk_*): the rows of a frame split by key hash into buckets, one workgroup per bucket
   struct TlnRec* rec = nullptr;   // [rec_cap] 32-byte row records, grouped by (split block, bucket)
@@ -185,14 +184,14 @@ static int ensure_rows(tln_lattice* l, int64_t rows) {
   int64_t cap = 1;
   while (cap < rows) cap <<= 1;
   void* ptrs[] = {l->row_slot, l->block_cnt, l->sk_in, l->sk_out, l->sv_in, l->sv_out, l->sort_temp, l->pieces,
-                  l->row_rank, l->bin_xyzv, l->bin_w, l->bin_row, l->bin_vtx, l->rec, l->bk_off, l->first_flag,
+                  l->row_rank, l->bin_xyzv, l->bin_meta, l->rec, l->bk_off, l->first_flag,
                   l->bucket_rows, l->bits_pre};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   l->row_slot = l->block_cnt = l->sk_in = l->sk_out = l->sv_in = l->sv_out = nullptr;
-  l->row_rank = l->bin_row = l->bin_vtx = nullptr;
+  l->row_rank = nullptr;
   l->bin_xyzv = nullptr;
-  l->bin_w = nullptr;
+  l->bin_meta = nullptr;
   l->rec = nullptr;
   l->bk_off = l->first_flag = l->bucket_rows = l->bits_pre = nullptr;
   l->rec_cap = 0;
@@ -211,9 +210,7 @@ static int ensure_rows(tln_lattice* l, int64_t rows) {
   if (l->level == 0) {
     TLN_HIP(hipMalloc(&l->row_rank, cap * sizeof(int32_t)));
     TLN_HIP(hipMalloc(&l->bin_xyzv, cap * sizeof(float4)));
-    TLN_HIP(hipMalloc(&l->bin_w, cap * sizeof(float)));
-    TLN_HIP(hipMalloc(&l->bin_row, cap * sizeof(int32_t)));
-    TLN_HIP(hipMalloc(&l->bin_vtx, cap * sizeof(int32_t)));
+    TLN_HIP(hipMalloc(&l->bin_meta, cap * sizeof(uint4)));
     // partitioned K1: the split blocks' record regions (each rounded up to whole blocks of points), the bucket offsets
     // of every split block, the first-touch flags (zero between frames) and the bucket directories
     l->rec_cap = cap + cap / 128 + 2048;
@@ -257,7 +254,8 @@ static int lattice_alloc(tln_lattice** out, int pos_dim, const double* sigmas, i
   TLN_HIP(hipMalloc(&l->slots, ns * sizeof(TlnSlot)));
   TLN_HIP(hipMalloc(&l->vkeys, capacity * 4 * sizeof(int32_t)));
   TLN_HIP(hipMalloc(&l->d_ctr, CTR_COUNT * sizeof(int32_t)));
-  TLN_HIP(hipHostMalloc(&l->h_ctr, CTR_COUNT * sizeof(int32_t)));
+  TLN_HIP(hipHostMalloc(&l->h_ctr, CTR_COUNT * sizeof(int32_t), hipHostMallocMapped));
+  TLN_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&l->h_ctr_dev), l->h_ctr, 0));
   TLN_HIP(hipMalloc(&l->seg_start, (capacity + 2) * sizeof(int32_t)));
   TLN_HIP(hipMalloc(&l->mean, capacity * 3 * sizeof(float)));
   if (level == 0) {
@@ -354,7 +352,7 @@ extern "C" int tln_lattice_destroy(tln_lattice_t* l) {
   void* ptrs[] = {l->slots, l->vkeys, l->d_ctr, l->nbr, l->c2f, l->f2c,
                   l->row_slot, l->block_cnt, l->sk_in, l->sk_out, l->sv_in, l->sv_out, l->sort_temp,
                   l->seg_start, l->pool_packed, l->mean, l->pieces, l->slot_cnt, l->vslot, l->vcnt, l->vstart,
-                  l->row_rank, l->bin_xyzv, l->bin_w, l->bin_row, l->bin_vtx, l->rec, l->bk_off, l->first_flag,
+                  l->row_rank, l->bin_xyzv, l->bin_meta, l->rec, l->bk_off, l->first_flag,
                   l->bucket_rows, l->bits_pre, l->vstamp};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -1426,8 +1424,7 @@ __global__ void __launch_bounds__(256) k_bins_scatter(TableRef t, const int32_t*
                                                       int val_dim, const float* __restrict__ weights,
                                                       uint32_t* __restrict__ slot_cnt, const int32_t* __restrict__ vstart,
                                                       int32_t* __restrict__ indices,
-                                                      float4* __restrict__ bin_xyzv, float* __restrict__ bin_w,
-                                                      int32_t* __restrict__ bin_row, int32_t* __restrict__ bin_vtx) {
+                                                      float4* __restrict__ bin_xyzv, uint4* __restrict__ bin_meta) {
   const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= rows) return;
   const int slot = row_slot[row];
@@ -1449,9 +1446,7 @@ __global__ void __launch_bounds__(256) k_bins_scatter(TableRef t, const int32_t*
     dest = t.ctr[CTR_CURSOR] + atomicAdd(&t.ctr[CTR_TAIL], 1);
   }
   bin_xyzv[dest] = make_float4(x, y, z, val_dim == 1 ? val[p] : 0.f);
-  bin_w[dest] = weights[row];
-  bin_row[dest] = (int32_t)row;
-  bin_vtx[dest] = v;
+  bin_meta[dest] = make_uint4(__float_as_uint(weights[row]), (uint32_t)row, (uint32_t)v, 0u);
 }
 
 // one WAVE per vertex: its rows are contiguous in the bins; positions summed in fixed point (int64: exact, any order)
@@ -1758,7 +1753,7 @@ __global__ void __launch_bounds__(TLN_BK_THREADS) k_bk_insert(const TlnRec* __re
 // the capacity in an earlier frame count again, which only brings the next table rebuild (exact again) forward.
 __global__ void __launch_bounds__(TLN_BK_THREADS) k_bk_prefix(const uint32_t* __restrict__ first_bits, int nr_words,
                                                               uint32_t* __restrict__ bits_pre, int32_t* __restrict__ ctr,
-                                                              int vold, int capacity) {
+                                                              int vold, int capacity, int32_t* __restrict__ host_ctr) {
   __shared__ uint32_t wtmp[16];
   // a thread owns `per` consecutive uint4s of the mask: one pass over them for the sum, one block scan, one pass to write
   const int nq = nr_words >> 2;
@@ -1783,6 +1778,8 @@ __global__ void __launch_bounds__(TLN_BK_THREADS) k_bk_prefix(const uint32_t* __
     ctr[CTR_NEW] = (int)carry;
     ctr[CTR_NV] = (int)(vnew < capacity ? vnew : capacity);
     ctr[CTR_OCCUPIED] += (int)carry;
+    // the host's copy (pinned, mapped): written from here instead of a copy kernel between this launch and k_bk_place
+    for (int i = 0; i < CTR_COUNT; ++i) host_ctr[i] = ctr[i];
   }
 }
 
@@ -1791,8 +1788,7 @@ __global__ void __launch_bounds__(TLN_BK_THREADS) k_bk_place(const TlnRec* __res
                                                   int64_t rows, int32_t* __restrict__ vstart, int32_t* __restrict__ vcnt,
                                                   int32_t* __restrict__ vstamp, int stamp, float* __restrict__ mean,
                                                   int32_t* __restrict__ indices, float4* __restrict__ bin_xyzv,
-                                                  float* __restrict__ bin_w, int32_t* __restrict__ bin_row,
-                                                  int32_t* __restrict__ bin_vtx, const uint32_t* __restrict__ first_bits,
+                                                  uint4* __restrict__ bin_meta, const uint32_t* __restrict__ first_bits,
                                                   const uint32_t* __restrict__ bits_pre, int vold, int capacity,
                                                   int32_t* __restrict__ vkeys, int32_t* __restrict__ vslot) {
   __shared__ unsigned long long hk[TLN_BK_HT];
@@ -1931,9 +1927,7 @@ __global__ void __launch_bounds__(TLN_BK_THREADS) k_bk_place(const TlnRec* __res
     if (vv >= 0) dest = (uint32_t)hstart[he] + atomicAdd(&hcnt[he], 1u);
     else dest = bin0 + P + atomicAdd(&s_tail, 1u);
     bin_xyzv[dest] = a;
-    bin_w[dest] = __uint_as_float(bb.x);
-    bin_row[dest] = (int32_t)bb.y;
-    bin_vtx[dest] = vv;
+    bin_meta[dest] = make_uint4(bb.x, bb.y, (uint32_t)vv, 0u);
     indices[bb.y] = vv;
   };
 #pragma unroll
@@ -1947,9 +1941,7 @@ __global__ void __launch_bounds__(TLN_BK_THREADS) k_bk_place(const TlnRec* __res
 bool tln_lat_bins(const tln_lattice* l, const float* d_distributed, int64_t rows, TlnBins* out) {
   if (!l || l->bins_rows != rows || rows <= 0 || l->bins_dist != d_distributed || l->dist_val_dim != 1) return false;
   out->xyzv = l->bin_xyzv;
-  out->w = l->bin_w;
-  out->row = l->bin_row;
-  out->vtx = l->bin_vtx;
+  out->meta = l->bin_meta;
   out->vstart = l->vstart;
   out->vcnt = l->vcnt;
   out->mean = l->mean;
@@ -2038,9 +2030,8 @@ extern "C" int tln_distribute_begin(tln_lattice_t* l, const float* d_positions, 
     hipLaunchKernelGGL(k_bk_insert, dim3((unsigned)B), dim3(TLN_BK_THREADS), 0, s, l->rec, l->bk_off, nblk, rpb, t, l->first_flag,
                        l->bucket_rows);
     hipLaunchKernelGGL(k_bk_prefix, dim3(1), dim3(TLN_BK_THREADS), 0, s, l->first_flag, nr_words, l->bits_pre, l->d_ctr,
-                       (int)l->nr_vertices, (int)l->capacity);
+                       (int)l->nr_vertices, (int)l->capacity, l->h_ctr_dev);
     TLN_LAUNCH_CHECK();
-    TLN_HIP(hipMemcpyAsync(l->h_ctr, l->d_ctr, CTR_COUNT * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     if (!l->ctr_event) TLN_HIP(hipEventCreateWithFlags(&l->ctr_event, hipEventDisableTiming));
     TLN_HIP(hipEventRecord(l->ctr_event, s));
     ++l->bins_stamp;
@@ -2050,7 +2041,7 @@ extern "C" int tln_distribute_begin(tln_lattice_t* l, const float* d_positions, 
                                 (int)place_lds));
     hipLaunchKernelGGL(k_bk_place, dim3((unsigned)B), dim3(TLN_BK_THREADS), place_lds, s, l->rec, l->bk_off, nblk, B, rpb, t,
                        l->bucket_rows, rows, l->vstart, l->vcnt, l->vstamp, l->bins_stamp, l->mean, d_indices, l->bin_xyzv,
-                       l->bin_w, l->bin_row, l->bin_vtx, l->first_flag, l->bits_pre, (int)l->nr_vertices, (int)l->capacity,
+                       l->bin_meta, l->first_flag, l->bits_pre, (int)l->nr_vertices, (int)l->capacity,
                        l->vkeys, l->vslot);
     TLN_LAUNCH_CHECK();
   } else {
@@ -2067,8 +2058,8 @@ extern "C" int tln_distribute_begin(tln_lattice_t* l, const float* d_positions, 
     // the bins: the host does not know the new vertex count yet; the kernels read it and stride over the vertices
     hipLaunchKernelGGL(k_bins_alloc, dim3(256), dim3(256), 0, s, l->d_ctr, l->vslot, l->slot_cnt, l->vcnt, l->vstart);
     hipLaunchKernelGGL(k_bins_scatter, dim3((unsigned)tln_cdiv(rows, 256)), dim3(256), 0, s, t, l->row_slot, l->row_rank, rows,
-                       d_positions, d_values, val_dim, d_weights, l->slot_cnt, l->vstart, d_indices, l->bin_xyzv, l->bin_w,
-                       l->bin_row, l->bin_vtx);
+                       d_positions, d_values, val_dim, d_weights, l->slot_cnt, l->vstart, d_indices, l->bin_xyzv,
+                       l->bin_meta);
     if (subtract_mean)
       hipLaunchKernelGGL(k_bins_mean, dim3(8192), dim3(256), 0, s, l->d_ctr, l->vcnt, l->vstart, l->bin_xyzv, l->mean);
     TLN_LAUNCH_CHECK();

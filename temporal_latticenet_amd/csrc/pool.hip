@@ -221,7 +221,8 @@ __global__ void __launch_bounds__(256) k_pool_bins(const TlnBins bn, int64_t row
   if (lane < cnt) {
     const int64_t at = j0 + lane;
     float4 q = bn.xyzv[at];
-    const int v = bn.vtx[at];
+    const uint4 meta = bn.meta[at];
+    const int v = (int)meta.z;
     int flags = 0, vv = 0;      // rows without a vertex fold into vertex 0 with their raw position (lm:480)
     if (v >= 0) {
       vv = v;
@@ -255,8 +256,8 @@ __global__ void __launch_bounds__(256) k_pool_bins(const TlnBins bn, int64_t row
 #pragma unroll
     for (int c = 0; c < HL; ++c) tile[lane * TS + c] = hl[c];
     tv[lane] = vv;
-    tr[lane] = bn.row[at];
-    tw[lane] = bn.w[at];
+    tr[lane] = (int)meta.y;
+    tw[lane] = __uint_as_float(meta.x);
     tf[lane] = flags;
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -413,9 +414,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     r.q = make_float4(0.f, 0.f, 0.f, 0.f);
     if (ch < chunks && at < rows) {
       r.q = bn.xyzv[at];
-      r.v = bn.vtx[at];
-      r.row = bn.row[at];
-      r.w = bn.w[at];
+      const uint4 meta = bn.meta[at];
+      r.v = (int)meta.z;
+      r.row = (int)meta.y;
+      r.w = __uint_as_float(meta.x);
     }
   };
   auto load_vtx = [&](const RowIn& r, VtxIn& g) {
