@@ -75,9 +75,12 @@ __device__ __forceinline__ float tln_unfix20(long long sum, double cnt) {
 
 // the vertex bins of the last distribute (lattice.hip) as the pool (pool.hip) sees them
 struct tln_lattice;
+struct __attribute__((aligned(16))) TlnBinRec {
+  float4 a;   // position, value
+  uint4 m;    // barycentric weight (bits), row id (4 * point + simplex vertex), vertex index or -1, 0
+};
 struct TlnBins {
-  const float4* xyzv;      // [rows] position, value — grouped by vertex, rows without a vertex last
-  const uint4* meta;       // [rows] {barycentric weight (bits), row id (4 * point + simplex vertex), vertex index or -1, 0}
+  const TlnBinRec* rec;    // [rows] the frame's rows grouped by vertex (rows without a vertex in between)
   const int32_t* vstart;   // [V] first bin position of a vertex
   const int32_t* vcnt;     // [V] rows of the frame on a vertex
   const float* mean;       // [V][3] local mean of the frame (valid when subtract)

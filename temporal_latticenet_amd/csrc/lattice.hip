@@ -116,8 +116,7 @@ struct tln_lattice {
   int32_t* row_rank = nullptr;    // [rows_cap]
   int32_t* vcnt = nullptr;        // [capacity] rows of the frame on vertex v
   int32_t* vstart = nullptr;      // [capacity] first bin position of vertex v
-  float4* bin_xyzv = nullptr;     // [rows_cap] position, value
-  uint4* bin_meta = nullptr;      // [rows_cap] {barycentric weight (bits), row id, vertex (-1: none), 0}
+  struct TlnBinRec* bin_rec = nullptr;   // [rows_cap] {position, value | barycentric weight, row id, vertex (-1: none), 0}
   int64_t bins_rows = -1;         // rows of the frame the bins hold (-1: none)
   // ---- partitioned K1 (k_bk_*): the rows of a frame split by key hash into buckets, one workgroup per bucket
   struct TlnRec* rec = nullptr;   // [rec_cap] 32-byte row records, grouped by (split block, bucket)
@@ -184,14 +183,13 @@ static int ensure_rows(tln_lattice* l, int64_t rows) {
   int64_t cap = 1;
   while (cap < rows) cap <<= 1;
   void* ptrs[] = {l->row_slot, l->block_cnt, l->sk_in, l->sk_out, l->sv_in, l->sv_out, l->sort_temp, l->pieces,
-                  l->row_rank, l->bin_xyzv, l->bin_meta, l->rec, l->bk_off, l->first_flag,
+                  l->row_rank, l->bin_rec, l->rec, l->bk_off, l->first_flag,
                   l->bucket_rows, l->bits_pre};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   l->row_slot = l->block_cnt = l->sk_in = l->sk_out = l->sv_in = l->sv_out = nullptr;
   l->row_rank = nullptr;
-  l->bin_xyzv = nullptr;
-  l->bin_meta = nullptr;
+  l->bin_rec = nullptr;
   l->rec = nullptr;
   l->bk_off = l->first_flag = l->bucket_rows = l->bits_pre = nullptr;
   l->rec_cap = 0;
@@ -209,8 +207,7 @@ static int ensure_rows(tln_lattice* l, int64_t rows) {
   TLN_HIP(hipMalloc(&l->pieces, (cap / 256 + 2) * 6 * sizeof(long long)));
   if (l->level == 0) {
     TLN_HIP(hipMalloc(&l->row_rank, cap * sizeof(int32_t)));
-    TLN_HIP(hipMalloc(&l->bin_xyzv, cap * sizeof(float4)));
-    TLN_HIP(hipMalloc(&l->bin_meta, cap * sizeof(uint4)));
+    TLN_HIP(hipMalloc(&l->bin_rec, cap * sizeof(TlnBinRec)));
     // partitioned K1: the split blocks' record regions (each rounded up to whole blocks of points), the bucket offsets
     // of every split block, the first-touch flags (zero between frames) and the bucket directories
     l->rec_cap = cap + cap / 128 + 2048;
@@ -352,7 +349,7 @@ extern "C" int tln_lattice_destroy(tln_lattice_t* l) {
   void* ptrs[] = {l->slots, l->vkeys, l->d_ctr, l->nbr, l->c2f, l->f2c,
                   l->row_slot, l->block_cnt, l->sk_in, l->sk_out, l->sv_in, l->sv_out, l->sort_temp,
                   l->seg_start, l->pool_packed, l->mean, l->pieces, l->slot_cnt, l->vslot, l->vcnt, l->vstart,
-                  l->row_rank, l->bin_xyzv, l->bin_meta, l->rec, l->bk_off, l->first_flag,
+                  l->row_rank, l->bin_rec, l->rec, l->bk_off, l->first_flag,
                   l->bucket_rows, l->bits_pre, l->vstamp};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -1424,7 +1421,7 @@ __global__ void __launch_bounds__(256) k_bins_scatter(TableRef t, const int32_t*
                                                       int val_dim, const float* __restrict__ weights,
                                                       uint32_t* __restrict__ slot_cnt, const int32_t* __restrict__ vstart,
                                                       int32_t* __restrict__ indices,
-                                                      float4* __restrict__ bin_xyzv, uint4* __restrict__ bin_meta) {
+                                                      TlnBinRec* __restrict__ bin_rec) {
   const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= rows) return;
   const int slot = row_slot[row];
@@ -1445,14 +1442,14 @@ __global__ void __launch_bounds__(256) k_bins_scatter(TableRef t, const int32_t*
     // behind all segments: CTR_CURSOR is final here (k_bins_alloc has completed)
     dest = t.ctr[CTR_CURSOR] + atomicAdd(&t.ctr[CTR_TAIL], 1);
   }
-  bin_xyzv[dest] = make_float4(x, y, z, val_dim == 1 ? val[p] : 0.f);
-  bin_meta[dest] = make_uint4(__float_as_uint(weights[row]), (uint32_t)row, (uint32_t)v, 0u);
+  bin_rec[dest].a = make_float4(x, y, z, val_dim == 1 ? val[p] : 0.f);
+  bin_rec[dest].m = make_uint4(__float_as_uint(weights[row]), (uint32_t)row, (uint32_t)v, 0u);
 }
 
 // one WAVE per vertex: its rows are contiguous in the bins; positions summed in fixed point (int64: exact, any order)
 __global__ void __launch_bounds__(256) k_bins_mean(const int32_t* __restrict__ ctr, const int32_t* __restrict__ vcnt,
                                                    const int32_t* __restrict__ vstart,
-                                                   const float4* __restrict__ bin_xyzv, float* __restrict__ mean) {
+                                                   const TlnBinRec* __restrict__ bin_rec, float* __restrict__ mean) {
   const int nv = ctr[CTR_NV];
   const int lane = threadIdx.x & 63;
   const int nwaves = (int)((gridDim.x * blockDim.x) >> 6);
@@ -1460,7 +1457,7 @@ __global__ void __launch_bounds__(256) k_bins_mean(const int32_t* __restrict__ c
     const int c = vcnt[v], st = vstart[v];
     long long sx = 0, sy = 0, sz = 0;
     for (int j = lane; j < c; j += 64) {
-      const float4 q = bin_xyzv[st + j];
+      const float4 q = bin_rec[st + j].a;
       sx += tln_fix20(q.x);
       sy += tln_fix20(q.y);
       sz += tln_fix20(q.z);
@@ -1787,8 +1784,8 @@ __global__ void __launch_bounds__(TLN_BK_THREADS) k_bk_place(const TlnRec* __res
                                                   int B, int64_t rpb, TableRef t, const uint32_t* __restrict__ bucket_rows,
                                                   int64_t rows, int32_t* __restrict__ vstart, int32_t* __restrict__ vcnt,
                                                   int32_t* __restrict__ vstamp, int stamp, float* __restrict__ mean,
-                                                  int32_t* __restrict__ indices, float4* __restrict__ bin_xyzv,
-                                                  uint4* __restrict__ bin_meta, const uint32_t* __restrict__ first_bits,
+                                                  int32_t* __restrict__ indices, TlnBinRec* __restrict__ bin_rec,
+                                                  const uint32_t* __restrict__ first_bits,
                                                   const uint32_t* __restrict__ bits_pre, int vold, int capacity,
                                                   int32_t* __restrict__ vkeys, int32_t* __restrict__ vslot) {
   __shared__ unsigned long long hk[TLN_BK_HT];
@@ -1926,8 +1923,8 @@ __global__ void __launch_bounds__(TLN_BK_THREADS) k_bk_place(const TlnRec* __res
     uint32_t dest;
     if (vv >= 0) dest = (uint32_t)hstart[he] + atomicAdd(&hcnt[he], 1u);
     else dest = bin0 + P + atomicAdd(&s_tail, 1u);
-    bin_xyzv[dest] = a;
-    bin_meta[dest] = make_uint4(bb.x, bb.y, (uint32_t)vv, 0u);
+    bin_rec[dest].a = a;   // (both halves of the 32-byte record: one memory transaction, not one per array)
+    bin_rec[dest].m = make_uint4(bb.x, bb.y, (uint32_t)vv, 0u);
     indices[bb.y] = vv;
   };
 #pragma unroll
@@ -1940,8 +1937,7 @@ __global__ void __launch_bounds__(TLN_BK_THREADS) k_bk_place(const TlnRec* __res
 // accessors for pool.hip: the bins of the last distribute, if they describe (d_distributed, rows)
 bool tln_lat_bins(const tln_lattice* l, const float* d_distributed, int64_t rows, TlnBins* out) {
   if (!l || l->bins_rows != rows || rows <= 0 || l->bins_dist != d_distributed || l->dist_val_dim != 1) return false;
-  out->xyzv = l->bin_xyzv;
-  out->meta = l->bin_meta;
+  out->rec = l->bin_rec;
   out->vstart = l->vstart;
   out->vcnt = l->vcnt;
   out->mean = l->mean;
@@ -2040,8 +2036,8 @@ extern "C" int tln_distribute_begin(tln_lattice_t* l, const float* d_positions, 
     TLN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bk_place), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)place_lds));
     hipLaunchKernelGGL(k_bk_place, dim3((unsigned)B), dim3(TLN_BK_THREADS), place_lds, s, l->rec, l->bk_off, nblk, B, rpb, t,
-                       l->bucket_rows, rows, l->vstart, l->vcnt, l->vstamp, l->bins_stamp, l->mean, d_indices, l->bin_xyzv,
-                       l->bin_meta, l->first_flag, l->bits_pre, (int)l->nr_vertices, (int)l->capacity,
+                       l->bucket_rows, rows, l->vstart, l->vcnt, l->vstamp, l->bins_stamp, l->mean, d_indices, l->bin_rec,
+                       l->first_flag, l->bits_pre, (int)l->nr_vertices, (int)l->capacity,
                        l->vkeys, l->vslot);
     TLN_LAUNCH_CHECK();
   } else {
@@ -2058,10 +2054,9 @@ extern "C" int tln_distribute_begin(tln_lattice_t* l, const float* d_positions, 
     // the bins: the host does not know the new vertex count yet; the kernels read it and stride over the vertices
     hipLaunchKernelGGL(k_bins_alloc, dim3(256), dim3(256), 0, s, l->d_ctr, l->vslot, l->slot_cnt, l->vcnt, l->vstart);
     hipLaunchKernelGGL(k_bins_scatter, dim3((unsigned)tln_cdiv(rows, 256)), dim3(256), 0, s, t, l->row_slot, l->row_rank, rows,
-                       d_positions, d_values, val_dim, d_weights, l->slot_cnt, l->vstart, d_indices, l->bin_xyzv,
-                       l->bin_meta);
+                       d_positions, d_values, val_dim, d_weights, l->slot_cnt, l->vstart, d_indices, l->bin_rec);
     if (subtract_mean)
-      hipLaunchKernelGGL(k_bins_mean, dim3(8192), dim3(256), 0, s, l->d_ctr, l->vcnt, l->vstart, l->bin_xyzv, l->mean);
+      hipLaunchKernelGGL(k_bins_mean, dim3(8192), dim3(256), 0, s, l->d_ctr, l->vcnt, l->vstart, l->bin_rec, l->mean);
     TLN_LAUNCH_CHECK();
   }
   l->dist_pending = true;

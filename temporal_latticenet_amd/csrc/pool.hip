@@ -220,8 +220,8 @@ __global__ void __launch_bounds__(256) k_pool_bins(const TlnBins bn, int64_t row
   // ---- phase 1: lane = row
   if (lane < cnt) {
     const int64_t at = j0 + lane;
-    float4 q = bn.xyzv[at];
-    const uint4 meta = bn.meta[at];
+    float4 q = bn.rec[at].a;
+    const uint4 meta = bn.rec[at].m;
     const int v = (int)meta.z;
     int flags = 0, vv = 0;      // rows without a vertex fold into vertex 0 with their raw position (lm:480)
     if (v >= 0) {
@@ -413,8 +413,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     r.w = 0.0f;
     r.q = make_float4(0.f, 0.f, 0.f, 0.f);
     if (ch < chunks && at < rows) {
-      r.q = bn.xyzv[at];
-      const uint4 meta = bn.meta[at];
+      r.q = bn.rec[at].a;
+      const uint4 meta = bn.rec[at].m;
       r.v = (int)meta.z;
       r.row = (int)meta.y;
       r.w = __uint_as_float(meta.x);

@@ -26,23 +26,3 @@ for _ in range(reps):
 torch.cuda.synchronize()
 print("distribute (operator call, host included): %.1f us per frame, V = %d" % (
     (time.perf_counter() - t0) / (4 * reps) * 1e6, lat.nr_lattice_vertices()))
-import ctypes
-import numpy as np
-from temporal_latticenet_amd import _lib
-L = ctypes.CDLL(_lib.LIB_PATH)
-if hasattr(L, "tln_debug_bk_prof"):
-    buf = torch.zeros(2 * 8192 * 8, dtype=torch.int64, device="cuda")
-    L.tln_debug_bk_prof(ctypes.c_void_p(buf.data_ptr()))
-    for t, (p, v) in enumerate(seq):
-        buf.zero_()
-        lat.distribute(p, v, reset_hashmap=(t == 0))
-        torch.cuda.synchronize()
-        a = buf.cpu().numpy().reshape(2, 8192, 8)
-        for k, name in ((0, "insert"), (1, "place")):
-            x = a[k]
-            x = x[x[:, 0] > 0]
-            t0 = x[:, 0].min()
-            nz = [i for i in range(8) if x[:, i].max() > 0]
-            print("frame", t, name, "blocks", len(x), "| stamp: mean / max after the first block start, 10 ns ticks:",
-                  ["%d: %.0f / %d" % (i, (x[:, i] - t0).mean(), (x[:, i] - t0).max()) for i in nz])
-    L.tln_debug_bk_prof(ctypes.c_void_p(0))
