@@ -43,13 +43,13 @@ def main():
     total = sum(r[4] * r[1] for r in g)
     summary = {"kernel": "k_gather_gemm", "launches": n, "hbm_bytes_per_launch": total / n,
                "correction": "2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950: FETCH_SIZE halves wide reads)"}
-    # the scatter / gather stages: HBM-side bytes per FRAME (sum over the stage's kernels / frames profiled).  The
-    # numbering kernels (k_count_new, k_assign_new, k_number_small) also serve the coarse levels: counted fully to K1.
-    stages = {"K1_distribute": ("k_distribute_insert", "k_count_new", "k_assign_new", "k_number_small", "k_bins_alloc",
-                                "k_bins_scatter", "k_bins_mean"),
+    # the scatter / gather stages: HBM-side bytes per FRAME (sum over the stage's kernels / frames profiled).  K1 =
+    # the partitioned kernels (k_bk_*) or, with TLN_K1_LEGACY=1, the per-row-atomic ones.
+    stages = {"K1_distribute": ("k_bk_split", "k_bk_insert", "k_bk_prefix", "k_bk_place", "k_distribute_insert",
+                                "k_bins_alloc", "k_bins_scatter", "k_bins_mean"),
               "K2_pointnet_pool": ("k_pool_bins", "k_pool_bins_finalize", "k_pool_chunks", "k_pool_finalize"),
               "K8_slice": ("k_slice_deform", "k_slice_gather", "k_slice")}
-    frames = sum(r[1] for r in rows if r[0].startswith("k_distribute_insert"))
+    frames = sum(r[1] for r in rows if r[0].startswith("k_distribute_insert") or r[0].startswith("k_bk_split"))
     last = sum(r[1] for r in rows if r[0].startswith("k_slice_deform"))
     sc = {}
     for name, ks in stages.items():
