@@ -19,7 +19,10 @@ SOURCES = {
     "fused.hip": [],
     "program.hip": [],
 }
-COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-I" + INCLUDE, "-Wall", "-Wno-unused-function"]
+# kernel arguments preloaded into SGPRs at wave launch (one memory round trip less before a kernel's first load: +1.7 %
+# clouds/s with one sequence in flight, where ~150 short dependent launches per frame are latency)
+COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-I" + INCLUDE, "-Wall", "-Wno-unused-function",
+          "-mllvm", "-amdgpu-kernarg-preload-count=16"]
 
 
 def _hipcc():
