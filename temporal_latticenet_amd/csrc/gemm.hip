@@ -817,11 +817,6 @@ __global__ void __launch_bounds__(768) k_gather_gemm_direct(const GemmArgs g) {
 // lock-step, tln_gather_gemm_multi; the GRU cell's two products): blockIdx.z selects the problem -- its own operands,
 // tables, row counts, outputs and statistics; N, K and the waves per tile are common.  A block past its problem's
 // rows leaves at once.
-#define TLN_GEMM_MULTI_MAX 8
-template <int NP>
-struct GemmArgsN {
-  GemmArgs a[NP];
-};
 static_assert(sizeof(GemmArgsN<TLN_GEMM_MULTI_MAX>) <= 4096, "the argument block must fit the kernarg segment");
 template <bool W_NK, int NP>
 __global__ void __launch_bounds__(768) k_gather_gemm_direct_multi(const GemmArgsN<NP> gg) {
@@ -1236,6 +1231,36 @@ extern "C" int tln_gather_gemm_multi(const tln_gemm_call* calls, int n, void* st
     int rc = prepare_gemm(c.M, c.N, c.s0, c.s1, c.d_w, c.w_is_nk, c.d_bias, c.d_residual, c.ld_res, c.relu, c.d_out,
                           c.ld_out, c.d_stats, q[i]);
     if (rc) return rc;
+  }
+  // products of one shape class whose rows together reach the large-M kernel's range (the coarse levels of lock-stepped
+  // sequences: 4 x 8.9k rows): one gemm_v2 launch, blockIdx.z = product
+  if (g_force_direct == 0 && !g_force_tm && !g_force_tn && !g_force_groups && !g_force_splits) {
+    GemmArgs gs[TLN_GEMM_MULTI_MAX];
+    bool vecs[TLN_GEMM_MULTI_MAX];
+    bool any_gn_fallback = false;
+    for (int i = 0; i < n; ++i) {
+      gs[i] = q[i].g;
+      vecs[i] = q[i].vec;
+      any_gn_fallback = any_gn_fallback || q[i].gn_fallback;
+      if (calls[i].w_is_nk != calls[0].w_is_nk) any_gn_fallback = true;
+    }
+    if (!any_gn_fallback && tln_gemm_v2_multi_ok(gs, n, calls[0].w_is_nk != 0, vecs)) {
+      hipStream_t s = (hipStream_t)stream_;
+      for (int i = 0; i < n; ++i) {   // as before a single gemm_v2 launch: the GroupNorm scale / shift of the source
+        SrcDev& d = gs[i].s[0];
+        if (d.gn_part == nullptr) continue;
+        TLN_REQUIRE(calls[i].s0->d_scale && calls[i].s0->d_shift, "GroupNorm fallback needs the d_scale/d_shift scratch of source 0");
+        int rc = tln_groupnorm_from_partials(d.gn_part, d.gn_rows, d.cin, d.gn_groups, d.gn_gamma, d.gn_beta, d.gn_eps,
+                                             const_cast<float*>(calls[i].s0->d_scale), const_cast<float*>(calls[i].s0->d_shift),
+                                             stream_);
+        if (rc) return rc;
+        d.gn_part = nullptr;
+      }
+      int rc = tln_gemm_v2_launch_multi(gs, n, calls[0].w_is_nk != 0, s);
+      if (rc) return rc;
+      TLN_LAUNCH_CHECK();
+      return TLN_OK;
+    }
   }
   // one launch only for products of the same shape class that all take the direct kernel as it is
   bool same = true;

@@ -42,7 +42,17 @@ struct GemmArgs {
 };
 
 
+#define TLN_GEMM_MULTI_MAX 8
+// up to TLN_GEMM_MULTI_MAX products of one shape class in one launch (blockIdx.z = product)
+template <int NP>
+struct GemmArgsN {
+  GemmArgs a[NP];
+};
+
 // gemm_v2.hip: the large-M kernel (block tile 128 x N, operands staged by LDS-DMA).  tln_gemm_v2_ok decides from the
 // prepared arguments alone, so every route (operator call, frame program, lock-step group) takes the same kernel.
 bool tln_gemm_v2_ok(const GemmArgs& g, bool w_is_nk, bool vec);
 int tln_gemm_v2_launch(GemmArgs& g, bool w_is_nk, hipStream_t s);
+// n products of one shape class whose rows TOGETHER make a large M (lock-stepped sequences on a coarse level): one launch
+bool tln_gemm_v2_multi_ok(const GemmArgs* g, int n, bool w_is_nk, const bool* vec);
+int tln_gemm_v2_launch_multi(GemmArgs* g, int n, bool w_is_nk, hipStream_t s);

@@ -29,7 +29,7 @@ __device__ __attribute__((aligned(16))) float g_v2_zero[4] = {0.f, 0.f, 0.f, 0.f
 #define V2_STAGES 3
 
 template <int WM, int WN, int TM, int TN, bool W_NK, bool PRO>
-__global__ void __launch_bounds__(64 * WM * WN) k_gather_gemm_v2(const GemmArgs g) {
+__device__ __forceinline__ void v2_body(const GemmArgs& g) {
   constexpr int NT = 64 * WM * WN;
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
@@ -268,6 +268,20 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gather_gemm_v2(const GemmArgs 
     }
 }
 
+template <int WM, int WN, int TM, int TN, bool W_NK, bool PRO>
+__global__ void __launch_bounds__(64 * WM * WN) k_gather_gemm_v2(const GemmArgs g) {
+  v2_body<WM, WN, TM, TN, W_NK, PRO>(g);
+}
+
+// several products of one shape class in one launch (blockIdx.z = product): the coarse levels of lock-stepped
+// sequences, whose rows only together fill the chip with 128-row tiles
+template <int WM, int WN, int TM, int TN, bool W_NK, bool PRO>
+__global__ void __launch_bounds__(64 * WM * WN) k_gather_gemm_v2_multi(const GemmArgsN<TLN_GEMM_MULTI_MAX> gg) {
+  const GemmArgs& g = gg.a[blockIdx.z];
+  if ((int64_t)blockIdx.x * (32 * TM * WM) >= g.M) return;   // (the grid is sized for the longest product)
+  v2_body<WM, WN, TM, TN, W_NK, PRO>(g);
+}
+
 // ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
@@ -326,6 +340,70 @@ static int dispatch_v2(GemmArgs& g, hipStream_t s) {
   if (n % 128 == 0) return launch_v2<2, 2, 2, 2, W_NK, PRO>(g, s);   // 128 x 128, waves 64 x 64
   if (n == 96) return launch_v2<4, 1, 1, 3, W_NK, PRO>(g, s);        // 128 x 96, waves 32 x 96
   return launch_v2<4, 1, 1, 2, W_NK, PRO>(g, s);                     // 128 x 64, waves 32 x 64
+}
+
+static bool v2_shape_ok(const GemmArgs& g, bool vec) {
+  if (g_v2_off || !vec || g.nsrc != 1) return false;
+  const SrcDev& s = g.s[0];
+  if (s.cin % 32 != 0 || s.cin > 1024 || s.pad != 0.f) return false;
+  if (!(s.taps == 1 || s.taps == TLN_TAPS)) return false;
+  if (s.src_rows >= (1ll << 31) || g.M >= (1ll << 31)) return false;
+  const bool affine = s.scale != nullptr || s.gn_part != nullptr;
+  if (affine && (!s.relu || s.scale == nullptr || s.shift == nullptr)) return false;
+  if (!affine && s.relu) return false;
+  const int n = g.N;
+  return n == 64 || n == 96 || n % 128 == 0 || n % 192 == 0;
+}
+
+bool tln_gemm_v2_multi_ok(const GemmArgs* g, int n, bool w_is_nk, const bool* vec) {
+  static const bool off = getenv("TLN_V2_MULTI_OFF") != nullptr;
+  if (off || n < 2 || n > TLN_GEMM_MULTI_MAX) return false;
+  int64_t total = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!v2_shape_ok(g[i], vec[i]) || g[i].M < 1024) return false;
+    const SrcDev &a = g[i].s[0], &b = g[0].s[0];
+    if (g[i].N != g[0].N || a.cin != b.cin || a.taps != b.taps || (a.table != nullptr) != (b.table != nullptr) ||
+        ((a.scale != nullptr || a.gn_part != nullptr) != (b.scale != nullptr || b.gn_part != nullptr)))
+      return false;
+    total += g[i].M;
+  }
+  (void)w_is_nk;
+  return total >= g_v2_min_m;
+}
+
+template <int WM, int WN, int TM, int TN, bool W_NK, bool PRO>
+static int launch_v2_multi(GemmArgs* g, int n, hipStream_t s) {
+  constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+  const size_t lds = (size_t)V2_STAGES * (BM + BN) * 128 + (size_t)BM * TLN_TAPS * 4 + (size_t)2 * g[0].s[0].cin * 4;
+  TLN_REQUIRE(lds <= 160 * 1024, "gemm v2: LDS %zu B", lds);
+  auto kern = k_gather_gemm_v2_multi<WM, WN, TM, TN, W_NK, PRO>;
+  TLN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  GemmArgsN<TLN_GEMM_MULTI_MAX> gg;
+  int64_t mmax = 0;
+  for (int i = 0; i < TLN_GEMM_MULTI_MAX; ++i) {
+    gg.a[i] = g[i < n ? i : 0];
+    gg.a[i].splits = 1;
+    if (i < n && g[i].M > mmax) mmax = g[i].M;
+  }
+  dim3 grid((unsigned)tln_cdiv(mmax, BM), (unsigned)tln_cdiv(g[0].N, BN), (unsigned)n);
+  hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, s, gg);
+  return TLN_OK;
+}
+
+template <bool W_NK, bool PRO>
+static int dispatch_v2_multi(GemmArgs* g, int n, hipStream_t s) {
+  const int nn = g[0].N;
+  if (nn % 192 == 0) return launch_v2_multi<4, 2, 1, 3, W_NK, PRO>(g, n, s);
+  if (nn % 128 == 0) return launch_v2_multi<4, 2, 1, 2, W_NK, PRO>(g, n, s);
+  if (nn == 64 && !PRO) return launch_v2_multi<4, 2, 1, 1, W_NK, PRO>(g, n, s);
+  if (nn == 96) return launch_v2_multi<4, 1, 1, 3, W_NK, PRO>(g, n, s);
+  return launch_v2_multi<4, 1, 1, 2, W_NK, PRO>(g, n, s);
+}
+
+int tln_gemm_v2_launch_multi(GemmArgs* g, int n, bool w_is_nk, hipStream_t s) {
+  const bool pro = g[0].s[0].scale != nullptr;
+  if (w_is_nk) return pro ? dispatch_v2_multi<true, true>(g, n, s) : dispatch_v2_multi<true, false>(g, n, s);
+  return pro ? dispatch_v2_multi<false, true>(g, n, s) : dispatch_v2_multi<false, false>(g, n, s);
 }
 
 int tln_gemm_v2_launch(GemmArgs& g, bool w_is_nk, hipStream_t s) {

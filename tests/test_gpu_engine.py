@@ -164,6 +164,11 @@ def test_lockstep_pair_equals_the_solo_frames(gpu, rnn, seq_learning, frames):
     twin.use_frame_program = True
     models = [model, twin]
     lib = _lib.lib()
+    # the bitwise half of the statement needs the same kernel on both routes: products that share a launch may take the
+    # large-M kernel where each alone takes the direct one (their rows are counted together), so that kernel stays off
+    # here; tests/test_gpu_fullsize.py runs the lock-step route with it against the oracle
+    lib.tln_gemm_v2_config(1, 0)
+    want = [_run(model, contents, s, gpu)[0] for s in seqs]
     try:
         for off in (1, 0, 0):
             lib.tln_gemm_pair_disable(off)
@@ -188,6 +193,7 @@ def test_lockstep_pair_equals_the_solo_frames(gpu, rnn, seq_learning, frames):
                 m.reset_sequence()
     finally:
         lib.tln_gemm_pair_disable(0)
+        lib.tln_gemm_v2_config(0, 0)
 
 
 def test_slice_head_writes_log_softmax(gpu):

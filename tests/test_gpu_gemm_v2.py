@@ -131,3 +131,58 @@ def test_v2_at_its_natural_size(gpu):
     rows = np.random.default_rng(0).choice(V, 2048, replace=False)
     want = O.im2row(lv, nb[rows]) @ W
     np.testing.assert_allclose(out.cpu().numpy()[rows], want.numpy(), rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("cin,cout,taps,nk,pro,nprod", [
+    (128, 128, 9, False, True, 3),     # a level-1 convolution of three lock-stepped sequences
+    (64, 64, 9, False, False, 2),
+    (192, 576, 1, True, False, 2),     # the GRU cell's pair x @ W_ih^T, h @ W_hh^T
+    (192, 96, 1, True, True, 4),
+])
+def test_v2_takes_products_whose_rows_only_together_are_large(gpu, lattice, cin, cout, taps, nk, pro, nprod):
+    """tln_gather_gemm_multi: products of one shape class with 2.3k-9k rows each (below the large-M kernel's threshold)
+    but 12 288 and more together go out as ONE gemm_v2 launch (blockIdx.z = product, the grid sized for the longest).
+    Each result against the oracle and bitwise against the same product forced through gemm_v2 alone (same kernel body,
+    same tile: the launch they share must not change a bit)."""
+    import ctypes as C
+    from temporal_latticenet_amd import _lib, ops
+    from temporal_latticenet_amd.lattice import stream_ptr
+    lat, table = lattice
+    V = lat.nr_lattice_vertices()
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(cin + cout + nprod)
+    Ms = [V // 2 - 517 * i for i in range(nprod)]          # different row counts, ragged last tiles
+    assert sum(Ms) >= 12288 and max(Ms) < 12288
+    W = (torch.randn(cout, taps * cin, generator=g) if nk else torch.randn(taps * cin, cout, generator=g)) / np.sqrt(taps * cin)
+    Wd = W.to(gpu)
+    gamma, beta = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g)
+    lvs = [torch.randn(V, cin, generator=g) for _ in range(nprod)]
+    bias = torch.randn(cout, generator=g).to(gpu)
+    keep, calls, outs = [], (_lib.GemmCall * nprod)(), []
+    for i in range(nprod):
+        kw = {}
+        if pro:
+            sc, sh = ops.groupnorm_stats(lvs[i].to(gpu), 32, gamma.to(gpu), beta.to(gpu))
+            kw = dict(scale=sc, shift=sh, relu=True)
+        src = ops.gemm_src(lvs[i].to(gpu), lat.neighbour_table_ptr() if taps == 9 else None, taps, **kw)
+        out = torch.full((Ms[i], cout), float("nan"), device=gpu)
+        keep.append((src, kw, out))
+        c = calls[i]
+        c.M, c.N, c.s0, c.s1 = Ms[i], cout, C.pointer(src[0]), None
+        c.d_w, c.w_is_nk, c.d_bias, c.d_residual, c.ld_res, c.relu = Wd.data_ptr(), 1 if nk else 0, bias.data_ptr(), None, 0, 0
+        c.d_out, c.ld_out, c.d_stats = out.data_ptr(), cout, None
+        outs.append(out)
+    _lib.check(lib.tln_gather_gemm_multi(calls, nprod, stream_ptr()), "tln_gather_gemm_multi")
+    torch.cuda.synchronize()
+    lib.tln_gemm_v2_config(0, 1)                           # the same products one by one through gemm_v2
+    try:
+        for i in range(nprod):
+            src, kw, _ = keep[i]
+            alone = ops.gather_gemm(Ms[i], Wd, src, w_is_nk=nk, bias=bias)
+            assert torch.equal(outs[i], alone), "product %d" % i
+            x = torch.relu(O.group_norm(lvs[i], gamma, beta)) if pro else lvs[i]
+            a = (O.im2row(x, table) if taps == 9 else x)[:Ms[i]]
+            want = a @ (W.t() if nk else W) + bias.cpu()
+            np.testing.assert_allclose(outs[i].cpu().numpy(), want.numpy(), rtol=1e-4, atol=5e-5)
+    finally:
+        lib.tln_gemm_v2_config(0, 12288)

@@ -56,6 +56,9 @@ def test_lockstep_pairs_match_the_single_sequence_results(gpu):
     model = build_model(contents).eval()
     _alone(model, contents, seqs[0])
     randomize_parameters(model, seed=19)
+    # (the bitwise half needs the same kernel on both routes: products sharing a launch may take the large-M kernel
+    # where each alone takes the direct one — their rows are counted together —, so that kernel stays off here)
+    _lib.lib().tln_gemm_v2_config(1, 0)
     want = [_alone(model, contents, s) for s in seqs]
     pool = SequenceStreams(model, lambda: build_model(contents).eval(), lambda: make_lattice(contents), seqs[0], S, pairs=True)
     assert len(pool.models) == 2 * S and len(pool) == S
@@ -75,6 +78,7 @@ def test_lockstep_pairs_match_the_single_sequence_results(gpu):
                     assert err <= 2e-4 * max(1.0, float(w.abs().max())), "sequence %d: %.3e" % (k, err)
     finally:
         lib.tln_gemm_pair_disable(0)
+        lib.tln_gemm_v2_config(0, 0)
         pool.close()
 
 
@@ -90,6 +94,7 @@ def test_lockstep_groups_of_three_and_four(gpu, group):
     model = build_model(contents).eval()
     _alone(model, contents, seqs[0])
     randomize_parameters(model, seed=29)
+    _lib.lib().tln_gemm_v2_config(1, 0)   # (as in the pairs test above)
     want = [_alone(model, contents, s) for s in seqs]
     pool = SequenceStreams(model, lambda: build_model(contents).eval(), lambda: make_lattice(contents), seqs[0], S, pairs=group)
     assert len(pool.models) == group * S
@@ -107,4 +112,5 @@ def test_lockstep_groups_of_three_and_four(gpu, group):
                     assert err <= 2e-4 * max(1.0, float(w.abs().max())), "sequence %d: %.3e" % (k, err)
     finally:
         lib.tln_gemm_pair_disable(0)
+        lib.tln_gemm_v2_config(0, 0)
         pool.close()
