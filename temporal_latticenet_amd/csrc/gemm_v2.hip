@@ -288,7 +288,7 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gather_gemm_v2_multi(const Gem
 // below: gemm.hip's kernels.  Measured at M = 8.9k (level 1 of the headline lattice) with 64x64, 32x128, 64x128 block
 // tiles of this kernel: 49-65 us against 52 us for the direct kernel on 128 -> 128 — too few chunks per block to pay
 // for the ring's fill and the per-chunk barrier, and 1.1 tiles per SIMD leave no tile shape that balances.
-static int64_t g_v2_min_m = 12288;
+static int64_t g_v2_min_m = getenv("TLN_V2_MIN_M") ? atoll(getenv("TLN_V2_MIN_M")) : 12288;
 static int g_v2_off = 0;
 extern "C" void tln_gemm_v2_config(int off, int64_t min_m) {
   g_v2_off = off;

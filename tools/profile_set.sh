@@ -10,15 +10,15 @@ if [ "$2" != "pmc-only" ]; then
   mkdir -p $O/ks4 $O/ks1
   python bench.py > $O/bench.json 2> $O/bench.err
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks4 -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_under_rocprof_4streams.json 2>/dev/null
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks1 -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --streams 1 > $O/bench_under_rocprof_1stream.json 2>/dev/null
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks1 -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --streams 1 --pairs 0 > $O/bench_under_rocprof_1stream.json 2>/dev/null
   cp $(ls $O/ks4/*/*kernel_stats.csv | head -1) $O/kernel_stats_4streams.csv
   cp $(ls $O/ks1/*/*kernel_stats.csv | head -1) $O/kernel_stats_1stream.csv
   rm -rf $O/ks4 $O/ks1
   cat $O/bench.json
 fi
 mkdir -p $O/pmc/FETCH_SIZE $O/pmc/WRITE_SIZE
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc/FETCH_SIZE -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --streams 1 > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc/WRITE_SIZE -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --streams 1 > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc/FETCH_SIZE -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --streams 1 --pairs 0 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc/WRITE_SIZE -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --streams 1 --pairs 0 > /dev/null 2>&1
 python tools/pmc_summary.py $O/pmc $O/pmc_traffic.csv $O/pmc_traffic.json
 rm -rf $O/pmc
 head -5 $O/pmc_traffic.csv
