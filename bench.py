@@ -270,6 +270,35 @@ def main():
             if getattr(model, "_program", None) is not None:
                 model._program.capture_gemms(False)
                 model._program.stage_timing(False)
+            # (1b) the same for a lock-step group as a stream of the timed mode steps it (--pairs P): P sequences (the
+            #      drive and its turned copies), product i of all of them through one tln_gather_gemm_multi call
+            grp = None
+            if tot_n and not frames_mode and per > 1:
+                from temporal_latticenet_amd.engine import FrameProgram
+                from temporal_latticenet_amd.models import forward_group
+                gmodels, gseqs = pool.models[:per], per_stream[:per]
+                glats = [make_lattice(contents) for _ in range(per)]
+                g_ms, g_n, g_fl = 0.0, 0, 0.0
+                with torch.no_grad():
+                    for rep in range(2):                 # first round: warm (tables, workspaces of these lattices)
+                        for m in gmodels:
+                            m.reset_sequence()
+                            if rep == 1:
+                                m._program.capture_gemms(True)
+                        cur = [make_lattice(contents) for _ in range(per)] if rep == 0 else glats
+                        for t in range(len(frames)):
+                            res = forward_group(gmodels, cur, [q[t][0] for q in gseqs], [q[t][1] for q in gseqs],
+                                                t != len(frames) - 1)
+                            cur = [r[2] for r in res]
+                            if rep == 1:
+                                ms, n, fl, by = FrameProgram.replay_gemms_group([m._program for m in gmodels], reps)
+                                g_ms, g_n, g_fl = g_ms + ms, g_n + n, g_fl + fl
+                for m in gmodels:
+                    m._program.capture_gemms(False)
+                    m.reset_sequence()
+                if g_n:
+                    grp = {"achieved": round(g_fl / (g_ms * 1e-3) / 1e12, 3), "avg_product_us": round(g_ms * 1e3 / g_n, 2),
+                           "products": g_n // reps, "sequences": per}
             if tot_n:
                 achieved = tot_fl / (tot_ms * 1e-3) / 1e12
                 seqs_per_step = (S * per) if not frames_mode else plan.nr_groups / max(1, args.gpus)
@@ -281,6 +310,11 @@ def main():
                         "flops_per_launch": tot_fl / tot_n, "algorithmic_bytes_per_launch": tot_by / tot_n,
                         "mode": "every gather-GEMM product of one %d-frame sequence (GRU projections included) "
                                 "replayed back to back on one stream running alone" % args.frames,
+                        "lockstep_group": None if grp is None else dict(
+                            grp, frac=round(grp["achieved"] / FP32_MFMA_PEAK_TFLOPS, 4),
+                            note="the products of one stream's lock-step group (%d sequences) replayed back to back as "
+                                 "the group issues them (shared launches): the launches of the timed mode, one stream "
+                                 "alone" % grp["sequences"]),
                         "whole_step": {"achieved": round(step_tf, 3), "frac": round(step_tf / FP32_MFMA_PEAK_TFLOPS, 4),
                                        "note": "the same flops per sequence x sequences per step / measured step time of "
                                                "the TIMED region (all streams): lower bound of the MFMA rate in that mode"}}

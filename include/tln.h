@@ -409,6 +409,10 @@ int tln_program_timing(tln_program_t* p, int enable);
 int tln_program_timing_read(tln_program_t* p, float* ms_out /* [3] */);
 int tln_program_replay_gemms(tln_program_t* p, int reps, double* ms_total, int64_t* launches, double* flops,
                              double* bytes, void* stream);
+/* the same for 1..8 lock-stepped programs (tln_program_run_group): product i of every program goes out through one
+ * tln_gather_gemm_multi call, as the group issued it; launches = products */
+int tln_program_replay_gemms_group(tln_program_t* const* pp, int n, int reps, double* ms_total, int64_t* launches,
+                                   double* flops, double* bytes, void* stream);
 /* The frame in segments, for the frame-sharded multi-GPU path (temporal_latticenet_amd/dist.py): the rank that owns
  * frame t receives every fusion module's hidden state from the rank of frame t-1 right before the first op that reads
  * it and sends the new one on right after the last op that writes it.  Per frame: tln_program_begin_frame, every state

@@ -1142,6 +1142,62 @@ extern "C" int tln_program_replay_gemms(tln_program_t* p, int reps, double* ms_t
   return TLN_OK;
 }
 
+// The products of the last frame of 1..8 lock-stepped programs replayed as the group issued them: product i of every
+// program through ONE tln_gather_gemm_multi call (the launches of the timed mode of bench.py on one stream).
+extern "C" int tln_program_replay_gemms_group(tln_program_t* const* pp, int n, int reps, double* ms_total, int64_t* launches,
+                                              double* flops, double* bytes, void* stream_) {
+  TLN_REQUIRE(pp && n >= 1 && n <= 8 && reps > 0 && ms_total && launches && flops && bytes, "bad replay arguments");
+  hipStream_t s = (hipStream_t)stream_;
+  *ms_total = 0.0;
+  *launches = 0;
+  *flops = 0.0;
+  *bytes = 0.0;
+  const size_t nc = pp[0]->calls.size();
+  for (int k = 0; k < n; ++k) TLN_REQUIRE(pp[k] && pp[k]->calls.size() == nc, "the programs captured different products");
+  if (nc == 0) return TLN_OK;
+  hipEvent_t e0, e1;
+  TLN_HIP(hipEventCreate(&e0));
+  TLN_HIP(hipEventCreate(&e1));
+  auto launch_all = [&]() -> int {
+    for (size_t i = 0; i < nc; ++i) {
+      tln_gemm_call calls[8];
+      for (int k = 0; k < n; ++k) {
+        const GemmCall& c = pp[k]->calls[i];
+        calls[k] = tln_gemm_call{c.M, c.N, &c.a[0], c.two ? &c.a[1] : nullptr, c.w, c.w_is_nk, c.bias, c.res, c.ld_res,
+                                 c.relu, c.out, c.ld_out, c.stats};
+      }
+      int rc = tln_gather_gemm_multi(calls, n, s);
+      if (rc) return rc;
+    }
+    return TLN_OK;
+  };
+  int rc = launch_all();  // warm
+  if (!rc) {
+    TLN_HIP(hipEventRecord(e0, s));
+    for (int r = 0; r < reps && !rc; ++r) rc = launch_all();
+    TLN_HIP(hipEventRecord(e1, s));
+    TLN_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    TLN_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *ms_total = ms;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (rc) return rc;
+  for (int k = 0; k < n; ++k)
+    for (const GemmCall& c : pp[k]->calls) {
+      const double K = (double)c.a[0].taps * c.a[0].cin + (c.two ? (double)c.a[1].taps * c.a[1].cin : 0.0);
+      const double cin = (double)c.a[0].cin + (c.two ? (double)c.a[1].cin : 0.0);
+      *flops += 2.0 * (double)c.M * K * c.N;
+      *bytes += 4.0 * ((double)c.M * cin + (double)c.M * c.N + K * c.N) + 4.0 * (double)c.M * c.a[0].taps +
+                (c.res ? 4.0 * (double)c.M * c.N : 0.0);
+    }
+  *launches = (int64_t)nc * n * reps;   // products (a shared launch counts once per product it carries)
+  *flops *= reps;
+  *bytes *= reps;
+  return TLN_OK;
+}
+
 extern "C" int tln_program_frame_rows(tln_program_t* p, const float** d_distributed, const int32_t** d_indices,
                                       const float** d_weights, int64_t* rows, int* cols) {
   TLN_REQUIRE(p && p->d_idx, "no frame yet");

@@ -497,6 +497,16 @@ class FrameProgram:
                                                        C.byref(by), stream_ptr()), "tln_program_replay_gemms")
         return ms.value, n.value, fl.value, by.value
 
+    @staticmethod
+    def replay_gemms_group(programs, reps=5):
+        """the same for the programs of a lock-step group (models.forward_group): product i of every program through
+        one tln_gather_gemm_multi call, as the group issued it; launches = products"""
+        hs = (C.c_void_p * len(programs))(*[p._h for p in programs])
+        ms, n, fl, by = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
+        _lib.check(_lib.lib().tln_program_replay_gemms_group(hs, len(programs), reps, C.byref(ms), C.byref(n), C.byref(fl),
+                                                             C.byref(by), stream_ptr()), "tln_program_replay_gemms_group")
+        return ms.value, n.value, fl.value, by.value
+
     # ---- the frame in segments (frame-sharded multi-GPU, dist.FrameShardRunner) -----------------------------------
     def state_ops(self, sid):
         """(first op that reads stored state `sid`, last op that writes the new one, lattice level of the state)"""

@@ -56,10 +56,11 @@ def _check_line(d, world):
 
 
 def test_bench_sequence_sharding_two_ranks(gpu):
-    d = _launch(2, ["--streams", "2"])
+    d = _launch(2, ["--streams", "2", "--pairs", "2"])
     _check_line(d, 2)
-    # value = clouds of ALL ranks / time: 2 ranks x 2 streams x 2 steps x 4 frames
-    assert abs(d["value"] - 2 * 2 * 2 * 4 / (d["ms_per_step"] * 2e-3)) < 1e-3 * d["value"]
+    # value = clouds of ALL ranks / time: 2 ranks x 2 streams x 2 lock-stepped sequences x 2 steps x 4 frames
+    assert abs(d["value"] - 2 * 2 * 2 * 2 * 4 / (d["ms_per_step"] * 2e-3)) < 1e-3 * d["value"]
+    assert "2 lock-stepped" in d["config"]["parallelism"]
     assert "no data-path collective" in d["config"]["parallelism"]
 
 
