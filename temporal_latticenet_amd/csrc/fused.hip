@@ -48,14 +48,27 @@ __global__ void __launch_bounds__(256) k_gn_partial(const float* __restrict__ x,
 // one BLOCK per group: thread t adds the group's partial sums t, t+256, ... (fixed order), the 256 subtotals are
 // combined by a fixed tree => deterministic.  (One wave per group, as this kernel used to be, walks 6k partials of a
 // 30k-vertex level serially: 18 us; a block takes 3.)
-__global__ void __launch_bounds__(256) k_gn_finalize(const double2* __restrict__ partial, int nblk, int64_t V, int C,
-                                                     int groups, const float* __restrict__ gamma,
-                                                     const float* __restrict__ beta, float eps,
-                                                     float* __restrict__ scale, float* __restrict__ shift) {
+struct GnFin {
+  const double2* partial;
+  int nblk;
+  int64_t V;
+  int C, groups;
+  const float* gamma;
+  const float* beta;
+  float eps;
+  float* scale;
+  float* shift;
+};
+struct GnFinN {
+  GnFin a[8];
+};
+
+__device__ __forceinline__ void gn_finalize_body(const GnFin& f, int g) {
   __shared__ double2 red[256];
-  const int g = blockIdx.x;
-  const int cpg = C / groups;
-  const int64_t items = (int64_t)nblk * cpg;
+  const double2* __restrict__ partial = f.partial;
+  const int C = f.C;
+  const int cpg = C / f.groups;
+  const int64_t items = (int64_t)f.nblk * cpg;
   double s0 = 0.0, q0 = 0.0, s1 = 0.0, q1 = 0.0;
   int64_t i = threadIdx.x;
   for (; i + 256 < items; i += 512) {          // two independent loads in flight per round
@@ -84,17 +97,25 @@ __global__ void __launch_bounds__(256) k_gn_finalize(const double2* __restrict__
     __syncthreads();
   }
   const double s = red[0].x, q = red[0].y;
-  const double cnt = (double)V * (double)cpg;
+  const double cnt = (double)f.V * (double)cpg;
   const double mean = s / cnt;
   double var = q / cnt - mean * mean;
   if (var < 0.0) var = 0.0;
-  const double rstd = 1.0 / sqrt(var + (double)eps);
+  const double rstd = 1.0 / sqrt(var + (double)f.eps);
   for (int c = g * cpg + threadIdx.x; c < (g + 1) * cpg; c += 256) {
-    const double gm = gamma ? (double)gamma[c] : 1.0;
-    const double bt = beta ? (double)beta[c] : 0.0;
-    scale[c] = (float)(gm * rstd);
-    shift[c] = (float)(bt - mean * rstd * gm);
+    const double gm = f.gamma ? (double)f.gamma[c] : 1.0;
+    const double bt = f.beta ? (double)f.beta[c] : 0.0;
+    f.scale[c] = (float)(gm * rstd);
+    f.shift[c] = (float)(bt - mean * rstd * gm);
   }
+}
+
+__global__ void __launch_bounds__(256) k_gn_finalize(const GnFin f) { gn_finalize_body(f, blockIdx.x); }
+// the same for the tensors of up to eight lock-stepped sequences in one launch (blockIdx.y = tensor)
+__global__ void __launch_bounds__(256) k_gn_finalize_multi(const GnFinN ff) {
+  const GnFin& f = ff.a[blockIdx.y];
+  if ((int)blockIdx.x >= f.groups) return;
+  gn_finalize_body(f, blockIdx.x);
 }
 
 extern "C" int64_t tln_groupnorm_ws_bytes(int64_t V, int C) {
@@ -111,8 +132,8 @@ extern "C" int tln_groupnorm_stats(const float* d_x, int64_t V, int C, int group
   hipStream_t s = (hipStream_t)stream_;
   const int nblk = (int)tln_cdiv(V, GN_ROWS_PER_BLOCK);
   hipLaunchKernelGGL(k_gn_partial, dim3(nblk, (unsigned)tln_cdiv(C, 64)), dim3(256), 0, s, d_x, V, C, (double2*)d_ws);
-  hipLaunchKernelGGL(k_gn_finalize, dim3((unsigned)groups), dim3(256), 0, s, (const double2*)d_ws, nblk, V,
-                     C, groups, d_gamma, d_beta, eps, d_scale, d_shift);
+  hipLaunchKernelGGL(k_gn_finalize, dim3((unsigned)groups), dim3(256), 0, s,
+                     GnFin{(const double2*)d_ws, nblk, V, C, groups, d_gamma, d_beta, eps, d_scale, d_shift});
   TLN_LAUNCH_CHECK();
   return TLN_OK;
 }
@@ -134,7 +155,28 @@ extern "C" int tln_groupnorm_from_partials(const void* d_partials, int64_t V, in
               groups);
   const int nblk = (int)tln_cdiv(V, GN_ROWS_PER_BLOCK);
   hipLaunchKernelGGL(k_gn_finalize, dim3((unsigned)groups), dim3(256), 0, (hipStream_t)stream_,
-                     (const double2*)d_partials, nblk, V, C, groups, d_gamma, d_beta, eps, d_scale, d_shift);
+                     GnFin{(const double2*)d_partials, nblk, V, C, groups, d_gamma, d_beta, eps, d_scale, d_shift});
+  TLN_LAUNCH_CHECK();
+  return TLN_OK;
+}
+
+// n <= 8 tensors (lock-stepped sequences) in one launch; the arguments as arrays
+int tln_groupnorm_from_partials_multi(int n, const void* const* d_partials, const int64_t* V, const int* C, const int* groups,
+                                      const float* const* d_gamma, const float* const* d_beta, const float* eps,
+                                      float* const* d_scale, float* const* d_shift, void* stream_) {
+  TLN_REQUIRE(n >= 1 && n <= 8, "bad number of tensors %d", n);
+  GnFinN ff;
+  int gmax = 0;
+  for (int i = 0; i < 8; ++i) {
+    const int k = i < n ? i : 0;
+    TLN_REQUIRE(d_partials[k] && d_scale[k] && d_shift[k], "null argument");
+    TLN_REQUIRE(V[k] > 0 && C[k] > 0 && groups[k] > 0 && C[k] % groups[k] == 0, "bad groupnorm shape V=%lld C=%d G=%d",
+                (long long)V[k], C[k], groups[k]);
+    ff.a[i] = GnFin{(const double2*)d_partials[k], (int)tln_cdiv(V[k], GN_ROWS_PER_BLOCK), V[k], C[k], groups[k], d_gamma[k],
+                    d_beta[k], eps[k], d_scale[k], d_shift[k]};
+    if (i < n && groups[k] > gmax) gmax = groups[k];
+  }
+  hipLaunchKernelGGL(k_gn_finalize_multi, dim3((unsigned)gmax, (unsigned)n), dim3(256), 0, (hipStream_t)stream_, ff);
   TLN_LAUNCH_CHECK();
   return TLN_OK;
 }

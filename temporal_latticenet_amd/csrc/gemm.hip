@@ -817,6 +817,9 @@ __global__ void __launch_bounds__(768) k_gather_gemm_direct(const GemmArgs g) {
 // lock-step, tln_gather_gemm_multi; the GRU cell's two products): blockIdx.z selects the problem -- its own operands,
 // tables, row counts, outputs and statistics; N, K and the waves per tile are common.  A block past its problem's
 // rows leaves at once.
+int tln_groupnorm_from_partials_multi(int n, const void* const* d_partials, const int64_t* V, const int* C, const int* groups,
+                                      const float* const* d_gamma, const float* const* d_beta, const float* eps,
+                                      float* const* d_scale, float* const* d_shift, void* stream_);   // fused.hip
 static_assert(sizeof(GemmArgsN<TLN_GEMM_MULTI_MAX>) <= 4096, "the argument block must fit the kernarg segment");
 template <bool W_NK, int NP>
 __global__ void __launch_bounds__(768) k_gather_gemm_direct_multi(const GemmArgsN<NP> gg) {
@@ -1246,15 +1249,35 @@ extern "C" int tln_gather_gemm_multi(const tln_gemm_call* calls, int n, void* st
     }
     if (!any_gn_fallback && tln_gemm_v2_multi_ok(gs, n, calls[0].w_is_nk != 0, vecs)) {
       hipStream_t s = (hipStream_t)stream_;
-      for (int i = 0; i < n; ++i) {   // as before a single gemm_v2 launch: the GroupNorm scale / shift of the source
-        SrcDev& d = gs[i].s[0];
-        if (d.gn_part == nullptr) continue;
-        TLN_REQUIRE(calls[i].s0->d_scale && calls[i].s0->d_shift, "GroupNorm fallback needs the d_scale/d_shift scratch of source 0");
-        int rc = tln_groupnorm_from_partials(d.gn_part, d.gn_rows, d.cin, d.gn_groups, d.gn_gamma, d.gn_beta, d.gn_eps,
-                                             const_cast<float*>(calls[i].s0->d_scale), const_cast<float*>(calls[i].s0->d_shift),
-                                             stream_);
-        if (rc) return rc;
-        d.gn_part = nullptr;
+      // as before a single gemm_v2 launch: the GroupNorm scale / shift of the sources, all in ONE launch
+      {
+        const void* part[TLN_GEMM_MULTI_MAX];
+        int64_t vv[TLN_GEMM_MULTI_MAX];
+        int cc[TLN_GEMM_MULTI_MAX], gg[TLN_GEMM_MULTI_MAX];
+        const float *gam[TLN_GEMM_MULTI_MAX], *bet[TLN_GEMM_MULTI_MAX];
+        float ep[TLN_GEMM_MULTI_MAX];
+        float *sc[TLN_GEMM_MULTI_MAX], *sh[TLN_GEMM_MULTI_MAX];
+        int m = 0;
+        for (int i = 0; i < n; ++i) {
+          SrcDev& d = gs[i].s[0];
+          if (d.gn_part == nullptr) continue;
+          TLN_REQUIRE(calls[i].s0->d_scale && calls[i].s0->d_shift, "GroupNorm fallback needs the d_scale/d_shift scratch of source 0");
+          part[m] = d.gn_part;
+          vv[m] = d.gn_rows;
+          cc[m] = d.cin;
+          gg[m] = d.gn_groups;
+          gam[m] = d.gn_gamma;
+          bet[m] = d.gn_beta;
+          ep[m] = d.gn_eps;
+          sc[m] = const_cast<float*>(calls[i].s0->d_scale);
+          sh[m] = const_cast<float*>(calls[i].s0->d_shift);
+          ++m;
+          d.gn_part = nullptr;
+        }
+        if (m) {
+          int rc = tln_groupnorm_from_partials_multi(m, part, vv, cc, gg, gam, bet, ep, sc, sh, stream_);
+          if (rc) return rc;
+        }
       }
       int rc = tln_gemm_v2_launch_multi(gs, n, calls[0].w_is_nk != 0, s);
       if (rc) return rc;
