@@ -1225,7 +1225,11 @@ extern "C" int tln_gather_gemm_multi(const tln_gemm_call* calls, int n, void* st
     for (int i = 0; i < n && !rc; ++i) rc = run_call(&calls[i], stream_);
     return rc;
   };
-  if (n == 1 || n > TLN_GEMM_MULTI_MAX || g_pair_off) return one_by_one();
+  if (n == 1 || n > TLN_GEMM_MULTI_MAX || g_pair_off) {
+    if (getenv("TLN_MULTI_DEBUG") && n == 1)
+      fprintf(stderr, "multi n=1: M=%ld N=%d cin=%d taps=%d\n", (long)calls[0].M, calls[0].N, calls[0].s0->cin, calls[0].s0->taps);
+    return one_by_one();
+  }
   for (int i = 0; i < n; ++i)
     if (calls[i].M <= 0) return one_by_one();
   Prep q[TLN_GEMM_MULTI_MAX];
@@ -1235,49 +1239,53 @@ extern "C" int tln_gather_gemm_multi(const tln_gemm_call* calls, int n, void* st
                           c.ld_out, c.d_stats, q[i]);
     if (rc) return rc;
   }
+  // GroupNorm statistics a kernel will not finalise in its own prologue (every product bound for gemm_v2: `all`; else
+  // the ones prepare_gemm marked gn_fallback): scale / shift of all those sources from ONE launch
+  auto finalize_pending_gn = [&](bool all) -> int {
+    const void* part[TLN_GEMM_MULTI_MAX];
+    int64_t vv[TLN_GEMM_MULTI_MAX];
+    int cc[TLN_GEMM_MULTI_MAX], gg[TLN_GEMM_MULTI_MAX];
+    const float *gam[TLN_GEMM_MULTI_MAX], *bet[TLN_GEMM_MULTI_MAX];
+    float ep[TLN_GEMM_MULTI_MAX];
+    float *sc[TLN_GEMM_MULTI_MAX], *sh[TLN_GEMM_MULTI_MAX];
+    int m = 0;
+    for (int i = 0; i < n; ++i) {
+      SrcDev& d = q[i].g.s[0];
+      if (d.gn_part == nullptr || !(all || q[i].gn_fallback)) continue;
+      TLN_REQUIRE(calls[i].s0->d_scale && calls[i].s0->d_shift, "GroupNorm fallback needs the d_scale/d_shift scratch of source 0");
+      part[m] = d.gn_part;
+      vv[m] = d.gn_rows;
+      cc[m] = d.cin;
+      gg[m] = d.gn_groups;
+      gam[m] = d.gn_gamma;
+      bet[m] = d.gn_beta;
+      ep[m] = d.gn_eps;
+      sc[m] = const_cast<float*>(calls[i].s0->d_scale);
+      sh[m] = const_cast<float*>(calls[i].s0->d_shift);
+      ++m;
+      d.gn_part = nullptr;
+      q[i].gn_fallback = false;
+    }
+    return m ? tln_groupnorm_from_partials_multi(m, part, vv, cc, gg, gam, bet, ep, sc, sh, stream_) : TLN_OK;
+  };
   // products of one shape class whose rows together reach the large-M kernel's range (the coarse levels of lock-stepped
   // sequences: 4 x 8.9k rows): one gemm_v2 launch, blockIdx.z = product
   if (g_force_direct == 0 && !g_force_tm && !g_force_tn && !g_force_groups && !g_force_splits) {
     GemmArgs gs[TLN_GEMM_MULTI_MAX];
     bool vecs[TLN_GEMM_MULTI_MAX];
-    bool any_gn_fallback = false;
+    bool mixed = false;
     for (int i = 0; i < n; ++i) {
       gs[i] = q[i].g;
       vecs[i] = q[i].vec;
-      any_gn_fallback = any_gn_fallback || q[i].gn_fallback;
-      if (calls[i].w_is_nk != calls[0].w_is_nk) any_gn_fallback = true;
+      if (calls[i].w_is_nk != calls[0].w_is_nk) mixed = true;
     }
-    if (!any_gn_fallback && tln_gemm_v2_multi_ok(gs, n, calls[0].w_is_nk != 0, vecs)) {
+    if (!mixed && tln_gemm_v2_multi_ok(gs, n, calls[0].w_is_nk != 0, vecs)) {
       hipStream_t s = (hipStream_t)stream_;
       // as before a single gemm_v2 launch: the GroupNorm scale / shift of the sources, all in ONE launch
       {
-        const void* part[TLN_GEMM_MULTI_MAX];
-        int64_t vv[TLN_GEMM_MULTI_MAX];
-        int cc[TLN_GEMM_MULTI_MAX], gg[TLN_GEMM_MULTI_MAX];
-        const float *gam[TLN_GEMM_MULTI_MAX], *bet[TLN_GEMM_MULTI_MAX];
-        float ep[TLN_GEMM_MULTI_MAX];
-        float *sc[TLN_GEMM_MULTI_MAX], *sh[TLN_GEMM_MULTI_MAX];
-        int m = 0;
-        for (int i = 0; i < n; ++i) {
-          SrcDev& d = gs[i].s[0];
-          if (d.gn_part == nullptr) continue;
-          TLN_REQUIRE(calls[i].s0->d_scale && calls[i].s0->d_shift, "GroupNorm fallback needs the d_scale/d_shift scratch of source 0");
-          part[m] = d.gn_part;
-          vv[m] = d.gn_rows;
-          cc[m] = d.cin;
-          gg[m] = d.gn_groups;
-          gam[m] = d.gn_gamma;
-          bet[m] = d.gn_beta;
-          ep[m] = d.gn_eps;
-          sc[m] = const_cast<float*>(calls[i].s0->d_scale);
-          sh[m] = const_cast<float*>(calls[i].s0->d_shift);
-          ++m;
-          d.gn_part = nullptr;
-        }
-        if (m) {
-          int rc = tln_groupnorm_from_partials_multi(m, part, vv, cc, gg, gam, bet, ep, sc, sh, stream_);
-          if (rc) return rc;
-        }
+        int rc = finalize_pending_gn(true);
+        if (rc) return rc;
+        for (int i = 0; i < n; ++i) gs[i] = q[i].g;
       }
       int rc = tln_gemm_v2_launch_multi(gs, n, calls[0].w_is_nk != 0, s);
       if (rc) return rc;
@@ -1285,7 +1293,16 @@ extern "C" int tln_gather_gemm_multi(const tln_gemm_call* calls, int n, void* st
       return TLN_OK;
     }
   }
-  // one launch only for products of the same shape class that all take the direct kernel as it is
+  // one launch only for products of the same shape class that all take the direct kernel; sources whose GroupNorm the
+  // kernel does not finalise itself get their scale / shift first (one launch for all of them)
+  {
+    bool all_direct = true;
+    for (int i = 0; i < n; ++i) all_direct = all_direct && q[i].direct && !q[i].v2;
+    if (all_direct) {
+      int rc = finalize_pending_gn(false);
+      if (rc) return rc;
+    }
+  }
   bool same = true;
   int64_t mmax = 0, tiles = 0;
   for (int i = 0; i < n && same; ++i) {
@@ -1296,7 +1313,13 @@ extern "C" int tln_gather_gemm_multi(const tln_gemm_call* calls, int n, void* st
     if (gi.M > mmax) mmax = gi.M;
     tiles += tln_cdiv(gi.M, 32) * tln_cdiv(gi.N, 32);
   }
-  if (!same) return one_by_one();
+  if (!same) {
+    if (getenv("TLN_MULTI_DEBUG"))
+      fprintf(stderr, "multi n=%d NOT shared: M=%ld N=%d nsrc=%d cin=%d taps=%d direct=%d gnfb=%d v2=%d | M1=%ld N1=%d cin1=%d\n", n,
+              (long)q[0].g.M, q[0].g.N, q[0].g.nsrc, q[0].g.s[0].cin, q[0].g.s[0].taps, (int)q[0].direct, (int)q[0].gn_fallback,
+              (int)q[0].v2, (long)q[1].g.M, q[1].g.N, q[1].g.s[0].cin);
+    return one_by_one();
+  }
   hipStream_t s = (hipStream_t)stream_;
   // waves per tile from the work of ALL problems (they share the CUs)
   int G = choose_groups(tiles, q[0].nchunks);
