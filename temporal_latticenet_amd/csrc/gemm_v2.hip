@@ -368,7 +368,8 @@ bool tln_gemm_v2_multi_ok(const GemmArgs* g, int n, bool w_is_nk, const bool* ve
     total += g[i].M;
   }
   (void)w_is_nk;
-  return total >= g_v2_min_m;
+  static const int64_t multi_min = getenv("TLN_V2_MULTI_MIN_M") ? atoll(getenv("TLN_V2_MULTI_MIN_M")) : 0;
+  return total >= (multi_min > 0 ? multi_min : g_v2_min_m);
 }
 
 template <int WM, int WN, int TM, int TN, bool W_NK, bool PRO>
