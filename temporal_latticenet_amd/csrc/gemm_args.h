@@ -56,3 +56,7 @@ int tln_gemm_v2_launch(GemmArgs& g, bool w_is_nk, hipStream_t s);
 // n products of one shape class whose rows TOGETHER make a large M (lock-stepped sequences on a coarse level): one launch
 bool tln_gemm_v2_multi_ok(const GemmArgs* g, int n, bool w_is_nk, const bool* vec);
 int tln_gemm_v2_launch_multi(GemmArgs* g, int n, bool w_is_nk, hipStream_t s);
+// the GRU cell's second product with the gates in its epilogue (large V, C a multiple of 64)
+bool tln_gemm_v2_gru_ok(int64_t V, int64_t Vh, int C);
+int tln_gemm_v2_launch_gru(const float* d_h, int64_t Vh, int64_t V, int C, const float* d_w_hh, const float* d_b_hh,
+                           const float* d_gi, float* d_out, hipStream_t s);

@@ -28,7 +28,14 @@ __device__ __attribute__((aligned(16))) float g_v2_zero[4] = {0.f, 0.f, 0.f, 0.f
 
 #define V2_STAGES 3
 
-template <int WM, int WN, int TM, int TN, bool W_NK, bool PRO>
+// GRU = true (only <4,2,1,3, W_NK, !PRO>, N = 3C, C a multiple of 64): the product is h @ W_hh^T of a GRU cell and the
+// epilogue is the cell (K9 without its kernel and without gh ever reaching memory).  The 192 columns of a block are
+// 64 channels x 3 gates, ordered so that the three 32-column tiles of a WAVE are the r, z, n gates of the same 32
+// channels (column t of the block: wave t/96, gate (t%96)/32, channel 64*blockIdx.y + 32*(t/96) + t%32; the weight row
+// staged for it is gate*C + channel): r, z, n of one (row, channel) then sit at the same accumulator index of the
+// wave's three tiles.  g.res = gi = x @ W_ih^T + b_ih ([M, 3C]), g.bias = b_hh, the A source is h itself (rows past
+// src_rows are the zero padding of lm:59-60), g.out = h' [M, C].
+template <int WM, int WN, int TM, int TN, bool W_NK, bool PRO, bool GRU = false>
 __device__ __forceinline__ void v2_body(const GemmArgs& g) {
   constexpr int NT = 64 * WM * WN;
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
@@ -113,7 +120,8 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
         data = g.W + (int64_t)(kbase + k) * g.ldw + (ok ? n : 0);
       } else {
         const int r = e >> 3, q = e & 7;
-        const int n = n0 + r;
+        int n = n0 + r;
+        if (GRU) n = ((r % 96) >> 5) * s.cin + 64 * (int)blockIdx.y + 32 * (r / 96) + (r & 31);
         ok = n < g.N;
         data = g.W + (int64_t)(ok ? n : 0) * g.ldw + kbase + 4 * (q ^ ((r >> 1) & 7));
       }
@@ -229,6 +237,34 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
   // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).  The residual is loaded for a whole
   // 32x32 tile at once from clamped (always valid) addresses: a per-element "load or not" makes the compiler branch
   // around every load and wait for each one.
+  if constexpr (GRU) {
+    static_assert(TM == 1 && TN == 3 && WN == 2 && W_NK && !PRO, "the GRU epilogue is written for the 128 x 192 tile");
+    const int C = s.cin;
+    const int ch = 64 * (int)blockIdx.y + 32 * wn + l31;
+    const float br = g.bias ? g.bias[ch] : 0.f, bz = g.bias ? g.bias[C + ch] : 0.f, bn = g.bias ? g.bias[2 * C + ch] : 0.f;
+    const int64_t mrow0 = m0 + wm * 32;
+    float gir[16], giz[16], gin[16], hv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {   // every load from a clamped (always valid) address, before the arithmetic
+      const int64_t m = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      const int64_t mc = m < g.M ? m : g.M - 1;
+      const float* gi = g.res + mc * g.ld_res;
+      gir[r] = gi[ch];
+      giz[r] = gi[C + ch];
+      gin[r] = gi[2 * C + ch];
+      hv[r] = s.src[(mc < src_rows ? mc : 0) * s.ld + ch];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t m = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      const float rr = 1.0f / (1.0f + expf(-(gir[r] + (acc[0][0][r] + br))));
+      const float zz = 1.0f / (1.0f + expf(-(giz[r] + (acc[0][1][r] + bz))));
+      const float nn = tanhf(gin[r] + rr * (acc[0][2][r] + bn));
+      const float hp = m < src_rows ? hv[r] : 0.0f;
+      if (m < g.M) g.out[m * g.ld_out + ch] = (1.0f - zz) * nn + zz * hp;
+    }
+    return;
+  }
   const bool has_res = g.res != nullptr;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -271,6 +307,10 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
 template <int WM, int WN, int TM, int TN, bool W_NK, bool PRO>
 __global__ void __launch_bounds__(64 * WM * WN) k_gather_gemm_v2(const GemmArgs g) {
   v2_body<WM, WN, TM, TN, W_NK, PRO>(g);
+}
+
+__global__ void __launch_bounds__(512) k_gather_gemm_v2_gru(const GemmArgs g) {
+  v2_body<4, 2, 1, 3, true, false, true>(g);
 }
 
 // several products of one shape class in one launch (blockIdx.z = product): the coarse levels of lock-stepped
@@ -405,6 +445,40 @@ int tln_gemm_v2_launch_multi(GemmArgs* g, int n, bool w_is_nk, hipStream_t s) {
   const bool pro = g[0].s[0].scale != nullptr;
   if (w_is_nk) return pro ? dispatch_v2_multi<true, true>(g, n, s) : dispatch_v2_multi<true, false>(g, n, s);
   return pro ? dispatch_v2_multi<false, true>(g, n, s) : dispatch_v2_multi<false, false>(g, n, s);
+}
+
+// h' = GRUCell given gi = x @ W_ih^T + b_ih: the product h @ W_hh^T with the gates in its epilogue (see v2_body)
+bool tln_gemm_v2_gru_ok(int64_t V, int64_t Vh, int C) {
+  static const bool off = getenv("TLN_GRU_FUSED_OFF") != nullptr;
+  return !off && !g_v2_off && V >= g_v2_min_m && V < (1ll << 31) && Vh >= 1 && Vh <= V && C % 64 == 0 && C <= 1024;
+}
+int tln_gemm_v2_launch_gru(const float* d_h, int64_t Vh, int64_t V, int C, const float* d_w_hh, const float* d_b_hh,
+                           const float* d_gi, float* d_out, hipStream_t s) {
+  GemmArgs g{};
+  g.M = V;
+  g.N = 3 * C;
+  g.K0 = C;
+  g.nsrc = 1;
+  g.s[0].src = d_h;
+  g.s[0].src_rows = Vh;
+  g.s[0].ld = C;
+  g.s[0].cin = C;
+  g.s[0].taps = 1;
+  g.W = d_w_hh;
+  g.ldw = C;
+  g.bias = d_b_hh;
+  g.res = d_gi;
+  g.ld_res = 3 * (int64_t)C;
+  g.out = d_out;
+  g.ld_out = C;
+  g.splits = 1;
+  constexpr int BM = 128, BN = 192;
+  const size_t lds = (size_t)V2_STAGES * (BM + BN) * 128 + (size_t)BM * TLN_TAPS * 4 + (size_t)2 * C * 4;
+  TLN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gather_gemm_v2_gru), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds));
+  dim3 grid((unsigned)tln_cdiv(V, BM), (unsigned)(3 * C / BN), 1);
+  hipLaunchKernelGGL(k_gather_gemm_v2_gru, grid, dim3(512), lds, s, g);
+  return TLN_OK;
 }
 
 int tln_gemm_v2_launch(GemmArgs& g, bool w_is_nk, hipStream_t s) {

@@ -174,11 +174,13 @@ def test_groupnorm_stats(gpu, V, C):
     np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=1e-4, atol=2e-5)
 
 
-@pytest.mark.parametrize("C", [64, 128, 192])
-def test_gru_cell(gpu, C):
+@pytest.mark.parametrize("C,V,Vh", [(64, 3000, 2500), (128, 3000, 2500), (192, 3000, 2500),
+                                    # large lattices: gi by the large-M kernel, h @ W_hh^T with the cell in its epilogue
+                                    # (k_gather_gemm_v2_gru); ragged last row tile, hidden state shorter than the frame
+                                    (64, 20011, 17000), (192, 13000, 12999), (128, 12345, 1)])
+def test_gru_cell(gpu, C, V, Vh):
     from temporal_latticenet_amd import ops
     g = torch.Generator().manual_seed(C)
-    V, Vh = 3000, 2500
     cell = torch.nn.GRUCell(C, C)
     x, h = torch.randn(V, C, generator=g), torch.randn(Vh, C, generator=g)
     out = ops.gru_cell(x.to(gpu), h.to(gpu), cell.weight_ih.detach().to(gpu), cell.weight_hh.detach().to(gpu),
