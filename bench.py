@@ -305,16 +305,18 @@ def main():
                 step_tf = (tot_fl / reps) * seqs_per_step / (elapsed / args.steps) / 1e12
                 solo = {"achieved": round(achieved, 3), "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
                         "launches_per_sequence": tot_n // reps, "avg_launch_us": round(tot_ms * 1e3 / tot_n, 2),
-                        "mode": "every gather-GEMM product of ONE %d-frame sequence (GRU projections included) replayed "
-                                "back to back on one stream running alone" % args.frames}
+                        "mode": "every gather-GEMM product of ONE %d-frame sequence replayed back to back on one stream "
+                                "running alone (the GRU cell's two projections as two plain products: the timed mode "
+                                "runs them as one fused launch with the same flops)" % args.frames}
                 # the headline figure is measured on the launches of the timed mode: with lock-step groups (--pairs P) a
                 # stream issues product i of its P sequences through one call (shared gemm_v2 launches on the coarse
                 # levels); without, a stream's launches are those of one sequence
                 if grp is not None:
                     head, head_us = grp["achieved"], grp["avg_product_us"]
-                    mode = ("every gather-GEMM product of one stream's lock-step group (%d sequences, GRU projections "
-                            "included) replayed back to back as the group issues them (product i of all sequences "
-                            "through one call), on one stream running alone" % grp["sequences"])
+                    mode = ("every gather-GEMM product of one stream's lock-step group (%d sequences) replayed back to "
+                            "back as the group issues them (product i of all sequences through one call; the GRU "
+                            "cell's two projections as two plain products: the timed mode runs them as one fused "
+                            "launch with the same flops), on one stream running alone" % grp["sequences"])
                 else:
                     head, head_us, mode = achieved, tot_ms * 1e3 / tot_n, solo["mode"]
                 roof = {"kernel": "gather-GEMM (k_gather_gemm_v2 / _v2_multi where the rows of a launch reach 12288, "

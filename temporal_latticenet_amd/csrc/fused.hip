@@ -245,14 +245,11 @@ extern "C" int tln_gru_cell(const float* d_x, const float* d_h, int64_t V, int64
   sh.src_rows = Vh;
   sh.pad_value = 0.0f;
   const tln_gemm_call ci{V, 3 * C, &sx, nullptr, d_w_ih, 1, d_b_ih, nullptr, 0, 0, gi, 3 * (int64_t)C, nullptr};
-  // large lattices: gi by the large-M kernel, then h @ W_hh^T with the cell in its epilogue — no gh in memory, no gates
-  // kernel (gemm_v2.hip); rows and channels must be 16-byte aligned as for every gemm_v2 launch
-  if (tln_gemm_v2_gru_ok(V, Vh, C) && ((uintptr_t)d_x % 16 == 0) && ((uintptr_t)d_h % 16 == 0) &&
-      ((uintptr_t)d_w_hh % 16 == 0)) {
-    int rc = tln_gather_gemm_ex(ci.M, ci.N, ci.s0, nullptr, ci.d_w, 1, ci.d_bias, nullptr, 0, 0, ci.d_out, ci.ld_out, nullptr,
-                                stream_);
-    if (rc) return rc;
-    rc = tln_gemm_v2_launch_gru(d_h, Vh, V, C, d_w_hh, d_b_hh, gi, d_out, (hipStream_t)stream_);
+  // large lattices: the whole cell as ONE two-source product with the gates in its epilogue — neither gi nor gh in
+  // memory, no gates kernel (gemm_v2.hip); rows and channels must be 16-byte aligned as for every gemm_v2 launch
+  if (tln_gemm_v2_gru_ok(V, Vh, C) && d_b_ih && d_b_hh && ((uintptr_t)d_x % 16 == 0) && ((uintptr_t)d_h % 16 == 0) &&
+      ((uintptr_t)d_w_ih % 16 == 0) && ((uintptr_t)d_w_hh % 16 == 0)) {
+    int rc = tln_gemm_v2_launch_gru(d_x, d_h, Vh, V, C, d_w_ih, d_w_hh, d_b_ih, d_b_hh, d_out, (hipStream_t)stream_);
     if (rc) return rc;
     TLN_LAUNCH_CHECK();
     return TLN_OK;

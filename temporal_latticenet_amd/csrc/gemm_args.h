@@ -39,6 +39,9 @@ struct GemmArgs {
   int* counters;    // split-K arrival counters [tiles], zero between launches
   int splits;
   unsigned long long* dbg;  // diagnostic: s_memtime stamps of block (0,0,0) (tools/gemm_stamps.py), else NULL
+  // the GRU cell as ONE product (gemm_v2.hip, k_gather_gemm_v2_gru): weights and bias of the second source (h)
+  const float* W2;
+  const float* bias2;
 };
 
 
@@ -56,7 +59,7 @@ int tln_gemm_v2_launch(GemmArgs& g, bool w_is_nk, hipStream_t s);
 // n products of one shape class whose rows TOGETHER make a large M (lock-stepped sequences on a coarse level): one launch
 bool tln_gemm_v2_multi_ok(const GemmArgs* g, int n, bool w_is_nk, const bool* vec);
 int tln_gemm_v2_launch_multi(GemmArgs* g, int n, bool w_is_nk, hipStream_t s);
-// the GRU cell's second product with the gates in its epilogue (large V, C a multiple of 64)
+// the GRU cell as one two-source product with the gates in its epilogue (large V, C a multiple of 64)
 bool tln_gemm_v2_gru_ok(int64_t V, int64_t Vh, int C);
-int tln_gemm_v2_launch_gru(const float* d_h, int64_t Vh, int64_t V, int C, const float* d_w_hh, const float* d_b_hh,
-                           const float* d_gi, float* d_out, hipStream_t s);
+int tln_gemm_v2_launch_gru(const float* d_x, const float* d_h, int64_t Vh, int64_t V, int C, const float* d_w_ih,
+                           const float* d_w_hh, const float* d_b_ih, const float* d_b_hh, float* d_out, hipStream_t s);

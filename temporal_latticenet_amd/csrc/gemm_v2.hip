@@ -21,6 +21,7 @@
 // One source only (the two-source products live on small levels); rows past the source read as zeros (pad = 0).
 #include "gemm_args.h"
 #include <stdlib.h>
+#include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -28,13 +29,15 @@ __device__ __attribute__((aligned(16))) float g_v2_zero[4] = {0.f, 0.f, 0.f, 0.f
 
 #define V2_STAGES 3
 
-// GRU = true (only <4,2,1,3, W_NK, !PRO>, N = 3C, C a multiple of 64): the product is h @ W_hh^T of a GRU cell and the
-// epilogue is the cell (K9 without its kernel and without gh ever reaching memory).  The 192 columns of a block are
-// 64 channels x 3 gates, ordered so that the three 32-column tiles of a WAVE are the r, z, n gates of the same 32
-// channels (column t of the block: wave t/96, gate (t%96)/32, channel 64*blockIdx.y + 32*(t/96) + t%32; the weight row
-// staged for it is gate*C + channel): r, z, n of one (row, channel) then sit at the same accumulator index of the
-// wave's three tiles.  g.res = gi = x @ W_ih^T + b_ih ([M, 3C]), g.bias = b_hh, the A source is h itself (rows past
-// src_rows are the zero padding of lm:59-60), g.out = h' [M, C].
+// GRU = true (only <4,2,1,3, W_NK, !PRO>, N = 3C, C a multiple of 64): the whole GRU cell (K9) as ONE product with two
+// sources: the K loop runs over the C channels of x (weights W_ih, g.W) and then over the C channels of h (W_hh, g.W2;
+// rows past s[1].src_rows are the zero padding of lm:59-60).  The 192 columns of a block are 64 channels x 3 gates,
+// ordered so that the three 32-column tiles of a WAVE are the r, z, n gates of the same 32 channels (column t of the
+// block: wave t/96, gate (t%96)/32, channel 64*blockIdx.y + 32*(t/96) + t%32; the weight row staged for it is
+// gate*C + channel): r, z, n of one (row, channel) sit at the same accumulator index of the wave's tiles.  r and z need
+// only gi + gh — one accumulator over both sources —, n needs gi_n and gh_n apart: a fourth accumulator tile takes the
+// h chunks of the n gate.  The cell is the epilogue: neither gi nor gh reaches memory, no gates kernel.
+// g.bias = b_ih, g.bias2 = b_hh, g.out = h' [M, C].
 template <int WM, int WN, int TM, int TN, bool W_NK, bool PRO, bool GRU = false>
 __device__ __forceinline__ void v2_body(const GemmArgs& g) {
   constexpr int NT = 64 * WM * WN;
@@ -70,6 +73,7 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
     int idx = -1;
     if (m < g.M) idx = has_table ? s.table[m * taps + (i - r * taps)] : (int)m;
     if (idx >= src_rows) idx = -1;            // rows past the source: zeros (pad value 0, checked on the host)
+    if (GRU && (i - r * taps) == 1 && idx >= (int)g.s[1].src_rows) idx = -1;   // "tap" 1 = the row of h
     Is[i] = idx;
   }
   if (PRO) {
@@ -91,7 +95,10 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
     const int t = t_raw < nchunks ? t_raw : nchunks - 1;
     const int tap = t / cpt;
     const int c0 = (t - tap * cpt) << 5;
-    const int kbase = tap * s.cin + c0;
+    // (GRU: "tap" 1 = the second source h with its own weights, both [3C][C])
+    const int kbase = GRU ? c0 : tap * s.cin + c0;
+    const float* srcp = (GRU && tap) ? g.s[1].src : s.src;
+    const float* Wp = (GRU && tap) ? g.W2 : g.W;
     char* As = ring + st * STAGE;
     char* Bs = As + A_BYTES;
     int idx[A_PIECES];
@@ -103,7 +110,7 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
       const int r = e >> 3, q = e & 7;
       // both addresses are computed, one is selected: a branch around the multiply would split the loop body
       const int ic = idx[p] > 0 ? idx[p] : 0;
-      const float* data = s.src + (int64_t)ic * s.ld + c0 + 4 * (q ^ ((r >> 1) & 7));
+      const float* data = srcp + (int64_t)ic * s.ld + c0 + 4 * (q ^ ((r >> 1) & 7));
       const float* src = idx[p] >= 0 ? data : zero;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(As + (p * NT + wv * 64) * 16), 16, 0, 0);
@@ -117,13 +124,13 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
         const int k = e / (BN / 4), nq = e - k * (BN / 4);
         const int n = n0 + 4 * nq;
         ok = n < g.N;
-        data = g.W + (int64_t)(kbase + k) * g.ldw + (ok ? n : 0);
+        data = Wp + (int64_t)(kbase + k) * g.ldw + (ok ? n : 0);
       } else {
         const int r = e >> 3, q = e & 7;
         int n = n0 + r;
         if (GRU) n = ((r % 96) >> 5) * s.cin + 64 * (int)blockIdx.y + 32 * (r / 96) + (r & 31);
         ok = n < g.N;
-        data = g.W + (int64_t)(ok ? n : 0) * g.ldw + kbase + 4 * (q ^ ((r >> 1) & 7));
+        data = Wp + (int64_t)(ok ? n : 0) * g.ldw + kbase + 4 * (q ^ ((r >> 1) & 7));
       }
       const float* src = ok ? data : zero;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -131,11 +138,12 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
     }
   };
 
-  f32x16 acc[TM][TN];
+  constexpr int TNA = GRU ? TN + 1 : TN;   // GRU: tile TN takes the h chunks of the n gate (gh_n apart from gi_n)
+  f32x16 acc[TM][TNA];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+    for (int j = 0; j < TNA; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
@@ -172,7 +180,8 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
       }
     }
   };
-  auto frag_mma = [&](int j, int c0, const bool (&live)[TM], Frag& f) {
+  auto frag_mma = [&](int j, int c0, const bool (&live)[TM], Frag& f, auto hpart) {
+    constexpr bool H = decltype(hpart)::value;   // GRU: this chunk belongs to the second source
     if (PRO) {
       const f32x4 sc = *reinterpret_cast<const f32x4*>(Gsc + c0 + 8 * j + 4 * half);
       const f32x4 sh = *reinterpret_cast<const f32x4*>(Gsh + c0 + 8 * j + 4 * half);
@@ -191,15 +200,19 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int jn = 0; jn < TN; ++jn)
-          acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][e], f.b[jn][e], acc[i][jn], 0, 0, 0);
+        for (int jn = 0; jn < TN; ++jn) {
+          constexpr int dummy = 0;
+          (void)dummy;
+          const int slot = (GRU && H && jn == TN - 1) ? TN : jn;   // compile-time after unrolling
+          acc[i][slot] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][e], f.b[jn][e], acc[i][slot], 0, 0, 0);
+        }
   };
 
   // ---- main loop: ring of three stages, DMAs two chunks ahead, one barrier per chunk
   issue(0, 0);
   issue(1, 1);
   int st = 0;
-  for (int t = 0; t < nchunks; ++t) {
+  auto chunk = [&](int t, auto hpart) {
     // this thread's DMAs of chunk t have landed (those of chunk t+1 may still fly); after the barrier everybody's
     // have, and everybody has finished reading the stage that chunk t+2 is about to overwrite
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PIECES) : "memory");
@@ -213,13 +226,13 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
     Frag f0, f1;
     frag_load(0, As, Bs, f0);
     frag_load(1, As, Bs, f1);
-    frag_mma(0, c0, live, f0);
+    frag_mma(0, c0, live, f0, hpart);
     issue(t + 2, st == 0 ? 2 : st - 1);
     frag_load(2, As, Bs, f0);
-    frag_mma(1, c0, live, f1);
+    frag_mma(1, c0, live, f1, hpart);
     frag_load(3, As, Bs, f1);
-    frag_mma(2, c0, live, f0);
-    frag_mma(3, c0, live, f1);
+    frag_mma(2, c0, live, f0, hpart);
+    frag_mma(3, c0, live, f1, hpart);
     // scheduling hint for the whole (branch-free) chunk body: one MFMA, then a little of everything else — an MFMA
     // occupies the matrix pipe for 16 issue slots, and what a wave issues between two MFMAs is free, what it issues
     // in a lump between two runs of MFMAs is not (with one wave per SIMD nobody else fills the pipe meanwhile)
@@ -231,6 +244,12 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
       if ((k & 7) == 7) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read (the LDS-DMAs)
     }
     st = st == V2_STAGES - 1 ? 0 : st + 1;
+  };
+  if constexpr (GRU) {
+    for (int t = 0; t < cpt; ++t) chunk(t, std::false_type{});          // the channels of x
+    for (int t = cpt; t < nchunks; ++t) chunk(t, std::true_type{});     // the channels of h
+  } else {
+    for (int t = 0; t < nchunks; ++t) chunk(t, std::false_type{});
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the repeated DMAs of the last two rounds
 
@@ -241,26 +260,24 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
     static_assert(TM == 1 && TN == 3 && WN == 2 && W_NK && !PRO, "the GRU epilogue is written for the 128 x 192 tile");
     const int C = s.cin;
     const int ch = 64 * (int)blockIdx.y + 32 * wn + l31;
-    const float br = g.bias ? g.bias[ch] : 0.f, bz = g.bias ? g.bias[C + ch] : 0.f, bn = g.bias ? g.bias[2 * C + ch] : 0.f;
+    // r, z: one bias for the sum; n: the two halves apart
+    const float br = g.bias[ch] + g.bias2[ch], bz = g.bias[C + ch] + g.bias2[C + ch];
+    const float bni = g.bias[2 * C + ch], bnh = g.bias2[2 * C + ch];
     const int64_t mrow0 = m0 + wm * 32;
-    float gir[16], giz[16], gin[16], hv[16];
+    const int64_t hrows = g.s[1].src_rows;
+    float hv[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {   // every load from a clamped (always valid) address, before the arithmetic
       const int64_t m = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      const int64_t mc = m < g.M ? m : g.M - 1;
-      const float* gi = g.res + mc * g.ld_res;
-      gir[r] = gi[ch];
-      giz[r] = gi[C + ch];
-      gin[r] = gi[2 * C + ch];
-      hv[r] = s.src[(mc < src_rows ? mc : 0) * s.ld + ch];
+      hv[r] = g.s[1].src[(m < hrows ? m : 0) * s.ld + ch];
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int64_t m = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      const float rr = 1.0f / (1.0f + expf(-(gir[r] + (acc[0][0][r] + br))));
-      const float zz = 1.0f / (1.0f + expf(-(giz[r] + (acc[0][1][r] + bz))));
-      const float nn = tanhf(gin[r] + rr * (acc[0][2][r] + bn));
-      const float hp = m < src_rows ? hv[r] : 0.0f;
+      const float rr = 1.0f / (1.0f + expf(-(acc[0][0][r] + br)));
+      const float zz = 1.0f / (1.0f + expf(-(acc[0][1][r] + bz)));
+      const float nn = tanhf((acc[0][2][r] + bni) + rr * (acc[0][3][r] + bnh));
+      const float hp = m < hrows ? hv[r] : 0.0f;
       if (m < g.M) g.out[m * g.ld_out + ch] = (1.0f - zz) * nn + zz * hp;
     }
     return;
@@ -447,28 +464,33 @@ int tln_gemm_v2_launch_multi(GemmArgs* g, int n, bool w_is_nk, hipStream_t s) {
   return pro ? dispatch_v2_multi<false, true>(g, n, s) : dispatch_v2_multi<false, false>(g, n, s);
 }
 
-// h' = GRUCell given gi = x @ W_ih^T + b_ih: the product h @ W_hh^T with the gates in its epilogue (see v2_body)
+// h' = GRUCell(x, pad(h)) as one two-source product with the cell in its epilogue (see v2_body)
 bool tln_gemm_v2_gru_ok(int64_t V, int64_t Vh, int C) {
   static const bool off = getenv("TLN_GRU_FUSED_OFF") != nullptr;
   return !off && !g_v2_off && V >= g_v2_min_m && V < (1ll << 31) && Vh >= 1 && Vh <= V && C % 64 == 0 && C <= 1024;
 }
-int tln_gemm_v2_launch_gru(const float* d_h, int64_t Vh, int64_t V, int C, const float* d_w_hh, const float* d_b_hh,
-                           const float* d_gi, float* d_out, hipStream_t s) {
+int tln_gemm_v2_launch_gru(const float* d_x, const float* d_h, int64_t Vh, int64_t V, int C, const float* d_w_ih,
+                           const float* d_w_hh, const float* d_b_ih, const float* d_b_hh, float* d_out, hipStream_t s) {
   GemmArgs g{};
   g.M = V;
   g.N = 3 * C;
-  g.K0 = C;
-  g.nsrc = 1;
-  g.s[0].src = d_h;
-  g.s[0].src_rows = Vh;
+  g.K0 = 2 * C;
+  g.nsrc = 2;
+  g.s[0].src = d_x;
+  g.s[0].src_rows = V;
   g.s[0].ld = C;
   g.s[0].cin = C;
-  g.s[0].taps = 1;
-  g.W = d_w_hh;
+  g.s[0].taps = 2;            // the kernel's "taps" are the two sources here
+  g.s[1].src = d_h;
+  g.s[1].src_rows = Vh;
+  g.s[1].ld = C;
+  g.s[1].cin = C;
+  g.s[1].taps = 1;
+  g.W = d_w_ih;
+  g.W2 = d_w_hh;
   g.ldw = C;
-  g.bias = d_b_hh;
-  g.res = d_gi;
-  g.ld_res = 3 * (int64_t)C;
+  g.bias = d_b_ih;
+  g.bias2 = d_b_hh;
   g.out = d_out;
   g.ld_out = C;
   g.splits = 1;
