@@ -38,7 +38,8 @@ __device__ __attribute__((aligned(16))) float g_v2_zero[4] = {0.f, 0.f, 0.f, 0.f
 // only gi + gh — one accumulator over both sources —, n needs gi_n and gh_n apart: a fourth accumulator tile takes the
 // h chunks of the n gate.  The cell is the epilogue: neither gi nor gh reaches memory, no gates kernel.
 // g.bias = b_ih, g.bias2 = b_hh, g.out = h' [M, C].
-template <int WM, int WN, int TM, int TN, bool W_NK, bool PRO, bool GRU = false>
+// STAGES = 3: DMAs two chunks ahead; STAGES = 2 (128 x 128 tile): one chunk ahead, but two workgroups fit a CU's LDS
+template <int WM, int WN, int TM, int TN, bool W_NK, bool PRO, bool GRU = false, int STAGES = V2_STAGES>
 __device__ __forceinline__ void v2_body(const GemmArgs& g) {
   constexpr int NT = 64 * WM * WN;
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
@@ -51,7 +52,7 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
 
   extern __shared__ __attribute__((aligned(16))) char smem2[];
   char* ring = smem2;
-  int* Is = reinterpret_cast<int*>(smem2 + V2_STAGES * STAGE);            // [BM][taps]
+  int* Is = reinterpret_cast<int*>(smem2 + STAGES * STAGE);            // [BM][taps]
   const SrcDev& s = g.s[0];
   const int taps = s.taps;
   float* Gsc = reinterpret_cast<float*>(Is + BM * TLN_TAPS);
@@ -210,12 +211,12 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
 
   // ---- main loop: ring of three stages, DMAs two chunks ahead, one barrier per chunk
   issue(0, 0);
-  issue(1, 1);
+  if (STAGES == 3) issue(1, 1);
   int st = 0;
   auto chunk = [&](int t, auto hpart) {
     // this thread's DMAs of chunk t have landed (those of chunk t+1 may still fly); after the barrier everybody's
     // have, and everybody has finished reading the stage that chunk t+2 is about to overwrite
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PIECES) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(STAGES == 3 ? PIECES : 0) : "memory");
     const int tap = t / cpt;
     const int c0 = (t - tap * cpt) << 5;
     const char* As = ring + st * STAGE;
@@ -227,7 +228,8 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
     frag_load(0, As, Bs, f0);
     frag_load(1, As, Bs, f1);
     frag_mma(0, c0, live, f0, hpart);
-    issue(t + 2, st == 0 ? 2 : st - 1);
+    if (STAGES == 3) issue(t + 2, st == 0 ? 2 : st - 1);
+    else issue(t + 1, st ^ 1);
     frag_load(2, As, Bs, f0);
     frag_mma(1, c0, live, f1, hpart);
     frag_load(3, As, Bs, f1);
@@ -243,7 +245,7 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
       __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);   // VALU
       if ((k & 7) == 7) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read (the LDS-DMAs)
     }
-    st = st == V2_STAGES - 1 ? 0 : st + 1;
+    st = st == STAGES - 1 ? 0 : st + 1;
   };
   if constexpr (GRU) {
     for (int t = 0; t < cpt; ++t) chunk(t, std::false_type{});          // the channels of x
@@ -321,9 +323,9 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
     }
 }
 
-template <int WM, int WN, int TM, int TN, bool W_NK, bool PRO>
+template <int WM, int WN, int TM, int TN, bool W_NK, bool PRO, int STAGES = V2_STAGES>
 __global__ void __launch_bounds__(64 * WM * WN) k_gather_gemm_v2(const GemmArgs g) {
-  v2_body<WM, WN, TM, TN, W_NK, PRO>(g);
+  v2_body<WM, WN, TM, TN, W_NK, PRO, false, STAGES>(g);
 }
 
 __global__ void __launch_bounds__(512) k_gather_gemm_v2_gru(const GemmArgs g) {
@@ -332,11 +334,11 @@ __global__ void __launch_bounds__(512) k_gather_gemm_v2_gru(const GemmArgs g) {
 
 // several products of one shape class in one launch (blockIdx.z = product): the coarse levels of lock-stepped
 // sequences, whose rows only together fill the chip with 128-row tiles
-template <int WM, int WN, int TM, int TN, bool W_NK, bool PRO>
+template <int WM, int WN, int TM, int TN, bool W_NK, bool PRO, int STAGES = V2_STAGES>
 __global__ void __launch_bounds__(64 * WM * WN) k_gather_gemm_v2_multi(const GemmArgsN<TLN_GEMM_MULTI_MAX> gg) {
   const GemmArgs& g = gg.a[blockIdx.z];
   if ((int64_t)blockIdx.x * (32 * TM * WM) >= g.M) return;   // (the grid is sized for the longest product)
-  v2_body<WM, WN, TM, TN, W_NK, PRO>(g);
+  v2_body<WM, WN, TM, TN, W_NK, PRO, false, STAGES>(g);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -367,12 +369,21 @@ bool tln_gemm_v2_ok(const GemmArgs& g, bool w_is_nk, bool vec) {
   return n == 64 || n == 96 || n % 128 == 0 || n % 192 == 0;
 }
 
-template <int WM, int WN, int TM, int TN, bool W_NK, bool PRO>
+// which tiles run with a ring of TWO stages (bit 0: 128 x 128, bit 1: 128 x 64; TLN_V2_STAGES2, default both): the DMAs
+// run one chunk ahead instead of two, but the workgroup needs 69 / 53 KB of LDS instead of 101 / 77 and two / three of
+// them share a CU — measured +1.6 % clouds/s together (the 128 x 192 tile stays at three stages: 86 KB with two, still
+// one workgroup per CU)
+static int v2_two_stage() {
+  static const int v = getenv("TLN_V2_STAGES2") ? atoi(getenv("TLN_V2_STAGES2")) : 3;
+  return v;
+}
+
+template <int WM, int WN, int TM, int TN, bool W_NK, bool PRO, int STAGES = V2_STAGES>
 static int launch_v2(GemmArgs& g, hipStream_t s) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
-  const size_t lds = (size_t)V2_STAGES * (BM + BN) * 128 + (size_t)BM * TLN_TAPS * 4 + (size_t)2 * g.s[0].cin * 4;
+  const size_t lds = (size_t)STAGES * (BM + BN) * 128 + (size_t)BM * TLN_TAPS * 4 + (size_t)2 * g.s[0].cin * 4;
   TLN_REQUIRE(lds <= 160 * 1024, "gemm v2: LDS %zu B", lds);
-  auto kern = k_gather_gemm_v2<WM, WN, TM, TN, W_NK, PRO>;
+  auto kern = k_gather_gemm_v2<WM, WN, TM, TN, W_NK, PRO, STAGES>;
   // set every time: the attribute is per device and this library serves several (one process per GPU is the normal case)
   TLN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   dim3 grid((unsigned)tln_cdiv(g.M, BM), (unsigned)tln_cdiv(g.N, BN), 1);
@@ -389,14 +400,17 @@ static int dispatch_v2(GemmArgs& g, hipStream_t s) {
   static const int waves = getenv("TLN_V2_WAVES") ? atoi(getenv("TLN_V2_WAVES")) : 8;
   if (waves == 8) {
     if (n % 192 == 0) return launch_v2<4, 2, 1, 3, W_NK, PRO>(g, s);   // 128 x 192, 8 waves of 32 x 96
-    if (n % 128 == 0) return launch_v2<4, 2, 1, 2, W_NK, PRO>(g, s);   // 128 x 128, 8 waves of 32 x 64
-    if (n == 64 && !PRO) return launch_v2<4, 2, 1, 1, W_NK, PRO>(g, s);   // 128 x 64, 8 waves of 32 x 32 (with the GroupNorm
+    if (n % 128 == 0) {   // 128 x 128, 8 waves of 32 x 64
+      return (v2_two_stage() & 1) ? launch_v2<4, 2, 1, 2, W_NK, PRO, 2>(g, s) : launch_v2<4, 2, 1, 2, W_NK, PRO>(g, s);
+    }
+    if (n == 64 && !PRO)
+      return (v2_two_stage() & 2) ? launch_v2<4, 2, 1, 1, W_NK, PRO, 2>(g, s) : launch_v2<4, 2, 1, 1, W_NK, PRO>(g, s);   // 128 x 64, 8 waves of 32 x 32 (with the GroupNorm
                                                                           // prologue both column waves would repeat it)
   }
   if (n % 192 == 0) return launch_v2<2, 2, 2, 3, W_NK, PRO>(g, s);   // 128 x 192, waves 64 x 96
   if (n % 128 == 0) return launch_v2<2, 2, 2, 2, W_NK, PRO>(g, s);   // 128 x 128, waves 64 x 64
   if (n == 96) return launch_v2<4, 1, 1, 3, W_NK, PRO>(g, s);        // 128 x 96, waves 32 x 96
-  return launch_v2<4, 1, 1, 2, W_NK, PRO>(g, s);                     // 128 x 64, waves 32 x 64
+  return (v2_two_stage() & 2) ? launch_v2<4, 1, 1, 2, W_NK, PRO, 2>(g, s) : launch_v2<4, 1, 1, 2, W_NK, PRO>(g, s);   // 128 x 64, waves 32 x 64
 }
 
 static bool v2_shape_ok(const GemmArgs& g, bool vec) {
@@ -429,12 +443,12 @@ bool tln_gemm_v2_multi_ok(const GemmArgs* g, int n, bool w_is_nk, const bool* ve
   return total >= (multi_min > 0 ? multi_min : g_v2_min_m);
 }
 
-template <int WM, int WN, int TM, int TN, bool W_NK, bool PRO>
+template <int WM, int WN, int TM, int TN, bool W_NK, bool PRO, int STAGES = V2_STAGES>
 static int launch_v2_multi(GemmArgs* g, int n, hipStream_t s) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
-  const size_t lds = (size_t)V2_STAGES * (BM + BN) * 128 + (size_t)BM * TLN_TAPS * 4 + (size_t)2 * g[0].s[0].cin * 4;
+  const size_t lds = (size_t)STAGES * (BM + BN) * 128 + (size_t)BM * TLN_TAPS * 4 + (size_t)2 * g[0].s[0].cin * 4;
   TLN_REQUIRE(lds <= 160 * 1024, "gemm v2: LDS %zu B", lds);
-  auto kern = k_gather_gemm_v2_multi<WM, WN, TM, TN, W_NK, PRO>;
+  auto kern = k_gather_gemm_v2_multi<WM, WN, TM, TN, W_NK, PRO, STAGES>;
   TLN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   GemmArgsN<TLN_GEMM_MULTI_MAX> gg;
   int64_t mmax = 0;
@@ -452,10 +466,13 @@ template <bool W_NK, bool PRO>
 static int dispatch_v2_multi(GemmArgs* g, int n, hipStream_t s) {
   const int nn = g[0].N;
   if (nn % 192 == 0) return launch_v2_multi<4, 2, 1, 3, W_NK, PRO>(g, n, s);
-  if (nn % 128 == 0) return launch_v2_multi<4, 2, 1, 2, W_NK, PRO>(g, n, s);
-  if (nn == 64 && !PRO) return launch_v2_multi<4, 2, 1, 1, W_NK, PRO>(g, n, s);
+  if (nn % 128 == 0) {
+    return (v2_two_stage() & 1) ? launch_v2_multi<4, 2, 1, 2, W_NK, PRO, 2>(g, n, s) : launch_v2_multi<4, 2, 1, 2, W_NK, PRO>(g, n, s);
+  }
+  if (nn == 64 && !PRO)
+    return (v2_two_stage() & 2) ? launch_v2_multi<4, 2, 1, 1, W_NK, PRO, 2>(g, n, s) : launch_v2_multi<4, 2, 1, 1, W_NK, PRO>(g, n, s);
   if (nn == 96) return launch_v2_multi<4, 1, 1, 3, W_NK, PRO>(g, n, s);
-  return launch_v2_multi<4, 1, 1, 2, W_NK, PRO>(g, n, s);
+  return (v2_two_stage() & 2) ? launch_v2_multi<4, 1, 1, 2, W_NK, PRO, 2>(g, n, s) : launch_v2_multi<4, 1, 1, 2, W_NK, PRO>(g, n, s);
 }
 
 int tln_gemm_v2_launch_multi(GemmArgs* g, int n, bool w_is_nk, hipStream_t s) {
