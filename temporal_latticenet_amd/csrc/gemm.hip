@@ -840,6 +840,7 @@ static int fill_src(SrcDev& d, const tln_gemm_src* s) {
   TLN_REQUIRE((s->d_scale == nullptr) == (s->d_shift == nullptr), "scale/shift must come together");
   d.src = s->d_src;
   d.table = s->d_table;
+  d.perm = nullptr;
   d.scale = s->d_scale;
   d.shift = s->d_shift;
   d.src_rows = s->src_rows;

@@ -57,6 +57,8 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
   const int taps = s.taps;
   float* Gsc = reinterpret_cast<float*>(Is + BM * TLN_TAPS);
   float* Gsh = Gsc + s.cin;
+  int* Rid = reinterpret_cast<int*>(Gsh + s.cin);   // [BM] row of block position r (the product's row order, or m0 + r)
+  int* Taps = Rid + BM;                             // [0] = number of taps present in this block, [1..] = which
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -67,16 +69,34 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
   const bool has_table = s.table != nullptr;
   const int src_rows = (int)s.src_rows;
 
-  // ---- block prologue: tap indices (or the row's own index) and the GroupNorm scale / shift -> LDS
-  for (int i = tid; i < BM * taps; i += NT) {
-    const int r = i / taps;
-    const int64_t m = m0 + r;
-    int idx = -1;
-    if (m < g.M) idx = has_table ? s.table[m * taps + (i - r * taps)] : (int)m;
-    if (idx >= src_rows) idx = -1;            // rows past the source: zeros (pad value 0, checked on the host)
-    if (GRU && (i - r * taps) == 1 && idx >= (int)g.s[1].src_rows) idx = -1;   // "tap" 1 = the row of h
-    Is[i] = idx;
+  // ---- block prologue: the rows of this block (in the table's row order when there is one: rows with the same set of
+  // present taps sit together, lattice.hip), their tap indices (or the row's own index), the GroupNorm scale / shift,
+  // and which taps at least one row of the block has (a K chunk of a tap nobody has multiplies zeros: skipped)
+  const int32_t* __restrict__ perm = s.perm;
+  for (int r = tid; r < BM; r += NT) {
+    const int64_t p = m0 + r;
+    Rid[r] = p < g.M ? (perm ? perm[p] : (int)p) : -1;
   }
+  unsigned present = 0;                       // taps seen by this wave
+  for (int i0 = 0; i0 < BM * taps; i0 += NT) {
+    const int i = i0 + tid;
+    const int r = i / taps, tap = i - r * taps;
+    int idx = -1;
+    if (i < BM * taps) {
+      const int64_t p = m0 + r;
+      const int m = p < g.M ? (perm ? perm[p] : (int)p) : -1;
+      if (m >= 0) idx = has_table ? s.table[(int64_t)m * taps + tap] : m;
+      if (idx >= src_rows) idx = -1;          // rows past the source: zeros (pad value 0, checked on the host)
+      if (GRU && tap == 1 && idx >= (int)g.s[1].src_rows) idx = -1;   // "tap" 1 = the row of h
+      Is[i] = idx;
+    }
+    if (has_table && !GRU) {
+#pragma unroll
+      for (int k = 0; k < TLN_TAPS; ++k)
+        if (__ballot(idx >= 0 && tap == k) != 0ull) present |= 1u << k;
+    }
+  }
+  if (lane == 0) Taps[16 + wv] = (int)present;   // [16 .. 16 + waves): what each wave saw
   if (PRO) {
     for (int c = tid; c < s.cin; c += NT) {
       Gsc[c] = s.scale[c];
@@ -85,17 +105,31 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();
+  // every wave builds the same list of present taps (identical values to the same words: no further barrier)
+  if (lane == 0) {
+    unsigned mask = 0;
+    for (int w = 0; w < WM * WN; ++w) mask |= (unsigned)Taps[16 + w];
+    if (!has_table || GRU) mask = (1u << taps) - 1u;   // only tap tables have holes worth skipping
+    int n_present = 0;
+    for (int k = 0; k < taps; ++k)
+      if ((mask >> k) & 1u) Taps[1 + n_present++] = k;
+    Taps[0] = n_present;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
   const int cpt = s.cin >> 5;                 // chunks per tap
-  const int nchunks = taps * cpt;
+  const int nchunks = Taps[0] * cpt;
   const float* zero = g_v2_zero;
 
   // issue the LDS-DMAs of chunk t into stage st: every thread PIECES x 16 bytes, lane-linear pieces of 1 KiB per wave
   auto issue = [&](int t_raw, int st) {
     // past the last chunk the DMAs repeat the last one into a stage nobody reads any more: no branch in the loop body
     const int t = t_raw < nchunks ? t_raw : nchunks - 1;
-    const int tap = t / cpt;
-    const int c0 = (t - tap * cpt) << 5;
+    const int ti = t / cpt;
+    const int tap = Taps[1 + ti];            // the ti-th tap present in this block
+    const int c0 = (t - ti * cpt) << 5;
     // (GRU: "tap" 1 = the second source h with its own weights, both [3C][C])
     const int kbase = GRU ? c0 : tap * s.cin + c0;
     const float* srcp = (GRU && tap) ? g.s[1].src : s.src;
@@ -210,15 +244,18 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
   };
 
   // ---- main loop: ring of three stages, DMAs two chunks ahead, one barrier per chunk
-  issue(0, 0);
-  if (STAGES == 3) issue(1, 1);
+  if (nchunks > 0) {
+    issue(0, 0);
+    if (STAGES == 3) issue(1, 1);
+  }
   int st = 0;
   auto chunk = [&](int t, auto hpart) {
     // this thread's DMAs of chunk t have landed (those of chunk t+1 may still fly); after the barrier everybody's
     // have, and everybody has finished reading the stage that chunk t+2 is about to overwrite
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(STAGES == 3 ? PIECES : 0) : "memory");
-    const int tap = t / cpt;
-    const int c0 = (t - tap * cpt) << 5;
+    const int ti = t / cpt;
+    const int tap = Taps[1 + ti];
+    const int c0 = (t - ti * cpt) << 5;
     const char* As = ring + st * STAGE;
     const char* Bs = As + A_BYTES;
     bool live[TM];
@@ -293,20 +330,21 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
       const bool ncol = n < g.N;
       const int nc = ncol ? n : g.N - 1;
       const float bias = g.bias ? g.bias[nc] : 0.f;
-      const int64_t mrow0 = m0 + wm * 32 * TM + i * 32;
+      const int prow0 = wm * 32 * TM + i * 32;           // block position of the tile's first row
+      const int64_t mrow0 = m0 + prow0;
+      int rid[16];                                       // the rows behind the 16 positions (-1: past the end)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) rid[r] = Rid[prow0 + (r & 3) + 8 * (r >> 2) + 4 * half];
       float rv[16];
       if (has_res) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int64_t m = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          rv[r] = g.res[(m < g.M ? m : g.M - 1) * g.ld_res + nc];
-        }
+        for (int r = 0; r < 16; ++r) rv[r] = g.res[(int64_t)(rid[r] >= 0 ? rid[r] : 0) * g.ld_res + nc];
       }
       double s1 = 0.0, s2 = 0.0;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int64_t m = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        const bool ok = ncol && m < g.M;
+        const int64_t m = rid[r];
+        const bool ok = ncol && m >= 0;
         float v = acc[i][j][r] + bias;
         if (has_res) v += rv[r];
         if (g.relu) v = fmaxf(v, 0.f);
@@ -355,7 +393,7 @@ extern "C" void tln_gemm_v2_config(int off, int64_t min_m) {
 }
 
 bool tln_gemm_v2_ok(const GemmArgs& g, bool w_is_nk, bool vec) {
-  if (g_v2_off || !vec || g.nsrc != 1 || g.M < g_v2_min_m) return false;
+  if ((g_v2_off & 1) || !vec || g.nsrc != 1 || g.M < g_v2_min_m) return false;
   const SrcDev& s = g.s[0];
   if (s.cin % 32 != 0 || s.cin > 1024 || s.pad != 0.f) return false;
   if (!(s.taps == 1 || s.taps == TLN_TAPS)) return false;
@@ -367,6 +405,14 @@ bool tln_gemm_v2_ok(const GemmArgs& g, bool w_is_nk, bool vec) {
   if (g.N % 32 != 0 && g.N != 96) return false;
   const int n = g.N;
   return n == 64 || n == 96 || n % 128 == 0 || n % 192 == 0;
+}
+
+// the row order of a product over a tap table (lattice.hip), unless switched off (TLN_V2_PERM_OFF, tln_gemm_v2_config bit 2)
+static const int32_t* v2_perm_of(const GemmArgs& g) {
+  static const bool off = getenv("TLN_V2_PERM_OFF") != nullptr;
+  const SrcDev& s = g.s[0];
+  if (off || (g_v2_off & 4) || s.table == nullptr || s.taps != TLN_TAPS) return nullptr;
+  return tln_table_perm(s.table, g.M);
 }
 
 // which tiles run with a ring of TWO stages (bit 0: 128 x 128, bit 1: 128 x 64; TLN_V2_STAGES2, default both): the DMAs
@@ -381,13 +427,14 @@ static int v2_two_stage() {
 template <int WM, int WN, int TM, int TN, bool W_NK, bool PRO, int STAGES = V2_STAGES>
 static int launch_v2(GemmArgs& g, hipStream_t s) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
-  const size_t lds = (size_t)STAGES * (BM + BN) * 128 + (size_t)BM * TLN_TAPS * 4 + (size_t)2 * g.s[0].cin * 4;
+  const size_t lds = (size_t)STAGES * (BM + BN) * 128 + (size_t)BM * TLN_TAPS * 4 + (size_t)2 * g.s[0].cin * 4 + (size_t)(BM + 32) * 4;
   TLN_REQUIRE(lds <= 160 * 1024, "gemm v2: LDS %zu B", lds);
   auto kern = k_gather_gemm_v2<WM, WN, TM, TN, W_NK, PRO, STAGES>;
   // set every time: the attribute is per device and this library serves several (one process per GPU is the normal case)
   TLN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   dim3 grid((unsigned)tln_cdiv(g.M, BM), (unsigned)tln_cdiv(g.N, BN), 1);
   g.splits = 1;
+  g.s[0].perm = v2_perm_of(g);
   hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, s, g);
   return TLN_OK;
 }
@@ -414,7 +461,7 @@ static int dispatch_v2(GemmArgs& g, hipStream_t s) {
 }
 
 static bool v2_shape_ok(const GemmArgs& g, bool vec) {
-  if (g_v2_off || !vec || g.nsrc != 1) return false;
+  if ((g_v2_off & 1) || !vec || g.nsrc != 1) return false;
   const SrcDev& s = g.s[0];
   if (s.cin % 32 != 0 || s.cin > 1024 || s.pad != 0.f) return false;
   if (!(s.taps == 1 || s.taps == TLN_TAPS)) return false;
@@ -446,7 +493,7 @@ bool tln_gemm_v2_multi_ok(const GemmArgs* g, int n, bool w_is_nk, const bool* ve
 template <int WM, int WN, int TM, int TN, bool W_NK, bool PRO, int STAGES = V2_STAGES>
 static int launch_v2_multi(GemmArgs* g, int n, hipStream_t s) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
-  const size_t lds = (size_t)STAGES * (BM + BN) * 128 + (size_t)BM * TLN_TAPS * 4 + (size_t)2 * g[0].s[0].cin * 4;
+  const size_t lds = (size_t)STAGES * (BM + BN) * 128 + (size_t)BM * TLN_TAPS * 4 + (size_t)2 * g[0].s[0].cin * 4 + (size_t)(BM + 32) * 4;
   TLN_REQUIRE(lds <= 160 * 1024, "gemm v2: LDS %zu B", lds);
   auto kern = k_gather_gemm_v2_multi<WM, WN, TM, TN, W_NK, PRO, STAGES>;
   TLN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -455,6 +502,7 @@ static int launch_v2_multi(GemmArgs* g, int n, hipStream_t s) {
   for (int i = 0; i < TLN_GEMM_MULTI_MAX; ++i) {
     gg.a[i] = g[i < n ? i : 0];
     gg.a[i].splits = 1;
+    gg.a[i].s[0].perm = v2_perm_of(gg.a[i]);
     if (i < n && g[i].M > mmax) mmax = g[i].M;
   }
   dim3 grid((unsigned)tln_cdiv(mmax, BM), (unsigned)tln_cdiv(g[0].N, BN), (unsigned)n);
@@ -484,7 +532,7 @@ int tln_gemm_v2_launch_multi(GemmArgs* g, int n, bool w_is_nk, hipStream_t s) {
 // h' = GRUCell(x, pad(h)) as one two-source product with the cell in its epilogue (see v2_body)
 bool tln_gemm_v2_gru_ok(int64_t V, int64_t Vh, int C) {
   static const bool off = getenv("TLN_GRU_FUSED_OFF") != nullptr;
-  return !off && !g_v2_off && V >= g_v2_min_m && V < (1ll << 31) && Vh >= 1 && Vh <= V && C % 64 == 0 && C <= 1024;
+  return !off && !(g_v2_off & 1) && V >= g_v2_min_m && V < (1ll << 31) && Vh >= 1 && Vh <= V && C % 64 == 0 && C <= 1024;
 }
 int tln_gemm_v2_launch_gru(const float* d_x, const float* d_h, int64_t Vh, int64_t V, int C, const float* d_w_ih,
                            const float* d_w_hh, const float* d_b_ih, const float* d_b_hh, float* d_out, hipStream_t s) {
@@ -512,7 +560,7 @@ int tln_gemm_v2_launch_gru(const float* d_x, const float* d_h, int64_t Vh, int64
   g.ld_out = C;
   g.splits = 1;
   constexpr int BM = 128, BN = 192;
-  const size_t lds = (size_t)V2_STAGES * (BM + BN) * 128 + (size_t)BM * TLN_TAPS * 4 + (size_t)2 * C * 4;
+  const size_t lds = (size_t)V2_STAGES * (BM + BN) * 128 + (size_t)BM * TLN_TAPS * 4 + (size_t)2 * C * 4 + (size_t)(BM + 32) * 4;
   TLN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gather_gemm_v2_gru), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds));
   dim3 grid((unsigned)tln_cdiv(V, BM), (unsigned)(3 * C / BN), 1);

@@ -80,6 +80,9 @@ struct tln_lattice {
   tln_lattice* parent = nullptr;
   int32_t* c2f = nullptr;
   int32_t* f2c = nullptr;
+  // row orders of the three tap tables (rows with equal sets of present taps next to each other: perm section below)
+  int32_t *perm_nbr = nullptr, *perm_c2f = nullptr, *perm_f2c = nullptr;
+  int32_t *phist_nbr = nullptr, *phist_c2f = nullptr, *phist_f2c = nullptr;
   int64_t embedded_fine = 0;
   // tln_lattice_prepare_levels_begin without its _finish yet: coarse counters are in flight (root level only)
   int levels_pending = 0;
@@ -335,6 +338,8 @@ extern "C" int tln_lattice_create(tln_lattice_t** out, int pos_dim, const double
   return TLN_OK;
 }
 
+static void perm_forget(const int32_t* table);   // (row orders of the tap tables: below, with the tables)
+
 extern "C" int tln_lattice_destroy(tln_lattice_t* l) {
   if (l && l->ctr_event) {
     (void)hipEventDestroy(l->ctr_event);
@@ -346,7 +351,11 @@ extern "C" int tln_lattice_destroy(tln_lattice_t* l) {
   }
   if (!l) return TLN_OK;
   if (l->coarse) tln_lattice_destroy(l->coarse);
-  void* ptrs[] = {l->slots, l->vkeys, l->d_ctr, l->nbr, l->c2f, l->f2c,
+  perm_forget(l->nbr);
+  perm_forget(l->c2f);
+  perm_forget(l->f2c);
+  void* ptrs[] = {l->slots, l->vkeys, l->d_ctr, l->nbr, l->c2f, l->f2c, l->perm_nbr, l->perm_c2f, l->perm_f2c, l->phist_nbr,
+                  l->phist_c2f, l->phist_f2c,
                   l->row_slot, l->block_cnt, l->sk_in, l->sk_out, l->sv_in, l->sv_out, l->sort_temp,
                   l->seg_start, l->pool_packed, l->mean, l->pieces, l->slot_cnt, l->vslot, l->vcnt, l->vstart,
                   l->row_rank, l->bin_rec, l->rec, l->bk_off, l->first_flag,
@@ -2218,6 +2227,182 @@ __global__ void __launch_bounds__(256) k_tables_multi(const TableJobs jobs) {
   table_entry(jb.qkeys, jb.nq, jb.t, jb.mode, jb.out, (int64_t)(blockIdx.x - jb.block_begin) * blockDim.x + threadIdx.x);
 }
 
+// ---------------------------------------------------------------------------------------
+// Row orders of the tap tables.  About 30 % of the (vertex, neighbour) pairs of a LiDAR lattice do not exist (a surface
+// in space: 2-7 of the 8 neighbours), and the gather-GEMM multiplies a zero row for each of them.  The large-M kernel
+// works on blocks of 128 rows x one tap at a time: if the rows of a block all lack a tap, the whole K chunk of that
+// tap can be skipped — which never happens in vertex order (first-touch order of shuffled points) and happens for 23 %
+// of the (block, tap) pairs of a level-0 lattice once the rows are ordered by their set of present taps (41 % for the
+// coarsen tables).  The output rows of a product are independent, so the kernel may walk them in any order: this is
+// that order, one stable 8-bit counting sort per table (key = presence bits of the eight neighbour taps), rebuilt with
+// the table.  Deterministic: a wave walks its 1024 rows in order, lanes with equal keys are ranked by ballots.
+//   k_perm_count    wave = 1024 rows: counts per key -> hist[chunk][256]
+//   k_perm_scatter  wave = 1024 rows: first position of (chunk, key) from the histograms, rows written in order
+// gemm.hip asks tln_table_perm(table, M) for every product with a tap table; tables of more than 128k rows have none.
+// ---------------------------------------------------------------------------------------
+#define TLN_PERM_CHUNK 1024
+#define TLN_PERM_MAX_ROWS (1 << 17)
+struct PermJob {
+  const int32_t* table;
+  int64_t rows;
+  int32_t* hist;
+  int32_t* perm;
+};
+struct PermJobs {
+  PermJob j[8];
+  int n;
+};
+// sort key of a row: the presence bits of its eight neighbour taps.  (Ranking the sets by their number of taps, most
+// first, so that the heavy blocks of a launch start first, measured 3 % SLOWER than this plain order, in which light and
+// heavy blocks alternate along the grid: 1098 against 1132 clouds/s.)
+__device__ __forceinline__ int perm_key(const int32_t* __restrict__ table, int64_t row) {
+  const int32_t* t = table + row * TLN_TAPS;
+  int key = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) key |= (t[k] >= 0 ? 1 : 0) << k;
+  return key;
+}
+__global__ void __launch_bounds__(64) k_perm_count(const PermJobs jobs) {
+  const PermJob& jb = jobs.j[blockIdx.y];
+  const int64_t r0 = (int64_t)blockIdx.x * TLN_PERM_CHUNK;
+  if (r0 >= jb.rows) return;
+  __shared__ int cnt[256];
+  const int lane = threadIdx.x;
+  for (int c = lane; c < 256; c += 64) cnt[c] = 0;
+  __syncthreads();
+  for (int step = 0; step < TLN_PERM_CHUNK / 64; ++step) {
+    const int64_t row = r0 + step * 64 + lane;
+    if (row < jb.rows) atomicAdd(&cnt[perm_key(jb.table, row)], 1);
+  }
+  __syncthreads();
+  for (int c = lane; c < 256; c += 64) jb.hist[(int64_t)blockIdx.x * 256 + c] = cnt[c];
+}
+__global__ void __launch_bounds__(64) k_perm_scatter(const PermJobs jobs) {
+  const PermJob& jb = jobs.j[blockIdx.y];
+  const int chunk = blockIdx.x;
+  const int64_t r0 = (int64_t)chunk * TLN_PERM_CHUNK;
+  if (r0 >= jb.rows) return;
+  __shared__ int off[256];
+  const int lane = threadIdx.x;
+  const int nchunks = (int)((jb.rows + TLN_PERM_CHUNK - 1) / TLN_PERM_CHUNK);
+  // first position of (this chunk, key): rows of smaller keys anywhere + rows of this key in earlier chunks
+  int tot[4] = {0, 0, 0, 0}, before[4] = {0, 0, 0, 0};
+  for (int j = 0; j < nchunks; ++j) {
+    const int4 h = *reinterpret_cast<const int4*>(jb.hist + (int64_t)j * 256 + 4 * lane);
+    tot[0] += h.x;
+    tot[1] += h.y;
+    tot[2] += h.z;
+    tot[3] += h.w;
+    if (j < chunk) {
+      before[0] += h.x;
+      before[1] += h.y;
+      before[2] += h.z;
+      before[3] += h.w;
+    }
+  }
+  const int mine = tot[0] + tot[1] + tot[2] + tot[3];
+  int incl = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int u = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += u;
+  }
+  int run = incl - mine;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    off[4 * lane + k] = run + before[k];
+    run += tot[k];
+  }
+  __syncthreads();
+  for (int step = 0; step < TLN_PERM_CHUNK / 64; ++step) {
+    const int64_t row = r0 + step * 64 + lane;
+    const bool valid = row < jb.rows;
+    const int key = valid ? perm_key(jb.table, row) : 0;
+    unsigned long long peers = __ballot(valid);
+#pragma unroll
+    for (int bit = 0; bit < 8; ++bit) {
+      const bool one = (key >> bit) & 1;
+      const unsigned long long m = __ballot(one);
+      peers &= one ? m : ~m;
+    }
+    // lanes of one key: the lowest one reads and advances the key's position, the others take theirs from it
+    const int leader = valid ? __builtin_ctzll(peers) : lane;
+    int base = 0;
+    if (valid && leader == lane) {
+      base = off[key];
+      off[key] = base + __popcll(peers);
+    }
+    base = __shfl(base, leader, 64);
+    if (valid) jb.perm[base + __popcll(peers & ((1ull << lane) - 1ull))] = (int32_t)row;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the next step reads the advanced positions
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
+// table -> its row order, for gemm.hip (several lattices on several host threads: a lock around a small map)
+#include <mutex>
+#include <unordered_map>
+struct PermInfo {
+  const int32_t* perm;
+  int64_t rows;
+};
+static std::mutex g_perm_mu;
+static std::unordered_map<const int32_t*, PermInfo> g_perm;
+static bool perm_enabled() {
+  static const bool off = getenv("TLN_PERM_OFF") != nullptr;
+  return !off;
+}
+const int32_t* tln_table_perm(const int32_t* table, int64_t rows) {
+  if (!table || !perm_enabled()) return nullptr;
+  std::lock_guard<std::mutex> lk(g_perm_mu);
+  auto it = g_perm.find(table);
+  return (it != g_perm.end() && it->second.rows == rows) ? it->second.perm : nullptr;
+}
+static void perm_forget(const int32_t* table) {
+  if (!table) return;
+  std::lock_guard<std::mutex> lk(g_perm_mu);
+  g_perm.erase(table);
+}
+// the row orders of up to 8 freshly built tables: two launches for all of them
+struct PermWant {
+  const int32_t* table;
+  int64_t rows;
+  int32_t** perm;     // the level's buffers (allocated here on first use)
+  int32_t** hist;
+  int64_t capacity;   // rows the table can hold
+};
+static int build_perms(const PermWant* w, int n, hipStream_t s) {
+  if (!perm_enabled()) return TLN_OK;
+  PermJobs jobs{};
+  int64_t maxchunks = 0;
+  for (int i = 0; i < n; ++i) {
+    if (w[i].rows <= 0 || w[i].rows > TLN_PERM_MAX_ROWS) {
+      perm_forget(w[i].table);
+      continue;
+    }
+    if (!*w[i].perm) {
+      const int64_t cap = w[i].capacity < TLN_PERM_MAX_ROWS ? w[i].capacity : TLN_PERM_MAX_ROWS;
+      TLN_HIP(hipMalloc(w[i].perm, (size_t)cap * sizeof(int32_t)));
+      TLN_HIP(hipMalloc(w[i].hist, (size_t)(cap / TLN_PERM_CHUNK + 2) * 256 * sizeof(int32_t)));
+    }
+    PermJob& jb = jobs.j[jobs.n++];
+    jb.table = w[i].table;
+    jb.rows = w[i].rows;
+    jb.hist = *w[i].hist;
+    jb.perm = *w[i].perm;
+    const int64_t ch = tln_cdiv(w[i].rows, TLN_PERM_CHUNK);
+    if (ch > maxchunks) maxchunks = ch;
+    std::lock_guard<std::mutex> lk(g_perm_mu);
+    g_perm[w[i].table] = PermInfo{*w[i].perm, w[i].rows};
+  }
+  if (jobs.n == 0) return TLN_OK;
+  hipLaunchKernelGGL(k_perm_count, dim3((unsigned)maxchunks, (unsigned)jobs.n), dim3(64), 0, s, jobs);
+  hipLaunchKernelGGL(k_perm_scatter, dim3((unsigned)maxchunks, (unsigned)jobs.n), dim3(64), 0, s, jobs);
+  TLN_LAUNCH_CHECK();
+  return TLN_OK;
+}
+
 static int ensure_table(int32_t** p, int64_t capacity) {
   if (*p) return TLN_OK;
   TLN_HIP(hipMalloc(p, capacity * TLN_TAPS * sizeof(int32_t)));
@@ -2234,6 +2419,9 @@ extern "C" int tln_neighbour_table(tln_lattice_t* l, const int32_t** d_table_out
                        l->vkeys, l->nr_vertices, table_ref(l), 0, l->nbr);
     TLN_LAUNCH_CHECK();
     l->nbr_gen = l->gen;
+    const PermWant w{l->nbr, l->nr_vertices, &l->perm_nbr, &l->phist_nbr, l->capacity};
+    rc = build_perms(&w, 1, (hipStream_t)stream_);
+    if (rc) return rc;
   }
   *d_table_out = l->nbr;
   return TLN_OK;
@@ -2332,6 +2520,9 @@ extern "C" int tln_coarse_to_fine_table(tln_lattice_t* c, const int32_t** d_tabl
     TLN_LAUNCH_CHECK();
     c->c2f_gen_c = c->gen;
     c->c2f_gen_f = f->gen;
+    const PermWant w{c->c2f, c->nr_vertices, &c->perm_c2f, &c->phist_c2f, c->capacity};
+    rc = build_perms(&w, 1, (hipStream_t)stream_);
+    if (rc) return rc;
   }
   *d_table_out = c->c2f;
   return TLN_OK;
@@ -2353,6 +2544,9 @@ extern "C" int tln_fine_to_coarse_table(tln_lattice_t* c, const int32_t** d_tabl
     TLN_LAUNCH_CHECK();
     c->f2c_gen_c = c->gen;
     c->f2c_gen_f = f->gen;
+    const PermWant w{c->f2c, f->nr_vertices, &c->perm_f2c, &c->phist_f2c, f->capacity};
+    rc = build_perms(&w, 1, (hipStream_t)stream_);
+    if (rc) return rc;
   }
   *d_table_out = c->f2c;
   return TLN_OK;
@@ -2424,6 +2618,7 @@ extern "C" int tln_lattice_prepare_levels_finish(tln_lattice_t* l0, void* stream
     }
   }
   TableJobs jobs{};
+  PermWant pw[8];
   int blocks = 0;
   auto add = [&](const int32_t* qkeys, int64_t nq, tln_lattice* target, int mode, int32_t* out) {
     TableJob& j = jobs.j[jobs.n++];
@@ -2440,6 +2635,7 @@ extern "C" int tln_lattice_prepare_levels_finish(tln_lattice_t* l0, void* stream
     int rc = ensure_table(&p->nbr, p->capacity);
     if (rc) return rc;
     if (p->nbr_gen != p->gen) {
+      pw[jobs.n] = PermWant{p->nbr, p->nr_vertices, &p->perm_nbr, &p->phist_nbr, p->capacity};
       add(p->vkeys, p->nr_vertices, p, 0, p->nbr);
       p->nbr_gen = p->gen;
     }
@@ -2450,11 +2646,13 @@ extern "C" int tln_lattice_prepare_levels_finish(tln_lattice_t* l0, void* stream
       rc = ensure_table(&p->f2c, f->capacity);
       if (rc) return rc;
       if (p->c2f_gen_c != p->gen || p->c2f_gen_f != f->gen) {
+        pw[jobs.n] = PermWant{p->c2f, p->nr_vertices, &p->perm_c2f, &p->phist_c2f, p->capacity};
         add(p->vkeys, p->nr_vertices, f, 1, p->c2f);
         p->c2f_gen_c = p->gen;
         p->c2f_gen_f = f->gen;
       }
       if (p->f2c_gen_c != p->gen || p->f2c_gen_f != f->gen) {
+        pw[jobs.n] = PermWant{p->f2c, f->nr_vertices, &p->perm_f2c, &p->phist_f2c, f->capacity};
         add(f->vkeys, f->nr_vertices, p, 2, p->f2c);
         p->f2c_gen_c = p->gen;
         p->f2c_gen_f = f->gen;
@@ -2465,6 +2663,8 @@ extern "C" int tln_lattice_prepare_levels_finish(tln_lattice_t* l0, void* stream
   if (jobs.n > 0) {
     hipLaunchKernelGGL(k_tables_multi, dim3((unsigned)blocks), dim3(256), 0, s, jobs);
     TLN_LAUNCH_CHECK();
+    int rc = build_perms(pw, jobs.n, s);
+    if (rc) return rc;
   }
   return TLN_OK;
 }

@@ -82,13 +82,15 @@ def test_v2_matches_oracle_and_the_other_kernels(gpu, lattice, v2_forced, cin, c
     if relu:
         want = torch.relu(want)
     np.testing.assert_allclose(out.cpu().numpy(), want.numpy(), rtol=1e-4, atol=5e-5)
-    # the fused GroupNorm partial sums describe the tensor that was written
+    # the fused GroupNorm partial sums describe the tensor that was written: one (sum, sum of squares) per group of 32
+    # rows and column — the groups follow the product's row order (rows with the same present taps together when the
+    # tap table has one, lattice.hip), so what is checked is their number and that together they cover every row once
     st = out._tln_stats.cpu()
     got = out.cpu().double()
     nb = (V + 31) // 32
-    blk = torch.cat([got, torch.zeros(nb * 32 - V, cout, dtype=torch.float64)]).reshape(nb, 32, cout)
-    np.testing.assert_allclose(st[:, :, 0].numpy(), blk.sum(1).numpy(), rtol=1e-12, atol=1e-9)
-    np.testing.assert_allclose(st[:, :, 1].numpy(), (blk * blk).sum(1).numpy(), rtol=1e-12, atol=1e-9)
+    assert tuple(st.shape) == (nb, cout, 2)
+    np.testing.assert_allclose(st[:, :, 0].sum(0).numpy(), got.sum(0).numpy(), rtol=1e-10, atol=1e-7)
+    np.testing.assert_allclose(st[:, :, 1].sum(0).numpy(), (got * got).sum(0).numpy(), rtol=1e-10, atol=1e-7)
     # same product from gemm.hip's kernels (v2 off): equal up to the order of the K summation
     v2_forced.tln_gemm_v2_config(1, 0)
     try:
@@ -186,3 +188,40 @@ def test_v2_takes_products_whose_rows_only_together_are_large(gpu, lattice, cin,
             np.testing.assert_allclose(outs[i].cpu().numpy(), want.numpy(), rtol=1e-4, atol=5e-5)
     finally:
         lib.tln_gemm_v2_config(0, 12288)
+
+
+@pytest.mark.parametrize("cin,cout,pro", [(64, 64, True), (192, 192, False), (128, 64, True)])
+def test_row_order_by_present_taps_changes_no_bit(gpu, lattice, v2_forced, cin, cout, pro):
+    """Every 9-tap product over a tap table walks its rows in the table's row order (rows with the same set of present
+    neighbour taps together, lattice.hip) and skips the K chunks of the taps no row of a 128-row block has.  A skipped
+    chunk would have added exact zeros, and a row's sum does not depend on which rows share its block: the result is
+    bitwise the one without the row order (tln_gemm_v2_config bit 2), and the GroupNorm partial sums still add up to the
+    tensor.  On this lattice a third of the neighbour taps is missing: the fixture also checks that there is something
+    to skip."""
+    from temporal_latticenet_amd import ops
+    lat, table = lattice
+    V = lat.nr_lattice_vertices()
+    missing = float((table[:, :8] < 0).mean())
+    assert 0.15 < missing < 0.6, missing
+    g = torch.Generator().manual_seed(cin + cout)
+    lv = torch.randn(V, cin, generator=g).to(gpu)
+    W = (torch.randn(9 * cin, cout, generator=g) / np.sqrt(9 * cin)).to(gpu)
+    gamma, beta = (torch.rand(cin, generator=g) + 0.5).to(gpu), torch.randn(cin, generator=g).to(gpu)
+
+    def run():
+        kw = {}
+        if pro:
+            sc, sh = ops.groupnorm_stats(lv, 32, gamma, beta)
+            kw = dict(scale=sc, shift=sh, relu=True)
+        s0 = ops.gemm_src(lv, lat.neighbour_table_ptr(), 9, **kw)
+        return ops.gather_gemm(V, W, s0, stats=True)
+
+    with_order = run()
+    v2_forced.tln_gemm_v2_config(4, 0)          # large-M kernel on, row order off
+    try:
+        plain = run()
+    finally:
+        v2_forced.tln_gemm_v2_config(0, 0)
+    assert torch.equal(with_order, plain)
+    a, b = with_order._tln_stats.double().sum(0), plain._tln_stats.double().sum(0)
+    np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-10, atol=1e-7)
