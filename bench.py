@@ -325,6 +325,9 @@ def main():
                         "unit": "TFLOP/s", "frac": round(head / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                         "products_per_sequence": tot_n // reps, "avg_launch_us": round(head_us, 2),
                         "flops_per_launch": tot_fl / tot_n, "algorithmic_bytes_per_launch": tot_by / tot_n,
+                        "flops_note": "2*M*K*N with the full K = taps*C_in of the reference's im2row product, the zero "
+                                      "rows of missing lattice neighbours included; the large-M kernel skips the K "
+                                      "chunks of taps no row of a 128-row block has (13-41 % of them, DESIGN.md 5d)",
                         "mode": mode, "one_sequence_alone": solo,
                         "whole_step": {"achieved": round(step_tf, 3), "frac": round(step_tf / FP32_MFMA_PEAK_TFLOPS, 4),
                                        "note": "the same flops per sequence x sequences per step / measured step time of "

@@ -2235,9 +2235,9 @@ __global__ void __launch_bounds__(256) k_tables_multi(const TableJobs jobs) {
 // of the (block, tap) pairs of a level-0 lattice once the rows are ordered by their set of present taps (41 % for the
 // coarsen tables).  The output rows of a product are independent, so the kernel may walk them in any order: this is
 // that order, one stable 8-bit counting sort per table (key = presence bits of the eight neighbour taps), rebuilt with
-// the table.  Deterministic: a wave walks its 1024 rows in order, lanes with equal keys are ranked by ballots.
-//   k_perm_count    wave = 1024 rows: counts per key -> hist[chunk][256]
-//   k_perm_scatter  wave = 1024 rows: first position of (chunk, key) from the histograms, rows written in order
+// the table.  Deterministic: a wave walks its 256 rows in order, lanes with equal keys are ranked by ballots.
+//   k_perm_count    block = 1024 rows: counts per key -> hist[chunk][256]
+//   k_perm_scatter  block = 1024 rows: first position of (chunk, key) from the histograms, rows written in order
 // gemm.hip asks tln_table_perm(table, M) for every product with a tap table; tables of more than 128k rows have none.
 // ---------------------------------------------------------------------------------------
 #define TLN_PERM_CHUNK 1024
@@ -2262,62 +2262,72 @@ __device__ __forceinline__ int perm_key(const int32_t* __restrict__ table, int64
   for (int k = 0; k < 8; ++k) key |= (t[k] >= 0 ? 1 : 0) << k;
   return key;
 }
-__global__ void __launch_bounds__(64) k_perm_count(const PermJobs jobs) {
+__global__ void __launch_bounds__(256) k_perm_count(const PermJobs jobs) {
   const PermJob& jb = jobs.j[blockIdx.y];
   const int64_t r0 = (int64_t)blockIdx.x * TLN_PERM_CHUNK;
   if (r0 >= jb.rows) return;
   __shared__ int cnt[256];
-  const int lane = threadIdx.x;
-  for (int c = lane; c < 256; c += 64) cnt[c] = 0;
+  const int tid = threadIdx.x;
+  cnt[tid] = 0;
   __syncthreads();
-  for (int step = 0; step < TLN_PERM_CHUNK / 64; ++step) {
-    const int64_t row = r0 + step * 64 + lane;
+  for (int k = 0; k < TLN_PERM_CHUNK / 256; ++k) {
+    const int64_t row = r0 + k * 256 + tid;
     if (row < jb.rows) atomicAdd(&cnt[perm_key(jb.table, row)], 1);
   }
   __syncthreads();
-  for (int c = lane; c < 256; c += 64) jb.hist[(int64_t)blockIdx.x * 256 + c] = cnt[c];
+  jb.hist[(int64_t)blockIdx.x * 256 + tid] = cnt[tid];
 }
-__global__ void __launch_bounds__(64) k_perm_scatter(const PermJobs jobs) {
+// block = 1024 rows, four waves of 256 consecutive rows each (four steps of 64): thread c first finds where key c of
+// this chunk starts (rows of smaller keys anywhere + rows of key c in earlier chunks), the waves' shares of the chunk
+// follow from their own counts, then every wave places its rows in order
+__global__ void __launch_bounds__(256) k_perm_scatter(const PermJobs jobs) {
   const PermJob& jb = jobs.j[blockIdx.y];
   const int chunk = blockIdx.x;
   const int64_t r0 = (int64_t)chunk * TLN_PERM_CHUNK;
   if (r0 >= jb.rows) return;
-  __shared__ int off[256];
-  const int lane = threadIdx.x;
-  const int nchunks = (int)((jb.rows + TLN_PERM_CHUNK - 1) / TLN_PERM_CHUNK);
-  // first position of (this chunk, key): rows of smaller keys anywhere + rows of this key in earlier chunks
-  int tot[4] = {0, 0, 0, 0}, before[4] = {0, 0, 0, 0};
-  for (int j = 0; j < nchunks; ++j) {
-    const int4 h = *reinterpret_cast<const int4*>(jb.hist + (int64_t)j * 256 + 4 * lane);
-    tot[0] += h.x;
-    tot[1] += h.y;
-    tot[2] += h.z;
-    tot[3] += h.w;
-    if (j < chunk) {
-      before[0] += h.x;
-      before[1] += h.y;
-      before[2] += h.z;
-      before[3] += h.w;
-    }
+  __shared__ int cntw[4][256];   // rows of key c in wave w of this chunk, then the wave's next position for key c
+  __shared__ int wsum[4];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  for (int k = 0; k < 4; ++k) cntw[k][tid] = 0;
+  __syncthreads();
+  int keys[4];
+#pragma unroll
+  for (int step = 0; step < 4; ++step) {
+    const int64_t row = r0 + w * 256 + step * 64 + lane;
+    keys[step] = row < jb.rows ? perm_key(jb.table, row) : -1;
+    if (keys[step] >= 0) atomicAdd(&cntw[w][keys[step]], 1);
   }
-  const int mine = tot[0] + tot[1] + tot[2] + tot[3];
-  int incl = mine;
+  // key c = tid: rows of this key in all chunks / in the chunks before this one
+  const int nchunks = (int)((jb.rows + TLN_PERM_CHUNK - 1) / TLN_PERM_CHUNK);
+  int tot = 0, before = 0;
+  for (int j = 0; j < nchunks; ++j) {
+    const int h = jb.hist[(int64_t)j * 256 + tid];
+    tot += h;
+    if (j < chunk) before += h;
+  }
+  int incl = tot;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
     const int u = __shfl_up(incl, o, 64);
     if (lane >= o) incl += u;
   }
-  int run = incl - mine;
+  if (lane == 63) wsum[w] = incl;
+  __syncthreads();   // (also: every wave's counts are complete)
+  int pre = 0;
+  for (int k = 0; k < w; ++k) pre += wsum[k];
+  int pos = pre + incl - tot + before;   // first position of (this chunk, key tid)
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    off[4 * lane + k] = run + before[k];
-    run += tot[k];
+    const int c = cntw[k][tid];
+    cntw[k][tid] = pos;                  // wave k's first position for key tid
+    pos += c;
   }
   __syncthreads();
-  for (int step = 0; step < TLN_PERM_CHUNK / 64; ++step) {
-    const int64_t row = r0 + step * 64 + lane;
-    const bool valid = row < jb.rows;
-    const int key = valid ? perm_key(jb.table, row) : 0;
+#pragma unroll
+  for (int step = 0; step < 4; ++step) {
+    const int64_t row = r0 + w * 256 + step * 64 + lane;
+    const int key = keys[step];
+    const bool valid = key >= 0;
     unsigned long long peers = __ballot(valid);
 #pragma unroll
     for (int bit = 0; bit < 8; ++bit) {
@@ -2325,12 +2335,12 @@ __global__ void __launch_bounds__(64) k_perm_scatter(const PermJobs jobs) {
       const unsigned long long m = __ballot(one);
       peers &= one ? m : ~m;
     }
-    // lanes of one key: the lowest one reads and advances the key's position, the others take theirs from it
+    // lanes of one key: the lowest one reads and advances the wave's position for the key, the others take theirs from it
     const int leader = valid ? __builtin_ctzll(peers) : lane;
     int base = 0;
     if (valid && leader == lane) {
-      base = off[key];
-      off[key] = base + __popcll(peers);
+      base = cntw[w][key];
+      cntw[w][key] = base + __popcll(peers);
     }
     base = __shfl(base, leader, 64);
     if (valid) jb.perm[base + __popcll(peers & ((1ull << lane) - 1ull))] = (int32_t)row;
@@ -2397,8 +2407,8 @@ static int build_perms(const PermWant* w, int n, hipStream_t s) {
     g_perm[w[i].table] = PermInfo{*w[i].perm, w[i].rows};
   }
   if (jobs.n == 0) return TLN_OK;
-  hipLaunchKernelGGL(k_perm_count, dim3((unsigned)maxchunks, (unsigned)jobs.n), dim3(64), 0, s, jobs);
-  hipLaunchKernelGGL(k_perm_scatter, dim3((unsigned)maxchunks, (unsigned)jobs.n), dim3(64), 0, s, jobs);
+  hipLaunchKernelGGL(k_perm_count, dim3((unsigned)maxchunks, (unsigned)jobs.n), dim3(256), 0, s, jobs);
+  hipLaunchKernelGGL(k_perm_scatter, dim3((unsigned)maxchunks, (unsigned)jobs.n), dim3(256), 0, s, jobs);
   TLN_LAUNCH_CHECK();
   return TLN_OK;
 }
