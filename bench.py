@@ -251,21 +251,31 @@ def main():
             if prog is not None:
                 prog.capture_gemms(True)
                 prog.stage_timing(True)
-            for t, (pos, val) in enumerate(frames):
-                if prog is None:
-                    break
-                model(lat, pos, val, t != len(frames) - 1, False)
-                if not getattr(model, "_program_active", False):
-                    break
-                v0 = lat.nr_lattice_vertices()
-                for k, (ms, by) in enumerate(zip(prog.stage_times_ms(),
-                                                 (128.0 * n_pts, 96.0 * n_pts + 512.0 * v0, 768.0 * v0 + 148.0 * n_pts))):
-                    if ms is not None:
-                        st_ms[k] += ms
-                        st_by[k] += by
-                        st_n[k] += 1
-                ms, n, fl, by = prog.replay_gemms(reps)
-                tot_ms, tot_n, tot_fl, tot_by = tot_ms + ms, tot_n + n, tot_fl + fl, tot_by + by
+            # three passes over the sequence; the stage times of the pass with the smallest sum are kept per stage (the
+            # stages are 50-100 us of latency-bound kernels: a pass now and then runs 20 % slower)
+            for rep in range(3):
+                p_ms, p_by, p_n = [0.0, 0.0, 0.0], [0.0, 0.0, 0.0], [0, 0, 0]
+                for t, (pos, val) in enumerate(frames):
+                    if prog is None:
+                        break
+                    model(lat, pos, val, t != len(frames) - 1, False)
+                    if not getattr(model, "_program_active", False):
+                        break
+                    v0 = lat.nr_lattice_vertices()
+                    for k, (ms, by) in enumerate(zip(prog.stage_times_ms(),
+                                                     (128.0 * n_pts, 96.0 * n_pts + 512.0 * v0, 768.0 * v0 + 148.0 * n_pts))):
+                        if ms is not None:
+                            p_ms[k] += ms
+                            p_by[k] += by
+                            p_n[k] += 1
+                    if rep == 0:
+                        ms, n, fl, by = prog.replay_gemms(reps)
+                        tot_ms, tot_n, tot_fl, tot_by = tot_ms + ms, tot_n + n, tot_fl + fl, tot_by + by
+                model.reset_sequence()
+                lat = make_lattice(contents) if rep < 2 else lat
+                for k in range(3):
+                    if p_n[k] and (st_n[k] == 0 or p_ms[k] < st_ms[k]):
+                        st_ms[k], st_by[k], st_n[k] = p_ms[k], p_by[k], p_n[k]
             model.reset_sequence()
             if getattr(model, "_program", None) is not None:
                 model._program.capture_gemms(False)
