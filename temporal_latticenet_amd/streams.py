@@ -68,6 +68,7 @@ class SequenceStreams:
                 m.reset_sequence()
             self.models.append(share_parameters(m, base_model))
         self.streams = [torch.cuda.Stream() for _ in range(n_streams)]
+        self._copy_streams = [torch.cuda.Stream() for _ in range(n_streams)]   # host -> device copies of the next frame
         self.lattices = [make_lattice() for _ in range(n_models)]
         # persistent workers (a fresh host thread pays HIP's per-thread set-up on its first call)
         self._jobs = [queue.Queue() for _ in range(n_streams)]
@@ -94,6 +95,27 @@ class SequenceStreams:
                 return
             self._done.put((i,) + self._work(i, *job))
 
+    def _fetch(self, i, grp, t):
+        """frame t of the sequences of a lock-step group: device tensors as they are; host tensors (pinned) start their
+        way to the device on stream i's COPY stream.  Returns (positions, values, event or None)."""
+        if all(sq[t][0].is_cuda for sq in grp):
+            return [sq[t][0] for sq in grp], [sq[t][1] for sq in grp], None
+        cs = self._copy_streams[i]
+        with torch.cuda.stream(cs):
+            ps = [sq[t][0] if sq[t][0].is_cuda else sq[t][0].to("cuda", non_blocking=True) for sq in grp]
+            vs = [sq[t][1] if sq[t][1].is_cuda else sq[t][1].to("cuda", non_blocking=True) for sq in grp]
+            ev = torch.cuda.Event()
+            ev.record(cs)
+        return ps, vs, ev
+
+    def _arrived(self, i, fetched):
+        ps, vs, ev = fetched
+        if ev is not None:
+            self.streams[i].wait_event(ev)
+            for x in ps + vs:
+                x.record_stream(self.streams[i])    # allocated on the copy stream, used (and released) on this one
+        return ps, vs
+
     def _work(self, i, sequences, keep_outputs):
         try:
             outs = []
@@ -105,9 +127,12 @@ class SequenceStreams:
                     k = 0
                     while k + g <= len(sequences) and all(len(sequences[k + j]) == len(sequences[k]) for j in range(g)):
                         grp = sequences[k:k + g]
+                        nxt = self._fetch(i, grp, 0)
                         for t in range(len(grp[0])):
-                            ps = [sq[t][0] if sq[t][0].is_cuda else sq[t][0].to("cuda", non_blocking=True) for sq in grp]
-                            vs = [sq[t][1] if sq[t][1].is_cuda else sq[t][1].to("cuda", non_blocking=True) for sq in grp]
+                            ps, vs = self._arrived(i, nxt)
+                            # frames waiting in (pinned) host memory: the next frame's copies run on the stream pool's copy
+                            # stream while this frame computes
+                            nxt = self._fetch(i, grp, t + 1) if t + 1 < len(grp[0]) else None
                             res = forward_group(models, lats, ps, vs, t != len(grp[0]) - 1)
                             lats = [r[2] for r in res]
                         for mod in models:
@@ -119,9 +144,10 @@ class SequenceStreams:
                 else:
                     rest, model, lat = sequences, self.models[i], self.lattices[i]
                 for seq in rest:
-                    for t, (p, v) in enumerate(seq):
-                        if not p.is_cuda:      # frames waiting in (pinned) host memory: copied on this stream
-                            p, v = p.to("cuda", non_blocking=True), v.to("cuda", non_blocking=True)
+                    nxt = self._fetch(i, [seq], 0)
+                    for t in range(len(seq)):
+                        (p,), (v,) = self._arrived(i, nxt)
+                        nxt = self._fetch(i, [seq], t + 1) if t + 1 < len(seq) else None
                         out, raw, lat = model(lat, p, v, t != len(seq) - 1, False)
                     model.reset_sequence()
                     if keep_outputs:
