@@ -37,6 +37,25 @@ void tln_set_error(const char* fmt, ...);
 
 static inline int64_t tln_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize for a kernel, set once per host thread, device and kernel (a driver call
+// per launch otherwise: a frame has a hundred launches that need it).  `slot` is a static thread_local of the caller.
+struct TlnLdsAttr {
+  int device = -1;
+  int bytes = 0;
+};
+static inline hipError_t tln_set_max_lds(TlnLdsAttr& slot, const void* kern, int bytes) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (slot.device == dev && slot.bytes >= bytes) return hipSuccess;
+  e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) {
+    slot.device = dev;
+    slot.bytes = bytes;
+  }
+  return e;
+}
+
 // ---- device helpers -------------------------------------------------------------------
 __device__ __forceinline__ int tln_lane() { return threadIdx.x & 63; }
 

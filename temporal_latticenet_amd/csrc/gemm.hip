@@ -926,8 +926,10 @@ static int launch_gemm(GemmArgs& g, int splits, hipStream_t s) {
   const int ntab = (g.nsrc > 1 && g.s[1].table != nullptr) ? 2 : 1;
   const size_t lds = (size_t)(REGION + ntab * BM * TLN_TAPS + 4 + gn_floats) * sizeof(float);
   auto kern = k_gather_gemm<WM, TM, TN, BK, G, W_NK, VEC>;
-  if (lds > 48 * 1024)   // the attribute is per device: set whenever it is needed (a host-side table write)
-    TLN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if (lds > 48 * 1024) {
+    static thread_local TlnLdsAttr attr;   // (one per template instantiation)
+    TLN_HIP(tln_set_max_lds(attr, reinterpret_cast<const void*>(kern), (int)lds));
+  }
   dim3 grid((unsigned)tln_cdiv(g.M, BM), (unsigned)tln_cdiv(g.N, BN), (unsigned)splits);
   g.splits = splits;
   if (splits > 1) {
@@ -981,9 +983,10 @@ static int launch_direct(GemmArgs& g, int nchunks, int groups, hipStream_t s) {
   const int T = 64 * G;
   const size_t lds = direct_lds_bytes(g, G);
   TLN_REQUIRE(lds <= 96 * 1024, "direct gemm: LDS %zu B", lds);
-  if (lds > 48 * 1024)
-    TLN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gather_gemm_direct<W_NK>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+  if (lds > 48 * 1024) {
+    static thread_local TlnLdsAttr attr;
+    TLN_HIP(tln_set_max_lds(attr, reinterpret_cast<const void*>(k_gather_gemm_direct<W_NK>), 96 * 1024));
+  }
   dim3 grid((unsigned)tln_cdiv(g.M, 32), (unsigned)tln_cdiv(g.N, 32), 1);
   g.splits = 1;
   hipLaunchKernelGGL(k_gather_gemm_direct<W_NK>, grid, dim3(T), lds, s, g);
@@ -1211,9 +1214,10 @@ template <bool W_NK, int NP>
 static int launch_multi(const Prep* q, int n, int G, size_t lds, int64_t mt, hipStream_t s) {
   GemmArgsN<NP> gg;
   for (int i = 0; i < NP; ++i) gg.a[i] = q[i < n ? i : 0].g;
-  if (lds > 48 * 1024)
-    TLN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gather_gemm_direct_multi<W_NK, NP>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+  if (lds > 48 * 1024) {
+    static thread_local TlnLdsAttr attr;
+    TLN_HIP(tln_set_max_lds(attr, reinterpret_cast<const void*>(k_gather_gemm_direct_multi<W_NK, NP>), 96 * 1024));
+  }
   dim3 grid((unsigned)mt, (unsigned)tln_cdiv(q[0].g.N, 32), (unsigned)n);
   hipLaunchKernelGGL((k_gather_gemm_direct_multi<W_NK, NP>), grid, dim3(64 * G), lds, s, gg);
   return TLN_OK;

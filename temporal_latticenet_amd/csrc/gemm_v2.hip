@@ -432,8 +432,8 @@ static int launch_v2(GemmArgs& g, hipStream_t s) {
   const size_t lds = (size_t)STAGES * (BM + BN) * 128 + (size_t)BM * TLN_TAPS * 4 + (size_t)2 * g.s[0].cin * 4 + (size_t)(BM + 32) * 4;
   TLN_REQUIRE(lds <= 160 * 1024, "gemm v2: LDS %zu B", lds);
   auto kern = k_gather_gemm_v2<WM, WN, TM, TN, W_NK, PRO, STAGES>;
-  // set every time: the attribute is per device and this library serves several (one process per GPU is the normal case)
-  TLN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  static thread_local TlnLdsAttr attr;   // (one per template instantiation)
+  TLN_HIP(tln_set_max_lds(attr, reinterpret_cast<const void*>(kern), (int)lds));
   dim3 grid((unsigned)tln_cdiv(g.M, BM), (unsigned)tln_cdiv(g.N, BN), 1);
   g.splits = 1;
   g.s[0].perm = v2_perm_of(g);
@@ -498,7 +498,8 @@ static int launch_v2_multi(GemmArgs* g, int n, hipStream_t s) {
   const size_t lds = (size_t)STAGES * (BM + BN) * 128 + (size_t)BM * TLN_TAPS * 4 + (size_t)2 * g[0].s[0].cin * 4 + (size_t)(BM + 32) * 4;
   TLN_REQUIRE(lds <= 160 * 1024, "gemm v2: LDS %zu B", lds);
   auto kern = k_gather_gemm_v2_multi<WM, WN, TM, TN, W_NK, PRO, STAGES>;
-  TLN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  static thread_local TlnLdsAttr attr;   // (one per template instantiation)
+  TLN_HIP(tln_set_max_lds(attr, reinterpret_cast<const void*>(kern), (int)lds));
   GemmArgsN<TLN_GEMM_MULTI_MAX> gg;
   int64_t mmax = 0;
   for (int i = 0; i < TLN_GEMM_MULTI_MAX; ++i) {
@@ -563,8 +564,8 @@ int tln_gemm_v2_launch_gru(const float* d_x, const float* d_h, int64_t Vh, int64
   g.splits = 1;
   constexpr int BM = 128, BN = 192;
   const size_t lds = (size_t)V2_STAGES * (BM + BN) * 128 + (size_t)BM * TLN_TAPS * 4 + (size_t)2 * C * 4 + (size_t)(BM + 32) * 4;
-  TLN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gather_gemm_v2_gru), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds));
+  static thread_local TlnLdsAttr attr;
+  TLN_HIP(tln_set_max_lds(attr, reinterpret_cast<const void*>(k_gather_gemm_v2_gru), (int)lds));
   dim3 grid((unsigned)tln_cdiv(V, BM), (unsigned)(3 * C / BN), 1);
   hipLaunchKernelGGL(k_gather_gemm_v2_gru, grid, dim3(512), lds, s, g);
   return TLN_OK;

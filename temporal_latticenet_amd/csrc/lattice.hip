@@ -2042,14 +2042,8 @@ extern "C" int tln_distribute_begin(tln_lattice_t* l, const float* d_positions, 
     ++l->bins_stamp;
     l->bins_stamped = true;
     const size_t place_lds = (size_t)3 * TLN_BK_HT * sizeof(unsigned long long);
-    static thread_local int attr_device = -1;   // (the attribute is per device; set once per thread and device)
-    int dev = 0;
-    TLN_HIP(hipGetDevice(&dev));
-    if (attr_device != dev) {
-      TLN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bk_place), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)place_lds));
-      attr_device = dev;
-    }
+    static thread_local TlnLdsAttr place_attr;
+    TLN_HIP(tln_set_max_lds(place_attr, reinterpret_cast<const void*>(k_bk_place), (int)place_lds));
     hipLaunchKernelGGL(k_bk_place, dim3((unsigned)B), dim3(TLN_BK_THREADS), place_lds, s, l->rec, l->bk_off, nblk, B, rpb, t,
                        l->bucket_rows, rows, l->vstart, l->vcnt, l->vstamp, l->bins_stamp, l->mean, d_indices, l->bin_rec,
                        l->first_flag, l->bits_pre, (int)l->nr_vertices, (int)l->capacity,

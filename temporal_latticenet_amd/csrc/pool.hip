@@ -580,7 +580,8 @@ static int launch_pool_bins_mfma(const TlnBins& bn, int64_t rows, const float* c
   int64_t blocks = tln_cdiv(chunks, 4);
   if (blocks > 512) blocks = 512;   // two workgroups per CU: a wave takes several chunks on one set of weight registers
   auto kern = k_pool_bins_mfma<CIN>;
-  TLN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  static thread_local TlnLdsAttr attr;   // (one per template instantiation)
+  TLN_HIP(tln_set_max_lds(attr, reinterpret_cast<const void*>(kern), (int)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, s, bn, rows, min_points, w[0], b[0], w[1], b[1], w[2], b[2],
                      packed, d_out, d_argrow);
   TLN_LAUNCH_CHECK();
@@ -639,7 +640,8 @@ static int launch_pool_bins(const TlnBins& bn, int64_t rows, const float* const*
   }
   const int64_t chunks = tln_cdiv(rows, 64);
   auto kern = k_pool_bins<CIN, H1, H2, COUT>;
-  TLN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  static thread_local TlnLdsAttr attr;   // (one per template instantiation)
+  TLN_HIP(tln_set_max_lds(attr, reinterpret_cast<const void*>(kern), (int)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)tln_cdiv(chunks, 4)), dim3(256), lds, s, bn, rows, min_points, mp.w[0], mp.b[0],
                      mp.w[1], mp.b[1], mp.w[2], mp.b[2], packed, d_out, d_argrow);
   TLN_LAUNCH_CHECK();
@@ -659,7 +661,8 @@ static int launch_pool(tln_lattice* l, const float* d_dist, int64_t rows, int co
   }
   const int64_t chunks = tln_cdiv(rows, 64);
   auto kern = k_pool_chunks<CIN, H1, H2, COUT>;
-  TLN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  static thread_local TlnLdsAttr attr;   // (one per template instantiation)
+  TLN_HIP(tln_set_max_lds(attr, reinterpret_cast<const void*>(kern), (int)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)tln_cdiv(chunks, 4)), dim3(256), lds, s, d_dist, cols, tln_lat_order(l),
                      tln_lat_sorted_vertex(l), rows, nv, mp.w[0], mp.b[0], mp.w[1], mp.b[1], mp.w[2], mp.b[2], packed);
   TLN_LAUNCH_CHECK();
