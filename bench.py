@@ -58,10 +58,11 @@ def parse():
     ap.add_argument("--streams", type=int, default=4,
                     help="independent sequences in flight per GPU (one HIP stream + host thread + model replica each); "
                          "one step = one sequence on every stream")
-    ap.add_argument("--pairs", type=int, default=3,
-                    help="sequences a stream steps in lock-step (3 = default, up to 8; 0: one sequence per stream and "
+    ap.add_argument("--pairs", type=int, default=8,
+                    help="sequences a stream steps in lock-step (8 = default and maximum; 0: one sequence per stream and "
                          "step): their gather-GEMM products share launches, so the coarse levels (9k / 2.4k vertices per "
-                         "sequence) reach the 128-row-tile kernel's range together: +9 %% at 4 streams x 3")
+                         "sequence) reach the 128-row-tile kernel's range together and every launch fills the chip: "
+                         "913 clouds/s at 4 streams x 1, 1160 at 4 x 3, 1220 at 4 x 6 and 4 x 8")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) on the GPU node; gloo for rehearsals")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: all ranks use cuda:0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
