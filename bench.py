@@ -273,7 +273,6 @@ def main():
                         ms, n, fl, by = prog.replay_gemms(reps)
                         tot_ms, tot_n, tot_fl, tot_by = tot_ms + ms, tot_n + n, tot_fl + fl, tot_by + by
                 model.reset_sequence()
-                lat = make_lattice(contents) if rep < 2 else lat
                 for k in range(3):
                     if p_n[k] and (st_n[k] == 0 or p_ms[k] < st_ms[k]):
                         st_ms[k], st_by[k], st_n[k] = p_ms[k], p_by[k], p_n[k]
