@@ -56,6 +56,7 @@ struct __attribute__((aligned(16))) TlnSlot {
 #define TLN_BK_THREADS 512        // workgroup of a bucket: one run (= one split block's records of the bucket) per thread
 #define TLN_BK_MINB 16
 #define TLN_BK_MAXB 8192
+#define TLN_BK_MAX_PPB 4096   // points of a split block at most
 #define TLN_BK_SPLIT_BLOCKS TLN_BK_THREADS   // at most this many split blocks (columns of the bucket-offset table)
 struct __attribute__((aligned(16))) TlnRec {
   float4 a;   // x, y, z, value
@@ -213,7 +214,7 @@ static int ensure_rows(tln_lattice* l, int64_t rows) {
     TLN_HIP(hipMalloc(&l->bin_rec, cap * sizeof(TlnBinRec)));
     // partitioned K1: the split blocks' record regions (each rounded up to whole blocks of points), the bucket offsets
     // of every split block, the first-touch flags (zero between frames) and the bucket directories
-    l->rec_cap = cap + cap / 128 + 2048;
+    l->rec_cap = cap + cap / 128 + 4 * TLN_BK_MAX_PPB;
     l->bk_maxb = (int)(cap / 128 < TLN_BK_MINB ? TLN_BK_MINB : (cap / 128 > TLN_BK_MAXB ? TLN_BK_MAXB : cap / 128));
     TLN_HIP(hipMalloc(&l->rec, (size_t)l->rec_cap * sizeof(TlnRec)));
     TLN_HIP(hipMalloc(&l->bk_off, (size_t)TLN_BK_SPLIT_BLOCKS * (l->bk_maxb + 1) * sizeof(uint32_t)));
@@ -1534,7 +1535,7 @@ __device__ __forceinline__ uint32_t bk_block_scan(uint32_t v, uint32_t* wtmp /* 
   return pre + incl - v;
 }
 
-__global__ void __launch_bounds__(256) k_bk_split(const float* __restrict__ pos, const float* __restrict__ val, int64_t n,
+__global__ void __launch_bounds__(1024) k_bk_split(const float* __restrict__ pos, const float* __restrict__ val, int64_t n,
                                                   int val_dim, float s0, float s1, float s2, int ppb, int B,
                                                   TlnRec* __restrict__ rec, uint32_t* __restrict__ off,
                                                   float* __restrict__ weights, float* __restrict__ dist,
@@ -1542,16 +1543,16 @@ __global__ void __launch_bounds__(256) k_bk_split(const float* __restrict__ pos,
                                                   uint32_t* __restrict__ first_bits, int32_t* __restrict__ ctr) {
   extern __shared__ uint32_t bk_hist[];   // [B] bucket counts of this block, then the write cursors
   __shared__ uint32_t wtmp[16];
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, T = blockDim.x;   // T: 256, 512 or 1024 (a power of two, as B)
   const int nblk = gridDim.x;
   // what k_bk_insert accumulates into: the bit mask of the first-touch rows, their number
-  for (int i = blockIdx.x * 256 + tid; i < nr_words; i += nblk * 256) first_bits[i] = 0u;
+  for (int i = blockIdx.x * T + tid; i < nr_words; i += nblk * T) first_bits[i] = 0u;
   if (blockIdx.x == 0 && tid == 0) ctr[CTR_OVERFLOW] = 0;   // accumulated by k_bk_place
-  for (int i = tid; i < B; i += 256) bk_hist[i] = 0;
+  for (int i = tid; i < B; i += T) bk_hist[i] = 0;
   __syncthreads();
   const int64_t p0 = (int64_t)blockIdx.x * ppb;
   const int64_t p1 = p0 + ppb < n ? p0 + ppb : n;
-  for (int64_t p = p0 + tid; p < p1; p += 256) {
+  for (int64_t p = p0 + tid; p < p1; p += T) {
     const float x = pos[3 * p], y = pos[3 * p + 1], z = pos[3 * p + 2];
     int rem0[4], rank[4];
     float bary[4];
@@ -1579,9 +1580,9 @@ __global__ void __launch_bounds__(256) k_bk_split(const float* __restrict__ pos,
     }
   }
   __syncthreads();
-  // exclusive scan of the B counts: a thread owns B/256 consecutive buckets (one, for fewer than 256).  off is bucket-major ([B + 1][nblk]) so that
+  // exclusive scan of the B counts: a thread owns B/T consecutive buckets (one, for B < T).  off is bucket-major ([B + 1][nblk]) so that
   // a bucket's workgroup reads its runs with contiguous loads.
-  const int per = B >= 256 ? B >> 8 : (tid < B ? 1 : 0);
+  const int per = B >= T ? B / T : (tid < B ? 1 : 0);
   uint32_t mine = 0;
   for (int k = 0; k < per; ++k) mine += bk_hist[tid * per + k];
   uint32_t total;
@@ -1592,10 +1593,10 @@ __global__ void __launch_bounds__(256) k_bk_split(const float* __restrict__ pos,
     off[(size_t)(tid * per + k) * nblk + blockIdx.x] = run;
     run += c;
   }
-  if (tid == 255) off[(size_t)B * nblk + blockIdx.x] = total;
+  if (tid == 0) off[(size_t)B * nblk + blockIdx.x] = total;
   __syncthreads();
   TlnRec* region = rec + (size_t)blockIdx.x * (4 * (size_t)ppb);
-  for (int64_t p = p0 + tid; p < p1; p += 256) {
+  for (int64_t p = p0 + tid; p < p1; p += T) {
     const float x = pos[3 * p], y = pos[3 * p + 1], z = pos[3 * p + 2];
     int rem0[4], rank[4];
     float bary[4];
@@ -1638,25 +1639,30 @@ __device__ __forceinline__ int bk_lds_find(const unsigned long long* hk, uint64_
   return -1;
 }
 
-// the rows of bucket b that thread tid walks: run tid of the bucket (run j = the bucket's records inside split block j's
-// region, contiguous; there are at most TLN_BK_THREADS split blocks)
+// the rows of bucket b that thread tid walks.  Run j = the bucket's records inside split block j's region (contiguous;
+// at most TLN_BK_THREADS split blocks); 2^sh threads share a run (as many as fit the workgroup), thread q of them takes
+// its rows q, q + 2^sh, ...: neighbouring threads read neighbouring records
 #define BK_KEEP 3   // rows a thread keeps in registers between its two sweeps
 struct BkRuns {
   const TlnRec* at;
-  int total;
+  int total, step;
 };
 __device__ __forceinline__ void bk_runs_of(const uint32_t* __restrict__ off, const TlnRec* __restrict__ rec, int nblk,
                                            int64_t rpb, int b, BkRuns& rn) {
-  const int j = threadIdx.x;
+  int sh = 0;
+  while ((nblk << (sh + 1)) <= TLN_BK_THREADS) ++sh;
+  const int j = threadIdx.x >> sh, q = threadIdx.x & ((1 << sh) - 1);
   uint32_t s0 = 0, e0 = 0;
   if (j < nblk) {
     s0 = off[(size_t)b * nblk + j];
     e0 = off[(size_t)(b + 1) * nblk + j];
   }
-  rn.at = rec + (size_t)j * rpb + s0;
-  rn.total = (int)(e0 - s0);
+  const int len = (int)(e0 - s0);
+  rn.at = rec + (size_t)j * rpb + s0 + q;
+  rn.step = 1 << sh;
+  rn.total = len > q ? (len - q + rn.step - 1) >> sh : 0;
 }
-__device__ __forceinline__ const TlnRec* bk_rec_of(const BkRuns& rn, int k) { return rn.at + k; }
+__device__ __forceinline__ const TlnRec* bk_rec_of(const BkRuns& rn, int k) { return rn.at + k * rn.step; }
 
 __global__ void __launch_bounds__(TLN_BK_THREADS) k_bk_insert(const TlnRec* __restrict__ rec, const uint32_t* __restrict__ off,
                                                               int nblk, int64_t rpb, TableRef t,
@@ -2018,8 +2024,14 @@ extern "C" int tln_distribute_begin(tln_lattice_t* l, const float* d_positions, 
     const int bucket_rows = env_rows >= 128 && env_rows <= 8192 ? env_rows : TLN_BK_ROWS;
     int B = TLN_BK_MINB;
     while ((int64_t)B * bucket_rows < rows && B < l->bk_maxb) B <<= 1;
-    int64_t ppb = env_ppb >= 256 && env_ppb <= 4096 ? (env_ppb & ~255) : 256;
+    // points per split block: a block's run inside a bucket is ~ppb / 128 records long, and the longer the runs, the
+    // fewer partly used cache lines the bucket kernels pull; ~100 split blocks are kept at least
+    int64_t ppb = 256;
+    while (ppb < 2048 && n / (2 * ppb) >= 96) ppb *= 2;
+    if (env_ppb >= 256 && env_ppb <= TLN_BK_MAX_PPB) ppb = env_ppb & ~255;
     if (tln_cdiv(n, ppb) > TLN_BK_SPLIT_BLOCKS) ppb = (tln_cdiv(n, TLN_BK_SPLIT_BLOCKS) + 255) & ~(int64_t)255;
+    static const int env_st = getenv("TLN_BK_SPLIT_T") ? atoi(getenv("TLN_BK_SPLIT_T")) : 0;
+    const int split_t = env_st == 256 || env_st == 512 || env_st == 1024 ? env_st : (ppb >= 1024 ? 1024 : (ppb >= 512 ? 512 : 256));
     const int nblk = (int)tln_cdiv(n, ppb);
     const int64_t rpb = 4 * ppb;
     TLN_REQUIRE(B <= l->bk_maxb && (int64_t)nblk * rpb <= l->rec_cap && nblk <= TLN_BK_SPLIT_BLOCKS,
@@ -2029,7 +2041,7 @@ extern "C" int tln_distribute_begin(tln_lattice_t* l, const float* d_positions, 
     while ((1ll << slot_bits) < l->nslots) ++slot_bits;
     while ((1 << b_bits) < B) ++b_bits;
     TLN_REQUIRE((int64_t)B * TLN_SLOT_GROUP <= l->nslots, "more buckets (%d) than slot groups", B);
-    hipLaunchKernelGGL(k_bk_split, dim3((unsigned)nblk), dim3(256), (size_t)B * sizeof(uint32_t), s, d_positions, d_values, n,
+    hipLaunchKernelGGL(k_bk_split, dim3((unsigned)nblk), dim3(split_t), (size_t)B * sizeof(uint32_t), s, d_positions, d_values, n,
                        val_dim, l->scale[0], l->scale[1], l->scale[2], (int)ppb, B, l->rec, l->bk_off, d_weights,
                        d_distributed, t.mask, slot_bits - b_bits, nr_words, l->first_flag, l->d_ctr);
     hipLaunchKernelGGL(k_bk_insert, dim3((unsigned)B), dim3(TLN_BK_THREADS), 0, s, l->rec, l->bk_off, nblk, rpb, t, l->first_flag,

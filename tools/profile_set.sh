@@ -7,13 +7,16 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/$TAG
 mkdir -p $O
 if [ "$2" != "pmc-only" ]; then
-  mkdir -p $O/ks4 $O/ks1
+  mkdir -p $O/ks4 $O/ks1 $O/ks1g
   python bench.py > $O/bench.json 2> $O/bench.err
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks4 -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_under_rocprof_4streams.json 2>/dev/null
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks1 -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --streams 1 --pairs 0 > $O/bench_under_rocprof_1stream.json 2>/dev/null
+  # one stream stepping a lock-step group of 8 alone: the launches the `roofline` headline times, without other streams
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks1g -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --streams 1 --pairs 8 > $O/bench_under_rocprof_1stream_group8.json 2>/dev/null
   cp $(ls $O/ks4/*/*kernel_stats.csv | head -1) $O/kernel_stats_4streams.csv
+  cp $(ls $O/ks1g/*/*kernel_stats.csv | head -1) $O/kernel_stats_1stream_group8.csv
   cp $(ls $O/ks1/*/*kernel_stats.csv | head -1) $O/kernel_stats_1stream.csv
-  rm -rf $O/ks4 $O/ks1
+  rm -rf $O/ks4 $O/ks1 $O/ks1g
   cat $O/bench.json
 fi
 mkdir -p $O/pmc/FETCH_SIZE $O/pmc/WRITE_SIZE
