@@ -594,9 +594,10 @@ __global__ void __launch_bounds__(256) k_slice_deform(const float* __restrict__ 
   __syncthreads();
   // blend: the block's points x C classes are written by consecutive threads (coalesced rows of `out`, and each
   // gathered scores row is read by C neighbouring threads)
-  const int64_t live = (n - p0) < (int64_t)PPB ? (n - p0) : (int64_t)PPB;
-  for (int64_t e = threadIdx.x; e < live * C; e += blockDim.x) {
-    const int pt = (int)(e / C), c = (int)(e - (int64_t)pt * C);
+  const int live = (n - p0) < (int64_t)PPB ? (int)(n - p0) : PPB;
+  const int live_c = live * C;   // (32-bit index arithmetic: a 64-bit division per element costs more than the blend)
+  for (int e = threadIdx.x; e < live_c; e += blockDim.x) {
+    const int pt = e / C, c = e - pt * C;
     float acc = 0.0f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -609,19 +610,26 @@ __global__ void __launch_bounds__(256) k_slice_deform(const float* __restrict__ 
   }
   if (logsm == nullptr) return;   // uniform
   // log-softmax over the classes of every point (what LNN_SEQ.forward returns beside the raw scores, models.py:466-468):
-  // x - max - log(sum exp(x - max)), one thread per point for the statistics, then coalesced rows again
+  // x - max - log(sum exp(x - max)); the statistics by FOUR lanes per point (classes q, q + 4, ..; combined in a fixed
+  // order by two butterfly steps), then coalesced rows again
   __syncthreads();
-  if (threadIdx.x < live) {
-    float mx = lg_s[threadIdx.x][0];
-    for (int c = 1; c < C; ++c) mx = fmaxf(mx, lg_s[threadIdx.x][c]);
+  if (pl < live) {
+    float mx = -INFINITY;
+    for (int c = q; c < C; c += 4) mx = fmaxf(mx, lg_s[pl][c]);
+    mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
     float sum = 0.0f;
-    for (int c = 0; c < C; ++c) sum += expf(lg_s[threadIdx.x][c] - mx);
-    mx_s[threadIdx.x] = mx;
-    lse_s[threadIdx.x] = logf(sum);
+    for (int c = q; c < C; c += 4) sum += expf(lg_s[pl][c] - mx);
+    sum += __shfl_xor(sum, 1, 64);
+    sum += __shfl_xor(sum, 2, 64);
+    if (q == 0) {
+      mx_s[pl] = mx;
+      lse_s[pl] = logf(sum);
+    }
   }
   __syncthreads();
-  for (int64_t e = threadIdx.x; e < live * C; e += blockDim.x) {
-    const int pt = (int)(e / C), c = (int)(e - (int64_t)pt * C);
+  for (int e = threadIdx.x; e < live_c; e += blockDim.x) {
+    const int pt = e / C, c = e - pt * C;
     logsm[(p0 + pt) * C + c] = (lg_s[pt][c] - mx_s[pt]) - lse_s[pt];
   }
 }
