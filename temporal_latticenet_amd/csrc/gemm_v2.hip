@@ -192,8 +192,14 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
   struct Frag {
     f32x4 a[TM];
     float b[TN][4];
+    f32x4 sc, sh;   // PRO: the GroupNorm scale / shift of the step's four channels — requested with the fragments, a
+                    // step ahead: read where they are used, every step would start with an exposed LDS round trip
   };
-  auto frag_load = [&](int j, const char* As, const char* Bs, Frag& f) {
+  auto frag_load = [&](int j, int c0, const char* As, const char* Bs, Frag& f) {
+    if (PRO) {
+      f.sc = *reinterpret_cast<const f32x4*>(Gsc + c0 + 8 * j + 4 * half);
+      f.sh = *reinterpret_cast<const f32x4*>(Gsh + c0 + 8 * j + 4 * half);
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int r = arow0 + 32 * i;
@@ -215,19 +221,16 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
       }
     }
   };
-  auto frag_mma = [&](int j, int c0, const bool (&live)[TM], Frag& f, auto hpart) {
+  auto frag_mma = [&](const float (&hi)[TM], Frag& f, auto hpart) {
     constexpr bool H = decltype(hpart)::value;   // GRU: this chunk belongs to the second source
     if (PRO) {
-      const f32x4 sc = *reinterpret_cast<const f32x4*>(Gsc + c0 + 8 * j + 4 * half);
-      const f32x4 sh = *reinterpret_cast<const f32x4*>(Gsh + c0 + 8 * j + 4 * half);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          // GroupNorm affine, ReLU as an integer max on the bit pattern, then the zero row of a missing neighbour
-          const float v = fmaf(f.a[i][e], sc[e], sh[e]);
-          const float rl = __int_as_float(max(__float_as_int(v), 0));
-          f.a[i][e] = live[i] ? rl : 0.0f;
+          // GroupNorm affine; ReLU and the zero row of a missing neighbour in ONE median: a clamp to [0, inf) for a row
+          // that exists, to [0, 0] for one that does not
+          f.a[i][e] = __builtin_amdgcn_fmed3f(fmaf(f.a[i][e], f.sc[e], f.sh[e]), 0.0f, hi[i]);
         }
     }
 #pragma unroll
@@ -249,29 +252,42 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
     if (STAGES == 3) issue(1, 1);
   }
   int st = 0;
+  // PRO: upper end of the clamp behind the affine (frag_mma) for this lane's rows in chunk t: inf for a row that exists
+  // under the chunk's tap, 0 for a missing neighbour.  Two dependent LDS reads (tap list, index list), neither touched
+  // after the prologue: asked for one chunk AHEAD, in the middle of the MFMAs, instead of right behind the barrier
+  auto clamp_of = [&](int t_raw, float (&hi)[TM]) {
+    const int t = t_raw < nchunks ? t_raw : nchunks - 1;
+    const int tap = Taps[1 + t / cpt];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) hi[i] = (PRO && Is[(arow0 + 32 * i) * taps + tap] < 0) ? 0.0f : __builtin_inff();
+  };
+  float hi[TM];
+  if (nchunks > 0) clamp_of(0, hi);
   auto chunk = [&](int t, auto hpart) {
     // this thread's DMAs of chunk t have landed (those of chunk t+1 may still fly); after the barrier everybody's
     // have, and everybody has finished reading the stage that chunk t+2 is about to overwrite
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(STAGES == 3 ? PIECES : 0) : "memory");
     const int ti = t / cpt;
-    const int tap = Taps[1 + ti];
     const int c0 = (t - ti * cpt) << 5;
     const char* As = ring + st * STAGE;
     const char* Bs = As + A_BYTES;
-    bool live[TM];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) live[i] = PRO ? Is[(arow0 + 32 * i) * taps + tap] >= 0 : true;
     Frag f0, f1;
-    frag_load(0, As, Bs, f0);
-    frag_load(1, As, Bs, f1);
-    frag_mma(0, c0, live, f0, hpart);
+    frag_load(0, c0, As, Bs, f0);
+    frag_load(1, c0, As, Bs, f1);
+    frag_mma(hi, f0, hpart);
     if (STAGES == 3) issue(t + 2, st == 0 ? 2 : st - 1);
     else issue(t + 1, st ^ 1);
-    frag_load(2, As, Bs, f0);
-    frag_mma(1, c0, live, f1, hpart);
-    frag_load(3, As, Bs, f1);
-    frag_mma(2, c0, live, f0, hpart);
-    frag_mma(3, c0, live, f1, hpart);
+    frag_load(2, c0, As, Bs, f0);
+    frag_mma(hi, f1, hpart);
+    frag_load(3, c0, As, Bs, f1);
+    frag_mma(hi, f0, hpart);
+    float hin[TM];
+    if (PRO) clamp_of(t + 1, hin);
+    frag_mma(hi, f1, hpart);
+    if (PRO) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) hi[i] = hin[i];
+    }
     // scheduling hint for the whole (branch-free) chunk body: one MFMA, then a little of everything else — an MFMA
     // occupies the matrix pipe for 16 issue slots, and what a wave issues between two MFMAs is free, what it issues
     // in a lump between two runs of MFMAs is not (with one wave per SIMD nobody else fills the pipe meanwhile)
