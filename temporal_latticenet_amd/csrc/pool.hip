@@ -205,10 +205,7 @@ __global__ void __launch_bounds__(256) k_pool_bins(const TlnBins bn, int64_t row
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float* tile = smem + wid * (64 * TS + 256);
-  int* tv = reinterpret_cast<int*>(tile + 64 * TS);
-  int* tr = tv + 64;
-  float* tw = reinterpret_cast<float*>(tr + 64);
-  int* tf = reinterpret_cast<int*>(tw + 64);
+  float* tw = tile + 64 * TS;   // [64] barycentric weight of the chunk's rows
 
   const int64_t chunk = (int64_t)blockIdx.x * 4 + wid;
   const int64_t j0 = chunk * 64;
@@ -217,7 +214,10 @@ __global__ void __launch_bounds__(256) k_pool_bins(const TlnBins bn, int64_t row
   const int nv = bn.ctr[0];
   const float w0 = bn.weights[0];   // lm:514: an arg-max row id > V reads the barycentric weight of row 0
 
-  // ---- phase 1: lane = row
+  // ---- phase 1: lane = row.  Vertex, row id and flags of the lane's row stay in registers: phase 2 fetches those of
+  // row j with v_readlane (j is wave-uniform) — scalars, so the walk below branches on the scalar unit and keeps its
+  // per-vertex state there, instead of comparing broadcast LDS values lane by lane under exec masks
+  int my_v = 0, my_r = 0, my_f = 0;
   if (lane < cnt) {
     const int64_t at = j0 + lane;
     float4 q = bn.rec[at].a;
@@ -255,10 +255,10 @@ __global__ void __launch_bounds__(256) k_pool_bins(const TlnBins bn, int64_t row
     }
 #pragma unroll
     for (int c = 0; c < HL; ++c) tile[lane * TS + c] = hl[c];
-    tv[lane] = vv;
-    tr[lane] = (int)meta.y;
+    my_v = vv;
+    my_r = (int)meta.y;
+    my_f = flags;
     tw[lane] = __uint_as_float(meta.x);
-    tf[lane] = flags;
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the wave's own LDS writes have landed
@@ -295,10 +295,11 @@ __global__ void __launch_bounds__(256) k_pool_bins(const TlnBins bn, int64_t row
   };
   // a vertex's rows [js, je] of this chunk are done: its result goes straight to the output when they are ALL its rows
   auto flush = [&](int v, int js, int je, float best, int bj, int arg) {
-    const bool whole = (tf[js] & 1) && (tf[je] & 2);   // wave-uniform
+    const int fs = __builtin_amdgcn_readlane(my_f, js), fe = __builtin_amdgcn_readlane(my_f, je);
+    const bool whole = (fs & 1) && (fe & 2);   // wave-uniform
     if (!active) return;
     if (whole) {
-      const bool masked = (tf[js] & 4) != 0;
+      const bool masked = (fs & 4) != 0;
       const float bary = arg > nv ? w0 : tw[bj];
       out[(int64_t)v * (2 * COUT) + c] = masked ? 0.0f : best;
       out[(int64_t)v * (2 * COUT) + COUT + c] = masked ? 0.0f : bary;
@@ -308,23 +309,25 @@ __global__ void __launch_bounds__(256) k_pool_bins(const TlnBins bn, int64_t row
       atomicMax(&packed[(int64_t)v * COUT + c], p);
     }
   };
-  int cur = tv[0], js = 0, bj = 0, brow = tr[0];
+  int cur = __builtin_amdgcn_readlane(my_v, 0), js = 0;   // scalars
+  int bj = 0, brow = __builtin_amdgcn_readlane(my_r, 0);  // per lane (= channel): row of the running maximum
   float best = value_of(0);
   for (int j = 1; j < cnt; ++j) {
-    const int v = tv[j];
-    const int rj = tr[j];           // one address for the whole wave
+    const int v = __builtin_amdgcn_readlane(my_v, j);
+    const int rj = __builtin_amdgcn_readlane(my_r, j);
     const float val = value_of(j);
-    if (v != cur) {  // wave-uniform
+    if (v != cur) {  // scalar branch
       flush(cur, js, j - 1, best, bj, brow);
       cur = v;
       js = j;
       best = val;
       bj = j;
       brow = rj;
-    } else if (val > best || (val == best && rj < brow)) {   // ties: the smallest row id
-      best = val;
-      bj = j;
-      brow = rj;
+    } else {
+      const bool better = val > best || (val == best && rj < brow);   // ties: the smallest row id
+      best = better ? val : best;
+      bj = better ? j : bj;
+      brow = better ? rj : brow;
     }
   }
   flush(cur, js, cnt - 1, best, bj, brow);
