@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """K1 alone (distribute of the 4 frames of one calibrated 120k-point sequence, repeated): run under
 rocprofv3 --kernel-trace --stats to get the per-kernel durations of the variant selected by the environment
-(TLN_K1_LEGACY, TLN_BK_PPB, TLN_BK_ROWS).   python tools/k1_probe.py [reps]"""
+(TLN_K1_LEGACY, TLN_BK_PPB, TLN_BK_SPLIT_T, TLN_BK_ROWS).   python tools/k1_probe.py [reps]"""
 import os
 import sys
 import time
