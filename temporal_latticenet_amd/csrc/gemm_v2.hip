@@ -13,10 +13,11 @@
 //     [BN][32] ([N,K] weights, like A);
 //   * a ring of three LDS stages, loads two chunks ahead, ONE barrier per chunk: `s_waitcnt vmcnt(pieces)` (the
 //     next chunk's DMAs stay in flight) -> `s_barrier` -> issue chunk t+2 -> multiply chunk t;
-//   * four waves as 2 x 2 (or 4 x 1 for narrow N), each 64 x 96 / 64 x 64 / 32 x 64 outputs; the k order inside a
+//   * eight waves as 4 x 2 (four as 4 x 1 for narrow N), each 32 x 96 / 32 x 64 / 32 x 32 outputs; the k order inside a
 //     chunk is permuted (lane half h takes k = 8j + 4h + e), identically for A and B, so one b128 read feeds 4 MFMAs;
 //   * the GroupNorm affine + ReLU of the consumer side (GN -> ReLU -> conv) is applied when a fragment is read, a
-//     missing neighbour stays an exact zero row (flag from the tap table in LDS), as in gemm.hip;
+//     missing neighbour stays an exact zero row: fma, then ONE v_med3_f32 that clamps to [0, inf) or to [0, 0]; the
+//     scale / shift of a step arrive with its fragments, the clamp bound of a lane's rows a chunk ahead;
 //   * epilogue as in gemm.hip: bias, residual, ReLU, per-32-row (sum, sum^2) in fp64 for the next GroupNorm.
 // One source only (the two-source products live on small levels); rows past the source read as zeros (pad = 0).
 #include "gemm_args.h"
@@ -239,8 +240,6 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int jn = 0; jn < TN; ++jn) {
-          constexpr int dummy = 0;
-          (void)dummy;
           const int slot = (GRU && H && jn == TN - 1) ? TN : jn;   // compile-time after unrolling
           acc[i][slot] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][e], f.b[jn][e], acc[i][slot], 0, 0, 0);
         }
