@@ -1495,13 +1495,16 @@ __global__ void __launch_bounds__(256) k_bins_mean(const int32_t* __restrict__ c
 // points arrive shuffled.  Here the rows are first split by 8-13 bits of their key's hash into buckets of ~500 rows, and
 // ONE workgroup owns a bucket: every per-row atomic (find-or-insert, row count, first touch, fixed-point position sums)
 // is an LDS atomic on the bucket's own 1024-entry table; the global table sees one probe per DISTINCT key of the frame.
-//   k_bk_split   block = a range of points: simplex arithmetic, LDS histogram of the buckets, then the 32-byte records
+//   k_bk_split   block = a range of 256-2048 points (1024 on a 120k-point frame; a thread per point up to 1024
+//                threads): simplex arithmetic, LDS histogram of the buckets, then the 32-byte records
 //                {x, y, z, value, weight, row, key} written bucket by bucket into the block's own region (+ the block's
 //                bucket offsets, stored bucket-major); also the per-row weights and, when asked for, the [4N,5] rows
-//   k_bk_insert  block = a bucket: walks its runs (one per split block, ~1 row each), LDS find-or-insert with the
-//                smallest row per key; then one global probe_insert per distinct key, the first-touch flag of the keys
-//                without a vertex (and their count per 1024 rows, for the numbering), the bucket's row count
-//   k_assign_flags   first-touch numbering from the flag array (no per-row table reads)
+//   k_bk_insert  block = a bucket: walks its runs (one per split block, ~points per block / 128 records each; as many
+//                threads share a run as fit the workgroup), LDS find-or-insert with the smallest row per key; then one
+//                global probe per distinct key (a new key: one plain 16-byte store), the bit of the first-touch row of
+//                every key without a vertex in a bit mask over the rows, the bucket's row count
+//   k_bk_prefix  one workgroup: set bits of the mask before every 128 rows = the first-touch numbering a scan over the
+//                rows in order would hand out; the counters, also into the host's mapped words
 //   k_bk_place   block = a bucket: LDS table again, now with row counts and position sums; one global lookup per
 //                distinct key -> vertex; the bucket's rows go to the bin range [rows of the buckets before, +own rows),
 //                one segment per vertex (the layout k_pool_bins reads), rows without a vertex behind them; indices[row]
