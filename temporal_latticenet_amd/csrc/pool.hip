@@ -204,7 +204,7 @@ __global__ void __launch_bounds__(256) k_pool_bins(const TlnBins bn, int64_t row
   constexpr int TS = ((HL + 3) / 4) * 4 + 4;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  float* tile = smem + wid * (64 * TS + 256);
+  float* tile = smem + wid * (64 * TS + 64);
   float* tw = tile + 64 * TS;   // [64] barycentric weight of the chunk's rows
 
   const int64_t chunk = (int64_t)blockIdx.x * 4 + wid;
@@ -635,7 +635,7 @@ static int launch_pool_bins(const TlnBins& bn, int64_t rows, const float* const*
                             unsigned long long* packed, float* d_out, int32_t* d_argrow, hipStream_t s) {
   constexpr int HL = (H1 == 0) ? CIN : (H2 ? H2 : H1);
   constexpr int TS = ((HL + 3) / 4) * 4 + 4;
-  const size_t lds = (size_t)(4 * (64 * TS + 256)) * sizeof(float);
+  const size_t lds = (size_t)(4 * (64 * TS + 64)) * sizeof(float);   // 37.9 KB for the 32-wide last hidden layer: four workgroups per CU
   MlpParams mp{};
   for (int i = 0; i < 3; ++i) {
     mp.w[i] = (H1 && w) ? w[i < (H2 ? 3 : 2) ? i : 0] : nullptr;
