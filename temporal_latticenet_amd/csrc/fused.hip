@@ -508,7 +508,7 @@ extern "C" int tln_slice(const float* d_lv, int64_t V, int C, const int32_t* d_i
 // ---------------------------------------------------------------------------------------
 #define TLN_SLICE_MAX_C 64
 template <int CB>
-__global__ void __launch_bounds__(256) k_slice_deform(const float* __restrict__ b, const float* __restrict__ scores,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) k_slice_deform(const float* __restrict__ b, const float* __restrict__ scores,
                                                       int64_t V, int C, const int32_t* __restrict__ indices,
                                                       const float* __restrict__ weights,
                                                       const float* __restrict__ w_pre, const float* __restrict__ w_dw,
@@ -523,7 +523,11 @@ __global__ void __launch_bounds__(256) k_slice_deform(const float* __restrict__ 
   __shared__ float wd_s[4 * G];
   __shared__ float wr_s[PPB][4];
   __shared__ int idx_s[PPB][4];
-  __shared__ float lg_s[PPB][TLN_SLICE_MAX_C + 1];   // the block's logits, for the fused log-softmax (models.py:467)
+  // the block's logits, for the fused log-softmax (models.py:467): [PPB][C | 1], sized by the launch — with the other
+  // arrays 15 KB for 26 classes, so that eight workgroups share a CU and the 1875 of a 120k-point scan run in ONE round
+  // (the kernel is a chain of dependent gathers and four barriers: latency, not arithmetic)
+  extern __shared__ float lg_s[];
+  const int LS = C | 1;
   __shared__ float mx_s[PPB], lse_s[PPB];
   for (int i = threadIdx.x; i < G * GP; i += blockDim.x) {
     const int j = i / GP, k = i - j * GP;
@@ -606,7 +610,7 @@ __global__ void __launch_bounds__(256) k_slice_deform(const float* __restrict__ 
     }
     const float v = bias ? acc + bias[c] : acc;
     out[(p0 + pt) * C + c] = v;
-    if (logsm) lg_s[pt][c] = v;
+    if (logsm) lg_s[pt * LS + c] = v;
   }
   if (logsm == nullptr) return;   // uniform
   // log-softmax over the classes of every point (what LNN_SEQ.forward returns beside the raw scores, models.py:466-468):
@@ -615,11 +619,11 @@ __global__ void __launch_bounds__(256) k_slice_deform(const float* __restrict__ 
   __syncthreads();
   if (pl < live) {
     float mx = -INFINITY;
-    for (int c = q; c < C; c += 4) mx = fmaxf(mx, lg_s[pl][c]);
+    for (int c = q; c < C; c += 4) mx = fmaxf(mx, lg_s[pl * LS + c]);
     mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
     float sum = 0.0f;
-    for (int c = q; c < C; c += 4) sum += expf(lg_s[pl][c] - mx);
+    for (int c = q; c < C; c += 4) sum += expf(lg_s[pl * LS + c] - mx);
     sum += __shfl_xor(sum, 1, 64);
     sum += __shfl_xor(sum, 2, 64);
     if (q == 0) {
@@ -630,7 +634,7 @@ __global__ void __launch_bounds__(256) k_slice_deform(const float* __restrict__ 
   __syncthreads();
   for (int e = threadIdx.x; e < live_c; e += blockDim.x) {
     const int pt = e / C, c = e - pt * C;
-    logsm[(p0 + pt) * C + c] = (lg_s[pt][c] - mx_s[pt]) - lse_s[pt];
+    logsm[(p0 + pt) * C + c] = (lg_s[pt * LS + c] - mx_s[pt]) - lse_s[pt];
   }
 }
 
@@ -644,7 +648,8 @@ extern "C" int tln_slice_deform_ls(const float* d_b, int cb, const float* d_scor
   TLN_REQUIRE(d_logsm == nullptr || C <= TLN_SLICE_MAX_C, "fused log-softmax: at most %d classes (got %d)",
               TLN_SLICE_MAX_C, C);
   if (n <= 0) return TLN_OK;
-  hipLaunchKernelGGL(k_slice_deform<8>, dim3((unsigned)tln_cdiv(n, 64)), dim3(256), 0, (hipStream_t)stream_, d_b,
+  const size_t lds = d_logsm ? (size_t)64 * (C | 1) * sizeof(float) : 0;
+  hipLaunchKernelGGL(k_slice_deform<8>, dim3((unsigned)tln_cdiv(n, 64)), dim3(256), lds, (hipStream_t)stream_, d_b,
                      d_scores, V, C, d_indices, d_weights, d_w_pre, d_w_dw, d_b_dw, d_bias, n, d_out, d_logsm);
   TLN_LAUNCH_CHECK();
   return TLN_OK;
