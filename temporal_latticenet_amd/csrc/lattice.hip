@@ -1645,7 +1645,9 @@ __device__ __forceinline__ int bk_lds_find(const unsigned long long* hk, uint64_
 // the rows of bucket b that thread tid walks.  Run j = the bucket's records inside split block j's region (contiguous;
 // at most TLN_BK_THREADS split blocks); 2^sh threads share a run (as many as fit the workgroup), thread q of them takes
 // its rows q, q + 2^sh, ...: neighbouring threads read neighbouring records
-#define BK_KEEP 3   // rows a thread keeps in registers between its two sweeps
+#define BK_KEEP 1   // rows a thread keeps in registers between its two sweeps (a thread has one row, seldom two, now that the
+                    // threads of a run share it; with three k_bk_place needed 84 VGPRs: three workgroups per CU, and a
+                    // frame's 1024 buckets ran in two rounds)
 struct BkRuns {
   const TlnRec* at;
   int total, step;
@@ -1798,7 +1800,7 @@ __global__ void __launch_bounds__(TLN_BK_THREADS) k_bk_prefix(const uint32_t* __
   }
 }
 
-__global__ void __launch_bounds__(TLN_BK_THREADS) k_bk_place(const TlnRec* __restrict__ rec, const uint32_t* __restrict__ off, int nblk,
+__global__ void __launch_bounds__(TLN_BK_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) k_bk_place(const TlnRec* __restrict__ rec, const uint32_t* __restrict__ off, int nblk,
                                                   int B, int64_t rpb, TableRef t, const uint32_t* __restrict__ bucket_rows,
                                                   int64_t rows, int32_t* __restrict__ vstart, int32_t* __restrict__ vcnt,
                                                   int32_t* __restrict__ vstamp, int stamp, float* __restrict__ mean,
@@ -1858,16 +1860,12 @@ __global__ void __launch_bounds__(TLN_BK_THREADS) k_bk_place(const TlnRec* __res
   constexpr int EPT = TLN_BK_HT / TLN_BK_THREADS;
   int v[EPT];
   uint32_t c[EPT];
-  long long sx[EPT], sy[EPT], sz[EPT];
   uint32_t placed = 0;
 #pragma unroll
   for (int k = 0; k < EPT; ++k) {
     const int e = tid * EPT + k;
     c[k] = hcnt[e];
     v[k] = -1;
-    sx[k] = (long long)hsum[0][e];
-    sy[k] = (long long)hsum[1][e];
-    sz[k] = (long long)hsum[2][e];
     if (c[k]) {
       const unsigned long long K = hk[e];
       uint64_t slot = tln_mix64(K) & t.mask;
@@ -1908,7 +1906,15 @@ __global__ void __launch_bounds__(TLN_BK_THREADS) k_bk_place(const TlnRec* __res
         }
       }
     }
-    if (v[k] >= 0) placed += c[k];
+    if (v[k] >= 0) {
+      placed += c[k];
+      // the local mean needs the sums and the vertex only: written here, so that the sums need not live in registers
+      // across the scan below (64 VGPRs = four workgroups per CU: the 1024 buckets of a frame in ONE round)
+      const double cnt = (double)c[k];
+      mean[3 * v[k]] = tln_unfix20((long long)hsum[0][e], cnt);
+      mean[3 * v[k] + 1] = tln_unfix20((long long)hsum[1][e], cnt);
+      mean[3 * v[k] + 2] = tln_unfix20((long long)hsum[2][e], cnt);
+    }
   }
   uint32_t P;
   uint32_t st = bk_block_scan(placed, wtmp, &P);   // (barriers: every sum has been read, hsum may be overwritten)
@@ -1924,10 +1930,6 @@ __global__ void __launch_bounds__(TLN_BK_THREADS) k_bk_place(const TlnRec* __res
       vstart[vv] = (int)(bin0 + st);
       vcnt[vv] = (int)c[k];
       vstamp[vv] = stamp;
-      const double cnt = (double)c[k];
-      mean[3 * vv] = tln_unfix20(sx[k], cnt);
-      mean[3 * vv + 1] = tln_unfix20(sy[k], cnt);
-      mean[3 * vv + 2] = tln_unfix20(sz[k], cnt);
       st += c[k];
     }
   }
