@@ -173,22 +173,10 @@ def main():
             with quiet:
                 pool = SequenceStreams(model, lambda: build_model(contents).eval(), lambda: make_lattice(contents),
                                        frames, S, pairs=per if per > 1 else False)
-            # one ray-cast drive per stream (a different seed each: different vertex counts); the further sequences of a
-            # stream's lock-step group are that drive turned about the vertical axis (again other vertex counts, without
-            # paying the CPU ray casting 32 times)
-            drives = [frames] + [
-                [(torch.from_numpy(p).cuda(), torch.from_numpy(v).cuda())
-                 for p, v in make_sequence(args.points, args.frames, seed=seed + 1000 * i)] for i in range(1, S)]
-
-            def turned(drive, j):
-                if j == 0:
-                    return drive
-                import math
-                c, s_ = math.cos(0.7 * j), math.sin(0.7 * j)
-                rot = torch.tensor([[c, 0.0, s_], [0.0, 1.0, 0.0], [-s_, 0.0, c]], device="cuda")
-                return [((p @ rot.T).contiguous(), v) for p, v in drive]
-
-            per_stream = [turned(drives[i], j) for i in range(S) for j in range(per)]
+            # one ray-cast drive per stream, the further sequences of a stream's lock-step group = that drive turned about
+            # the vertical axis (temporal_latticenet_amd/workload.py: shared with the parity test of this configuration)
+            from temporal_latticenet_amd.workload import group_sequences, stream_drives
+            per_stream = group_sequences(stream_drives(args.points, args.frames, seed, S, first=frames), per)
 
             def run_steps(n):
                 pool.run([per_stream[per * i:per * i + per] * n for i in range(S)])
@@ -221,6 +209,12 @@ def main():
             barrier()
             el_h = D.max_over_ranks(time.perf_counter() - t0, device=None if via_host else "cuda")
             value_h2d = args.gpus * S * per * n_h * args.frames / el_h
+
+        # ---- what the timed region computed, checked: one more step of the same configuration with the outputs kept;
+        # one sequence per stream (at different positions of its lock-step group) against the same sequence run ALONE
+        checked, kept0 = None, None
+        if not frames_mode and rank == 0:
+            checked, kept0 = self_check(pool, per_stream, S, per, model, contents, make_lattice)
 
         # vertex counts of the workload (data dependent; printed with every result)
         model.reset_sequence()
@@ -405,7 +399,7 @@ def main():
 
     cpu = None
     if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(model, contents, args)
+        cpu = cpu_baseline(model, contents, args, checked, kept0)
 
     if rank == 0:
         par = ("frames of a sequence sharded over %d ranks (key all-gather + hidden-state hand-off), %d group(s)"
@@ -424,7 +418,7 @@ def main():
                                    "full U-Net lattice encoder/decoder, inference" % (args.frames, args.points, args.sigma, args.rnn),
                        "parallelism": par, "vertices_per_frame_V0_V1_V2": vcounts},
             "value_h2d": None if value_h2d is None else round(value_h2d, 3),
-            "roofline": roof, "roofline_scatter": scatter, "cpu_baseline": cpu,
+            "roofline": roof, "roofline_scatter": scatter, "cpu_baseline": cpu, "checked": checked,
         }
         if frames_mode:
             # the recurrence bounds what one sequence gains from more GPUs (latency); a stream of
@@ -438,7 +432,55 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(model, contents, args):
+def self_check(pool, per_stream, S, per, model, contents, make_lattice):
+    """The timed region keeps no outputs; this runs ONE more step of exactly that configuration (same pool, same
+    sequences, same kernel selection) with the last-frame scores kept and compares one sequence per stream -- at a
+    different position of its lock-step group each -- with the same sequence run alone on the null stream:
+      * with the lone run held on the kernels the group takes (tln_gemm_v2_config(0, 1): every product on gemm_v2, as the
+        shared launches of a group are): expected BITWISE equal -- a shared launch must not change a bit;
+      * with the lone run on its own default kernels (direct kernel on the coarse levels): equal up to the order of the
+        K summation; max |difference| reported.
+    cpu_baseline() adds the comparison of stream 0's first sequence with the CPU oracle (models.py:284-476 restated)."""
+    import torch
+    from temporal_latticenet_amd import _lib
+    lib = _lib.lib()
+    got = pool.run([per_stream[per * i:per * i + per] for i in range(S)], keep_outputs=True)
+
+    def alone(seq):
+        lat = make_lattice(contents)
+        for t, (pos, val) in enumerate(seq):
+            out, raw, lat = model(lat, pos, val, t != len(seq) - 1, False)
+        model.reset_sequence()
+        return raw
+
+    picks = [(i, (2 * i + 1) % per) for i in range(S)]
+    bitwise, d_same, d_default, scale = True, 0.0, 0.0, 0.0
+    for i, j in picks:
+        g = got[i][j]
+        seq = per_stream[per * i + j]
+        if per > 1:
+            lib.tln_gemm_v2_config(0, 1)
+        try:
+            a = alone(seq)
+        finally:
+            lib.tln_gemm_v2_config(0, 12288)
+        b = alone(seq) if per > 1 else a
+        bitwise = bitwise and bool(torch.equal(g, a))
+        d_same = max(d_same, float((g - a).abs().max()))
+        d_default = max(d_default, float((g - b).abs().max()))
+        scale = max(scale, float(b.abs().max()))
+    finite = all(bool(torch.isfinite(o).all()) for st in got for o in st)
+    checked = {"sequences_vs_solo": ["stream %d, group position %d" % p for p in picks],
+               "bitwise_solo": bitwise, "max_abs_vs_solo_same_kernels": d_same,
+               "max_abs_vs_solo_default_kernels": d_default, "max_abs_logit": round(scale, 3),
+               "all_outputs_finite": finite, "outputs": sum(len(st) for st in got),
+               "note": "one extra step of the timed configuration with outputs kept; solo = the same sequence alone on "
+                       "the null stream, (a) every product on gemm_v2 like the group's shared launches -> bitwise, "
+                       "(b) default kernel selection -> K-summation order only"}
+    return checked, got[0][0].cpu()
+
+
+def cpu_baseline(model, contents, args, checked=None, kept0=None):
     """Times the CPU oracle (PyTorch eager restatement of the same path, same weights) on a bounded sample:
     whole sequences of the bench workload until at least --cpu-seconds of CPU work were done."""
     import torch
@@ -463,6 +505,18 @@ def cpu_baseline(model, contents, args):
         dt = time.perf_counter() - t0
         if dt >= args.cpu_seconds or done >= 64:
             break
+    if checked is not None and kept0 is not None and args.cpu_points == args.points:
+        # parity of the timed configuration against the oracle: stream 0's first sequence (this very drive), the oracle
+        # with its bit-exact PointNet summation order (oracle/csrc/pool_mlp.c; the timed baseline above uses F.linear)
+        oracle.exact_pool = True
+        oracle.reset_sequence()
+        for t, (pos, val) in enumerate(seq):
+            want = oracle.forward(pos, val, early_return=(t != len(seq) - 1))
+        err = float((kept0 - want).abs().max())
+        checked["max_abs_vs_oracle"] = err
+        checked["max_abs_vs_oracle_over_max_logit"] = err / max(1.0, float(want.abs().max()))
+        checked["oracle_sequence"] = "stream 0, group position 0 (%d frames x %d points, last frame's %d x %d scores)" % (
+            len(seq), args.points, want.shape[0], want.shape[1])
     return {"value": round(done / dt, 4), "unit": "clouds/s", "cores": cores, "kind": "port",
             "sample": "%d frames (%d whole %d-frame sequences of %d points, same config and weights), oracle/model.py, %.1f s"
                       % (done, done // len(seq), len(seq), args.cpu_points, dt)}

@@ -31,3 +31,20 @@ def _seeded():
     torch.manual_seed(20240607)
     np.random.seed(20240607)
     yield
+
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """every full-size comparison with the oracle left (what, max_abs, max|logit|) in tests.helpers.PARITY: written to
+    gpurun_out/parity_errors.json (copied to profiles/ and tabulated in DESIGN.md section 2)"""
+    from tests.helpers import PARITY
+    if not PARITY:
+        return
+    import json
+    out = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_errors.json"), "w") as f:
+            json.dump(PARITY, f, indent=1)
+    except OSError:
+        pass

@@ -27,3 +27,13 @@ def oracle_from_model(model, contents, nr_classes=26):
     return OracleLNN(model.state_dict(), nr_classes, m["rnn_modules"], m["sequence_learning"], m["pointnet_layers"],
                      m["nr_downsamples"], m["nr_blocks_down_stage"], m["nr_blocks_bottleneck"],
                      m["nr_blocks_up_stage"], [sigma] * 3, int(lg["hash_table_capacity"]), m["experiment"])
+
+
+# parity record of the session (tests/conftest.py::pytest_sessionfinish writes it out)
+PARITY = []
+
+
+def parity_log(what, max_abs, scale, shape=None):
+    PARITY.append({"what": what, "max_abs": max_abs, "max_logit": scale, "max_abs_over_max_logit": max_abs / scale,
+                   "shape": list(shape) if shape else None})
+    print("[parity] %-70s max_abs %.3e  max|logit| %.2f  ratio %.3e" % (what, max_abs, scale, max_abs / scale))

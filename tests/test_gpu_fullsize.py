@@ -37,12 +37,18 @@ def _prepared(contents, seq, gpu, seed):
     return model
 
 
-def _check(got, want, what):
+def _check(got, want, what, tol=TOL):
+    """north-star tolerance: |logit - oracle| <= 1e-4 relative to the largest logit (fp32: the scores reach |x| ~ 30, one
+    ulp there is 2e-6).  Both readings are recorded (tests/helpers.py::parity_log -> gpurun_out/parity_errors.json, the
+    table of DESIGN.md section 2): max_abs and max_abs / max|logit|."""
+    from tests.helpers import parity_log
     got = got.cpu()
     assert got.shape == want.shape
     scale = max(1.0, float(want.abs().max()))
     err = float((got - want).abs().max())
-    assert err <= TOL * scale, "%s: max abs err %.3e (scale %.2f)" % (what, err, scale)
+    parity_log(what, err, scale, tuple(got.shape))
+    assert err <= tol * scale, "%s: max abs err %.3e (scale %.2f)" % (what, err, scale)
+    return err
 
 
 @pytest.mark.parametrize("rnn", [("gru", "gru", "aflow", "gru"), ("gru", "gru", "gru", "gru")])
@@ -75,6 +81,83 @@ def test_four_frames_of_120k_points_match_the_oracle(gpu, rnn):
     model.reset_sequence()
     other.reset_sequence()
     _check(res[0][1], want, "lock-step group, last frame")
+
+
+def test_the_timed_configuration_matches_the_oracle(gpu):
+    """bench.py's timed mode, exactly: SequenceStreams(4 streams x 8 lock-stepped sequences) of 4 x 120 000 points, the
+    four ray-cast drives and their turned copies (temporal_latticenet_amd/workload.py), default kernel selection (gemm_v2
+    on: k_gather_gemm_v2_multi over eight products, k_gn_finalize_multi, the fused GRU cell) -- models.py:284-476 per
+    sequence.  Checked:
+      * one sequence per stream, each at a different position of its group, against the CPU oracle (north-star tolerance);
+      * all 32 against their solo runs (same weights, default kernels: the coarse levels then run on the direct kernel,
+        so equal up to the K-summation order);
+      * the four oracle-checked ones also against a solo run held on the kernels the group takes (every product on
+        gemm_v2): a launch shared by eight products must not change a bit;
+      * the groups rotated by three positions: every sequence bit for bit what it was at its old position."""
+    from temporal_latticenet_amd import _lib
+    from temporal_latticenet_amd.streams import SequenceStreams
+    from temporal_latticenet_amd.workload import group_sequences, stream_drives
+    from tests.helpers import parity_log
+    S, per, T, N = 4, 8, 4, 120000
+    contents = make_config(rnn_modules=("gru", "gru", "aflow", "gru"), frames=T, sigma=0.6, capacity=1 << 18)
+    first = [(torch.from_numpy(p).to(gpu), torch.from_numpy(v).to(gpu)) for p, v in make_sequence(N, T, seed=1234)]
+    model = build_model(contents).eval()
+    with torch.no_grad():
+        lat = make_lattice(contents)
+        for t, (p, v) in enumerate(first[:2]):
+            model(lat, p[:4096], v[:4096], t != 1, False)
+        model.reset_sequence()
+    randomize_parameters(model, seed=11)
+    pool = SequenceStreams(model, lambda: build_model(contents).eval(), lambda: make_lattice(contents), first, S, pairs=per)
+    seqs = group_sequences(stream_drives(N, T, 1234, S, first=first), per)
+    assert len(seqs) == S * per
+    lib = _lib.lib()
+
+    def alone(seq):
+        lat = make_lattice(contents)
+        with torch.no_grad():
+            for t, (p, v) in enumerate(seq):
+                a, b, lat = model(lat, p, v, t != len(seq) - 1, False)
+        model.reset_sequence()
+        return b.clone(), lat.nr_lattice_vertices()
+
+    try:
+        got = pool.run([seqs[per * i:per * i + per] for i in range(S)], keep_outputs=True)
+        assert all(len(g) == per for g in got)
+        # (2) all 32 against their solo runs
+        worst, v_counts = 0.0, set()
+        for i in range(S):
+            for j in range(per):
+                want, v0 = alone(seqs[per * i + j])
+                v_counts.add(v0)
+                g = got[i][j]
+                assert g.shape == (N, 26) and bool(torch.isfinite(g).all())
+                err = float((g - want).abs().max()) / max(1.0, float(want.abs().max()))
+                worst = max(worst, err)
+        parity_log("timed configuration: 32 sequences vs solo runs (default kernels), worst", worst, 1.0)
+        assert worst <= TOL, worst
+        assert len(v_counts) >= 24, "the sequences of the groups are meant to differ in their vertex counts"
+        # (1) + (3) one per stream at a different group position: the oracle, and a solo run on the group's kernels
+        oracle = oracle_from_model(model, contents)
+        for i, j in ((0, 0), (1, 3), (2, 5), (3, 7)):
+            seq = seqs[per * i + j]
+            oracle.reset_sequence()
+            for t, (p, v) in enumerate(seq):
+                want = oracle.forward(p.cpu().numpy(), v.cpu().numpy(), early_return=(t != T - 1))
+            _check(got[i][j], want, "timed configuration 4 streams x 8: stream %d position %d vs oracle" % (i, j))
+            lib.tln_gemm_v2_config(0, 1)
+            try:
+                same, _ = alone(seq)
+            finally:
+                lib.tln_gemm_v2_config(0, 12288)
+            assert torch.equal(got[i][j], same), "stream %d position %d: the shared launches changed a bit" % (i, j)
+        # (4) other positions, same bits
+        rot = pool.run([[seqs[per * i + (j + 3) % per] for j in range(per)] for i in range(S)], keep_outputs=True)
+        for i in range(S):
+            for j in range(per):
+                assert torch.equal(rot[i][j], got[i][(j + 3) % per]), "stream %d: position %d -> %d" % (i, (j + 3) % per, j)
+    finally:
+        pool.close()
 
 
 def test_accumulated_cloud_and_prediction_tail(gpu, tmp_path):
