@@ -32,6 +32,14 @@ int tln_version(void);
 
 /* ---- Lattice handle: replaces latticenet.Lattice (train_ln.py:106, 239) -------------- */
 int tln_lattice_create(tln_lattice_t** out, int pos_dim, const double* sigmas, int64_t capacity);
+/* the same with the lattice scale constant c of scale_i = c / (sigma_i * sqrt((i+1)(i+2))) given: a free choice of the
+ * un-vendored lattice_net dependency (README.md:47; cfg key lattice_gpu.scale_constant here).  0 = the default,
+ * Adams 2010's (d+1)*sqrt(2/3) (meets the sizing hint of seq_config/lnn_train_semantic_kitti.cfg:71); 1.0 = the factor
+ * dropped (what a checkpoint trained against such a build expects).  Coarse levels inherit it. */
+int tln_lattice_create_ex(tln_lattice_t** out, int pos_dim, const double* sigmas, int64_t capacity,
+                          double scale_constant);
+double tln_lattice_default_scale_constant(void);
+double tln_lattice_scale_constant(const tln_lattice_t* l);
 int tln_lattice_destroy(tln_lattice_t* l);
 /* reset_hashmap=True of DistributeLatticeModule (models.py:287-298): clears every level */
 int tln_lattice_clear(tln_lattice_t* l, void* stream);

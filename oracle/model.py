@@ -24,7 +24,7 @@ class OracleLNN:
     def __init__(self, sd, nr_classes, rnn_modules, sequence_learning=True, pointnet_layers=(16, 32, 64),
                  nr_downsamples=2, nr_blocks_down_stage=(2, 2, 2), nr_blocks_bottleneck=3,
                  nr_blocks_up_stage=(1, 2, 2), sigmas=(0.6, 0.6, 0.6), capacity=100000, experiment="none",
-                 nr_levels_down_with_normal_resnet=3, nr_levels_up_with_normal_resnet=3):
+                 nr_levels_down_with_normal_resnet=3, nr_levels_up_with_normal_resnet=3, scale_constant=None):
         self.sd = {k: v.detach().cpu().float() if v.is_floating_point() else v.detach().cpu() for k, v in sd.items()}
         self.nr_classes = nr_classes
         self.rnn = [m if m in ("linear", "maxpool", "cga", "aflow", "lstm", "gru") else "none" for m in rnn_modules]
@@ -35,6 +35,7 @@ class OracleLNN:
         self.nbott = nr_blocks_bottleneck
         self.up = list(nr_blocks_up_stage)
         self.sigmas = list(sigmas)
+        self.scale_constant = scale_constant     # lattice scale constant (permuto.scale_factors); None = Adams'
         self.capacity = capacity
         self.experiment = experiment
         self.normal_down = nr_levels_down_with_normal_resnet
@@ -162,7 +163,7 @@ class OracleLNN:
                 lvl.embedded = 0
         l0 = self.levels[0]
         dist, indices, weights = O.distribute(l0.table, positions, values, self.sigmas,
-                                              self.experiment not in NO_MEAN)        # models.py:298
+                                              self.experiment not in NO_MEAN, self.scale_constant)   # models.py:298
         v0 = l0.table.nr_vertices
         tables = [P.neighbour_table(l0.table)]
         # PointNetSeq (lm:407-576)

@@ -23,11 +23,11 @@ from . import permuto as P
 # ------------------------------------------------------------------------------------------
 # K1 distribute
 # ------------------------------------------------------------------------------------------
-def distribute(table, positions, values, sigmas, subtract_mean=True):
+def distribute(table, positions, values, sigmas, subtract_mean=True, scale_constant=None):
     """positions [N,3] f32, values [N,vd] f32 -> distributed [4N, 3+vd+1], indices [4N] i32, weights [4N]."""
     positions = np.ascontiguousarray(positions, np.float32)
     n = positions.shape[0]
-    scale = P.scale_factors(sigmas)
+    scale = P.scale_factors(sigmas, scale_constant)
     rem0, rank, bary = P.simplex(P.elevate(positions, scale))
     keys = P.simplex_keys(rem0, rank).reshape(4 * n, 3)
     indices = table.insert(keys)
@@ -174,8 +174,16 @@ def im2row(lv, table, pad_rows_value=None):
     return g.reshape(m, -1)
 
 
+CONV_ROWS = 1 << 17   # rows of the materialised im2row per product (a 1M-vertex level at C = 192 would be 6.9 GB at once)
+
+
 def conv(lv, table, weight, bias=None):
-    out = im2row(lv, table) @ weight
+    m = np.asarray(table).shape[0]
+    if m <= CONV_ROWS:
+        out = im2row(lv, table) @ weight
+    else:           # the same product in row blocks (BASELINE config 5: ~1M vertices)
+        table = np.asarray(table)
+        out = torch.cat([im2row(lv, table[r:r + CONV_ROWS]) @ weight for r in range(0, m, CONV_ROWS)])
     return out + bias if bias is not None else out
 
 

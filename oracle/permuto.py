@@ -31,11 +31,18 @@ F32 = np.float32
 # the slab a 64-beam scan covers out to 60 m (about 5 m tall) holds < 2k such vertices whatever the
 # scene.  With Adams' factor (0.92 m^3 per vertex) a street scene gives 8-10k
 # (tests/test_scene_calibration.py).
-def scale_factors(sigmas):
-    """scale[i] = float32( (d+1)*sqrt(2/3) / (sigma_i * sqrt((i+1)(i+2))) ), computed in double."""
-    d1 = float(len(sigmas) + 1)
+#
+# The constant is a parameter (round 3): `constant=None` is Adams' factor, 1.0 drops it (SURVEY.md Appendix A's
+# recollection of upstream; unverified either way -- the dependency is not vendored, README.md:47).
+def default_scale_constant(d=3):
+    return float(d + 1) * math.sqrt(2.0 / 3.0)
+
+
+def scale_factors(sigmas, constant=None):
+    """scale[i] = float32( c / (sigma_i * sqrt((i+1)(i+2))) ), computed in double; c = (d+1)*sqrt(2/3) by default."""
+    c = default_scale_constant(len(sigmas)) if not constant else float(constant)
     return np.array(
-        [d1 * math.sqrt(2.0 / 3.0) / (float(s) * math.sqrt(float((i + 1) * (i + 2)))) for i, s in enumerate(sigmas)],
+        [c / (float(s) * math.sqrt(float((i + 1) * (i + 2)))) for i, s in enumerate(sigmas)],
         dtype=np.float64,
     ).astype(F32)
 

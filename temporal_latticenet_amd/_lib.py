@@ -65,6 +65,9 @@ _PROTOS = {
     "tln_last_error": (C.c_char_p, []),
     "tln_version": (_i, []),
     "tln_lattice_create": (_i, [C.POINTER(_vp), _i, C.POINTER(C.c_double), _i64]),
+    "tln_lattice_create_ex": (_i, [C.POINTER(_vp), _i, C.POINTER(C.c_double), _i64, C.c_double]),
+    "tln_lattice_default_scale_constant": (C.c_double, []),
+    "tln_lattice_scale_constant": (C.c_double, [_vp]),
     "tln_lattice_destroy": (_i, [_vp]),
     "tln_lattice_clear": (_i, [_vp, _vp]),
     "tln_lattice_nr_vertices": (_i64, [_vp]),

@@ -13,15 +13,16 @@ BASE_MODEL = {
 
 
 def make_config(rnn_modules=("gru", "gru", "aflow", "gru"), sequence_learning=True, frames=4, sigma=0.6,
-                capacity=100000, **model_overrides):
+                capacity=100000, scale_constant=None, **model_overrides):
     model = copy.deepcopy(BASE_MODEL)
     model["rnn_modules"] = list(rnn_modules)
     model["sequence_learning"] = sequence_learning
     model.update(model_overrides)
+    lg_extra = {} if scale_constant is None else {"scale_constant": scale_constant}
     return {
         "train": {"dataset_name": "semantickitti"},
         "model": model,
-        "lattice_gpu": {"hash_table_capacity": capacity, "nr_sigmas": 1, "sigma_0": "%s 3" % sigma},
+        "lattice_gpu": {"hash_table_capacity": capacity, "nr_sigmas": 1, "sigma_0": "%s 3" % sigma, **lg_extra},
         "loader_semantic_kitti": {"frames_per_seq": frames, "accumulate_clouds": False, "cloud_scope": 3,
                                   "include_moving_classes": True},
     }
@@ -62,4 +63,4 @@ def make_lattice(contents, nr_points=None, frames=None):
         if frames is None:
             frames = int(contents.get("loader_semantic_kitti", {}).get("frames_per_seq", 1))
         cap = suggest_capacity(nr_points, sigma, frames)
-    return Lattice.from_params([sigma] * 3, int(cap))
+    return Lattice.from_params([sigma] * 3, int(cap), scale_constant=lg.get("scale_constant", None))

@@ -68,6 +68,7 @@ struct tln_lattice {
   int64_t capacity = 0, nslots = 0;
   double sigmas[3] = {1, 1, 1};
   float scale[3] = {1, 1, 1};
+  double scale_constant = 0;   // c of scale_i = c / (sigma_i sqrt((i+1)(i+2))); tln_lattice_create_ex
   TlnSlot* slots = nullptr;   // [nslots] {key, vertex index, first-touch row}: one 16-byte record per probe step
   int32_t* vkeys = nullptr;  // [capacity][4]
   int32_t* d_ctr = nullptr;
@@ -235,7 +236,8 @@ static int ensure_rows(tln_lattice* l, int64_t rows) {
   return TLN_OK;
 }
 
-static int lattice_alloc(tln_lattice** out, int pos_dim, const double* sigmas, int64_t capacity, int level) {
+static int lattice_alloc(tln_lattice** out, int pos_dim, const double* sigmas, int64_t capacity, int level,
+                         double scale_constant) {
   TLN_REQUIRE(pos_dim == 3, "pos_dim %d unsupported (only 3)", pos_dim);
   TLN_REQUIRE(capacity >= 16 && capacity <= (1ll << 26), "capacity %lld out of range", (long long)capacity);
   tln_lattice* l = new tln_lattice();
@@ -248,10 +250,13 @@ static int lattice_alloc(tln_lattice** out, int pos_dim, const double* sigmas, i
   l->nslots = ns;
   for (int i = 0; i < 3; ++i) {
     l->sigmas[i] = sigmas[i];
-    // Adams 2010 §3.1 with its (d+1)*sqrt(2/3) factor: the choice that meets the reference's sizing hint
-    // (seq_config/lnn_train_semantic_kitti.cfg:71, ~10k vertices for a KITTI scan at sigma = 1); DESIGN.md §3.1
-    l->scale[i] = (float)(4.0 * sqrt(2.0 / 3.0) / (sigmas[i] * sqrt((double)((i + 1) * (i + 2)))));
+    // scale_i = c / (sigma_i sqrt((i+1)(i+2))).  The constant c is a free choice of the un-vendored dependency
+    // (README.md:47): default = Adams 2010 §3.1's (d+1)*sqrt(2/3), the choice that meets the reference's sizing hint
+    // (seq_config/lnn_train_semantic_kitti.cfg:71, ~10k vertices for a KITTI scan at sigma = 1); a
+    // checkpoint trained against a build that drops the factor needs c = 1 (tln_lattice_create_ex)
+    l->scale[i] = (float)(scale_constant / (sigmas[i] * sqrt((double)((i + 1) * (i + 2)))));
   }
+  l->scale_constant = scale_constant;
   TLN_HIP(hipMalloc(&l->slots, ns * sizeof(TlnSlot)));
   TLN_HIP(hipMalloc(&l->vkeys, capacity * 4 * sizeof(int32_t)));
   TLN_HIP(hipMalloc(&l->d_ctr, CTR_COUNT * sizeof(int32_t)));
@@ -329,15 +334,26 @@ extern "C" int tln_lattice_clear(tln_lattice_t* l, void* stream_) {
   return TLN_OK;
 }
 
-extern "C" int tln_lattice_create(tln_lattice_t** out, int pos_dim, const double* sigmas, int64_t capacity) {
+extern "C" double tln_lattice_default_scale_constant(void) { return 4.0 * sqrt(2.0 / 3.0); }
+
+extern "C" int tln_lattice_create_ex(tln_lattice_t** out, int pos_dim, const double* sigmas, int64_t capacity,
+                                     double scale_constant) {
   TLN_REQUIRE(out && sigmas, "null argument");
-  int rc = lattice_alloc(out, pos_dim, sigmas, capacity, 0);
+  if (scale_constant == 0.0) scale_constant = tln_lattice_default_scale_constant();
+  TLN_REQUIRE(scale_constant > 0.0 && scale_constant < 1e6, "scale constant %g out of range", scale_constant);
+  int rc = lattice_alloc(out, pos_dim, sigmas, capacity, 0, scale_constant);
   if (rc) return rc;
   rc = tln_lattice_clear(*out, nullptr);
   if (rc) return rc;
   TLN_HIP(hipStreamSynchronize(nullptr));
   return TLN_OK;
 }
+
+extern "C" int tln_lattice_create(tln_lattice_t** out, int pos_dim, const double* sigmas, int64_t capacity) {
+  return tln_lattice_create_ex(out, pos_dim, sigmas, capacity, 0.0);
+}
+
+extern "C" double tln_lattice_scale_constant(const tln_lattice_t* l) { return l ? l->scale_constant : 0.0; }
 
 static void perm_forget(const int32_t* table);   // (row orders of the tap tables: below, with the tables)
 
@@ -2470,7 +2486,7 @@ extern "C" int tln_coarsen(tln_lattice_t* fine, tln_lattice_t** coarse_out, void
   if (!fine->coarse) {
     double sg[3] = {fine->sigmas[0] * 2, fine->sigmas[1] * 2, fine->sigmas[2] * 2};
     tln_lattice* c = nullptr;
-    int rc = lattice_alloc(&c, fine->pos_dim, sg, fine->capacity, fine->level + 1);
+    int rc = lattice_alloc(&c, fine->pos_dim, sg, fine->capacity, fine->level + 1, fine->scale_constant);
     if (rc) return rc;
     c->parent = fine;
     fine->coarse = c;
@@ -2506,7 +2522,7 @@ static int coarsen_deferred(tln_lattice* fine, int64_t fine_bound, hipStream_t s
   if (!fine->coarse) {
     double sg[3] = {fine->sigmas[0] * 2, fine->sigmas[1] * 2, fine->sigmas[2] * 2};
     tln_lattice* c = nullptr;
-    int rc = lattice_alloc(&c, fine->pos_dim, sg, fine->capacity, fine->level + 1);
+    int rc = lattice_alloc(&c, fine->pos_dim, sg, fine->capacity, fine->level + 1, fine->scale_constant);
     if (rc) return rc;
     c->parent = fine;
     fine->coarse = c;

@@ -68,10 +68,31 @@ class Lattice:
         for i in range(nr_sigmas):
             val, extent = str(lg["sigma_%d" % i]).split()
             sigmas += [float(val)] * int(extent)
-        return Lattice.from_params(sigmas, int(lg["hash_table_capacity"]), name)
+        return Lattice.from_params(sigmas, int(lg["hash_table_capacity"]), name,
+                                   scale_constant=lg.get("scale_constant", None))
 
     @staticmethod
-    def from_params(sigmas, capacity, name="lattice"):
+    def parse_scale_constant(v):
+        """cfg key lattice_gpu.scale_constant (not in the reference's cfg: the constant is hard-coded in its un-vendored
+        lattice_net dependency, README.md:47): None / "adams" -> (d+1)*sqrt(2/3), the default (DESIGN.md section 3.1);
+        "unit" -> 1.0 (the factor dropped); or a positive number.  UNVERIFIED against upstream until a real checkpoint
+        or a scan with known vertex counts is at hand; cfg:71's sizing hint is what speaks for the default."""
+        if v is None:
+            return 0.0
+        if isinstance(v, str):
+            t = v.strip().lower()
+            if t in ("", "adams", "default"):
+                return 0.0
+            if t in ("unit", "one", "none"):
+                return 1.0
+            v = float(t)
+        v = float(v)
+        if not v > 0.0:
+            raise _lib.TlnError("lattice_gpu.scale_constant must be positive, 'adams' or 'unit'")
+        return v
+
+    @staticmethod
+    def from_params(sigmas, capacity, name="lattice", scale_constant=None):
         if not torch.cuda.is_available():
             raise _lib.TlnError("Lattice needs a HIP device (torch.cuda.is_available() is False)")
         sigmas = [float(s) for s in sigmas]
@@ -80,7 +101,8 @@ class Lattice:
         torch.cuda.current_stream()  # make sure the HIP context of the current device exists
         h = C.c_void_p()
         arr = (C.c_double * 3)(*sigmas)
-        _lib.check(_lib.lib().tln_lattice_create(C.byref(h), 3, arr, int(capacity)), "tln_lattice_create")
+        _lib.check(_lib.lib().tln_lattice_create_ex(C.byref(h), 3, arr, int(capacity),
+                                                    Lattice.parse_scale_constant(scale_constant)), "tln_lattice_create_ex")
         return Lattice(h, sigmas, capacity, None, name)
 
     def __del__(self):
@@ -118,6 +140,10 @@ class Lattice:
 
     def sigmas(self):
         return list(self._sigmas)
+
+    def scale_constant(self):
+        """c of scale_i = c / (sigma_i sqrt((i+1)(i+2))) this lattice (and its coarse levels) was created with"""
+        return float(_lib.lib().tln_lattice_scale_constant(self._h))
 
     def overflow_rows(self):
         return int(_lib.lib().tln_lattice_overflow_rows(self._h))

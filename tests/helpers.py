@@ -26,7 +26,17 @@ def oracle_from_model(model, contents, nr_classes=26):
     sigma = float(str(lg["sigma_0"]).split()[0])
     return OracleLNN(model.state_dict(), nr_classes, m["rnn_modules"], m["sequence_learning"], m["pointnet_layers"],
                      m["nr_downsamples"], m["nr_blocks_down_stage"], m["nr_blocks_bottleneck"],
-                     m["nr_blocks_up_stage"], [sigma] * 3, int(lg["hash_table_capacity"]), m["experiment"])
+                     m["nr_blocks_up_stage"], [sigma] * 3, int(lg["hash_table_capacity"]), m["experiment"],
+                     scale_constant=_scale_constant(lg.get("scale_constant")))
+
+
+def _scale_constant(v):
+    """cfg value of lattice_gpu.scale_constant -> what oracle.permuto.scale_factors takes (None = Adams' factor)"""
+    if v is None or (isinstance(v, str) and v.strip().lower() in ("", "adams", "default")):
+        return None
+    if isinstance(v, str) and v.strip().lower() in ("unit", "one", "none"):
+        return 1.0
+    return float(v)
 
 
 # parity record of the session (tests/conftest.py::pytest_sessionfinish writes it out)

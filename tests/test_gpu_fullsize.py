@@ -14,7 +14,9 @@ from tests.helpers import build_model, make_config, make_lattice, oracle_from_mo
 from temporal_latticenet_amd.synthetic import make_sequence
 
 pytestmark = pytest.mark.gpu
-TOL = 1e-4
+TOL = 1e-4          # north star: |logit - oracle| <= 1e-4 of the logit scale (read RELATIVE to max|logit|, see _check)
+ABS_TOL = 2.5e-4    # and absolutely: what the 120k-point runs reach is 0.4-1.8e-4 at max|logit| 7-42;
+                    # a regression past that shows here even where the relative bound would still hold
 
 
 def _run(model, contents, seq, gpu, lattice=None, **kw):
@@ -48,6 +50,7 @@ def _check(got, want, what, tol=TOL):
     err = float((got - want).abs().max())
     parity_log(what, err, scale, tuple(got.shape))
     assert err <= tol * scale, "%s: max abs err %.3e (scale %.2f)" % (what, err, scale)
+    assert err <= ABS_TOL, "%s: max abs err %.3e exceeds the recorded absolute level" % (what, err)
     return err
 
 
@@ -197,6 +200,58 @@ def test_eight_recurrent_frames_match_the_oracle(gpu):
     for t, (pos, val) in enumerate(seq):
         want = oracle.forward(pos, val, early_return=(t != len(seq) - 1))
         _check(outs[t], want, "frame %d of 8" % t)
+
+
+def test_config5_eight_frames_of_120k_points_match_the_oracle(gpu):
+    """BASELINE config 5, recurrent half at full size: 8 frames x 120 000 points, [gru,gru,aflow,gru], one growing
+    lattice (V0 19k -> ~40k).  Every frame against the oracle: seven early-return frames (the lattice values the
+    reference returns there, models.py:427) and the last frame's per-point scores."""
+    contents = make_config(rnn_modules=("gru", "gru", "aflow", "gru"), frames=8, sigma=0.6, capacity=1 << 18)
+    seq = make_sequence(120000, 8, seed=77)
+    model = _prepared(contents, seq, gpu, seed=12)
+    outs, lat = _run(model, contents, seq, gpu)
+    assert getattr(model, "_program", None) is not None, "the frame program was not used"
+    v0 = lat.nr_lattice_vertices()
+    print("[config 5] 8 x 120k recurrent: V0 after the last frame = %d" % v0)
+    assert v0 > 35000 and lat.overflow_rows() == 0
+    oracle = oracle_from_model(model, contents)
+    for t, (pos, val) in enumerate(seq):
+        want = oracle.forward(pos, val, early_return=(t != len(seq) - 1))
+        _check(outs[t], want, "config 5: frame %d of 8 x 120k" % t)
+    assert outs[-1].shape == (120000, 26)
+
+
+@pytest.mark.parametrize("sigma", [0.6, 0.07])
+def test_config5_accumulated_960k_cloud_through_the_whole_model(gpu, sigma):
+    """BASELINE config 5, accumulate_clouds half at full size: ONE cloud of 8 x 120 000 = 960 000 points
+    (kitti_dataloader.py:198-201) through the WHOLE model -- distribute, PointNet pool, both coarse levels, the U-Net, the
+    slice head -- with hash_table_capacity "auto" (cfg:71's 100000 overflows at the fine sigma), against the oracle.
+    sigma = 0.6: the pretrained configuration's lattice (~50k vertices); sigma = 0.07: ~1M hashed vertices (config 5's
+    "~1M hashed vertices"; most vertices then hold < 4 rows and are masked by lm:527-530, the quirk is part of the path)."""
+    import time
+    from temporal_latticenet_amd.configs import suggest_capacity
+    frames = make_sequence(120000, 8, seed=77)
+    pos = np.concatenate([p for p, _ in frames])
+    val = np.concatenate([v for _, v in frames])
+    rnn = ("gru", "gru", "aflow", "gru")
+    contents = make_config(rnn_modules=rnn, frames=1, sigma=sigma, capacity="auto")
+    cap = suggest_capacity(pos.shape[0], sigma, 1)
+    model = _prepared(make_config(rnn_modules=rnn, frames=1, sigma=sigma), frames, gpu, seed=13)
+    lat = make_lattice(contents, nr_points=pos.shape[0], frames=1)
+    assert lat.capacity() == cap
+    outs, lat = _run(model, contents, [(pos, val)], gpu, lattice=lat)
+    l1 = lat.coarsen()
+    counts = (lat.nr_lattice_vertices(), l1.nr_lattice_vertices(), l1.coarsen().nr_lattice_vertices())
+    print("[config 5] accumulated 960k cloud at sigma %.2f: V0, V1, V2 = %s, capacity %d" % (sigma, counts, cap))
+    assert lat.overflow_rows() == 0 and counts[0] < cap
+    assert counts[0] > (900000 if sigma < 0.1 else 40000)
+    again, _ = _run(model, contents, [(pos, val)], gpu, lattice=make_lattice(contents, nr_points=pos.shape[0], frames=1))
+    assert torch.equal(outs[0], again[0]), "two runs, same bits"
+    t0 = time.time()
+    contents_o = make_config(rnn_modules=rnn, frames=1, sigma=sigma, capacity=cap)
+    want = oracle_from_model(model, contents_o).forward(pos, val)
+    print("[config 5] oracle: %.1f s" % (time.time() - t0))
+    _check(outs[0], want, "config 5: accumulated cloud of 960k points, sigma %.2f, V0 = %d" % (sigma, counts[0]))
 
 
 def test_vis_aflow_forward(gpu, monkeypatch):

@@ -11,15 +11,15 @@ from temporal_latticenet_amd.synthetic import make_sequence
 pytestmark = pytest.mark.gpu
 
 
-def _run_sequence(gpu, seq, sigma, capacity, subtract_mean=True):
+def _run_sequence(gpu, seq, sigma, capacity, subtract_mean=True, scale_constant=None):
     from temporal_latticenet_amd.lattice import Lattice
-    lat = Lattice.from_params([sigma] * 3, capacity)
+    lat = Lattice.from_params([sigma] * 3, capacity, scale_constant=scale_constant)
     tab = P.VertexTable(3, capacity)
     outs = []
     for t, (pos, val) in enumerate(seq):
         d, i, w = lat.distribute(torch.from_numpy(pos).to(gpu), torch.from_numpy(val).to(gpu),
                                  reset_hashmap=(t == 0), subtract_mean=subtract_mean)
-        od, oi, ow = O.distribute(tab, pos, val, [sigma] * 3, subtract_mean)
+        od, oi, ow = O.distribute(tab, pos, val, [sigma] * 3, subtract_mean, scale_constant)
         outs.append((d.cpu().numpy(), i.cpu().numpy(), w.cpu().numpy(), od, oi, ow))
         assert lat.nr_lattice_vertices() == tab.nr_vertices
         _check_csr(lat, oi)
@@ -57,10 +57,19 @@ def test_build_csr_is_a_stable_sort(gpu, rows, nv):
         idx = np.roll(idx, 17)
 
 
+# the lattice scale constant c (scale_i = c / (sigma_i sqrt((i+1)(i+2))), tln_lattice_create_ex) is a free choice of the
+# un-vendored dependency (README.md:47): None = Adams' (d+1) sqrt(2/3), the default that meets cfg:71's sizing hint; 1.0 =
+# the factor dropped; 2.0 = nobody's choice, the parameter is not a two-way switch
+@pytest.mark.parametrize("scale_constant", [None, 1.0, 2.0])
 @pytest.mark.parametrize("n,sigma", [(20000, 1.0), (120000, 0.6), (5000, 0.2)])
-def test_distribute_matches_oracle(gpu, n, sigma):
+def test_distribute_matches_oracle(gpu, n, sigma, scale_constant):
     seq = make_sequence(n, 3, seed=7)
-    lat, tab, outs = _run_sequence(gpu, seq, sigma, 1 << 18)
+    lat, tab, outs = _run_sequence(gpu, seq, sigma, 1 << 18, scale_constant=scale_constant)
+    assert abs(lat.scale_constant() - (scale_constant or P.default_scale_constant())) < 1e-12
+    lvl = lat
+    for _ in range(2):                      # coarse levels inherit the constant
+        lvl = lvl.coarsen()
+        assert lvl.scale_constant() == lat.scale_constant()
     for d, i, w, od, oi, ow in outs:
         assert np.array_equal(i, oi), "vertex indices must be bit-exact"
         assert np.array_equal(w, ow), "barycentric weights must be bit-exact (same fp32 sequence)"

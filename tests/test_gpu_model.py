@@ -44,6 +44,30 @@ def test_sequence_logits_match_oracle(gpu, rnn):
     assert outs[-1].shape == (15000, 26)
 
 
+@pytest.mark.parametrize("scale_constant", ["unit", 2.0])
+def test_sequence_logits_match_oracle_under_another_lattice_scale_constant(gpu, scale_constant):
+    """cfg key lattice_gpu.scale_constant (Lattice.create / make_lattice -> tln_lattice_create_ex): the whole path with the
+    lattice scale constant an upstream build WITHOUT Adams' (d+1) sqrt(2/3) would use ("unit": cells 3.27x wider in
+    every direction), and with a third value -- against the oracle run with the same constant"""
+    contents = make_config(rnn_modules=("gru", "gru", "aflow", "gru"), frames=3, sigma=0.3, scale_constant=scale_constant)
+    seq = make_sequence(15000, 3, seed=37)
+    model = build_model(contents).eval()
+    _run(model, contents, seq, gpu)
+    randomize_parameters(model, seed=2)
+    from temporal_latticenet_amd.configs import make_lattice as mk
+    lat = mk(contents)
+    assert abs(lat.scale_constant() - (1.0 if scale_constant == "unit" else scale_constant)) < 1e-12
+    outs = _run(model, contents, seq, gpu)
+    oracle = oracle_from_model(model, contents)
+    assert oracle.scale_constant == (1.0 if scale_constant == "unit" else scale_constant)
+    for t, (pos, val) in enumerate(seq):
+        want = oracle.forward(pos, val, early_return=(t != len(seq) - 1))
+        scale = max(1.0, float(want.abs().max()))
+        err = float((outs[t] - want).abs().max())
+        assert err <= LOGIT_TOL * scale, "frame %d: max abs err %.3e (scale %.2f)" % (t, err, scale)
+    assert oracle.levels[0].table.nr_vertices > 500
+
+
 def test_single_frame_no_sequence_learning(gpu):
     contents = make_config(rnn_modules=("gru", "none", "none", "none"), sequence_learning=False, frames=1, sigma=1.0)
     seq = make_sequence(20000, 1, seed=2)

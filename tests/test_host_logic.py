@@ -172,3 +172,22 @@ def test_ctypes_mirrors_match_the_header_layout(tmp_path):
         assert got[(cname, "size")] == C.sizeof(cls), cname
         for fname, _ in cls._fields_:
             assert got[(cname, fname)] == getattr(cls, fname).offset, "%s.%s" % (cname, fname)
+
+
+def test_lattice_scale_constant_cfg_values():
+    """lattice_gpu.scale_constant (tln_lattice_create_ex): names and numbers; 0.0 is the C ABI's "default" """
+    import pytest
+    from temporal_latticenet_amd._lib import TlnError
+    from temporal_latticenet_amd.configs import make_config
+    from temporal_latticenet_amd.lattice import Lattice
+    f = Lattice.parse_scale_constant
+    assert f(None) == 0.0 and f("adams") == 0.0 and f("") == 0.0
+    assert f("unit") == 1.0 and f(1) == 1.0 and f("1.0") == 1.0 and f(3.25) == 3.25
+    with pytest.raises(TlnError):
+        f(-1.0)
+    with pytest.raises(ValueError):
+        f("adam")
+    assert "scale_constant" not in make_config()["lattice_gpu"]          # the reference's cfg has no such key
+    assert make_config(scale_constant="unit")["lattice_gpu"]["scale_constant"] == "unit"
+    from tests.helpers import _scale_constant
+    assert _scale_constant(None) is None and _scale_constant("unit") == 1.0 and _scale_constant(2) == 2.0

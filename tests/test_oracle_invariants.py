@@ -8,14 +8,18 @@ from oracle import permuto as P
 from temporal_latticenet_amd.synthetic import make_sequence
 
 
-def _keys(pos, sigma):
-    rem0, rank, bary = P.simplex(P.elevate(pos, P.scale_factors([sigma] * 3)))
+import pytest
+
+
+def _keys(pos, sigma, constant=None):
+    rem0, rank, bary = P.simplex(P.elevate(pos, P.scale_factors([sigma] * 3, constant)))
     return P.simplex_keys(rem0, rank), bary, rem0, rank
 
 
-def test_barycentric_weights_are_a_partition_of_unity():
+@pytest.mark.parametrize("constant", [None, 1.0, 2.0])
+def test_barycentric_weights_are_a_partition_of_unity(constant):
     pos = make_sequence(20000, 1, seed=1)[0][0]
-    keys, bary, _, _ = _keys(pos, 0.6)
+    keys, bary, _, _ = _keys(pos, 0.6, constant)
     assert bary[:, :4].min() >= -1e-5
     np.testing.assert_allclose(bary[:, :4].sum(1), 1.0, atol=1e-5)
 

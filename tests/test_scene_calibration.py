@@ -9,8 +9,8 @@ from oracle import permuto as P
 from temporal_latticenet_amd.synthetic import make_sequence
 
 
-def _vertices(pos, sigma):
-    rem0, rank, _ = P.simplex(P.elevate(pos, P.scale_factors([sigma] * 3)))
+def _vertices(pos, sigma, constant=None):
+    rem0, rank, _ = P.simplex(P.elevate(pos, P.scale_factors([sigma] * 3, constant)))
     return int(np.unique(P.pack_keys(P.simplex_keys(rem0, rank)).reshape(-1)).size)
 
 
@@ -26,6 +26,20 @@ def test_default_scene_splats_around_10k_vertices_at_sigma_1():
     assert 15000 <= v06 <= 30000, v06
     # the default hash capacity of cfg:71 holds a whole 4-frame sequence at sigma = 0.6
     assert _vertices(np.concatenate([p for p, _ in seq]), 0.6) < 100000
+
+
+def test_the_sizing_hint_decides_between_the_two_scale_constants():
+    """The lattice scale constant is a parameter (lattice_gpu.scale_constant, tln_lattice_create_ex); what this build
+    can say about its two candidate values WITHOUT upstream's source: on the calibrated street scene cfg:71's "around
+    10k [vertices] with sigma of 1" is met by Adams' (d+1) sqrt(2/3) and missed by an order of magnitude by 1.0.  Not a
+    proof (the scene is synthetic): DESIGN.md section 3.1 says so, and a checkpoint trained against the other constant
+    only needs the cfg key."""
+    pos = make_sequence(120000, 1)[0][0]
+    adams, unit = _vertices(pos, 1.0, None), _vertices(pos, 1.0, 1.0)
+    assert adams == _vertices(pos, 1.0, P.default_scale_constant())
+    assert 8000 <= adams <= 12000 and unit < 2000, (adams, unit)
+    # the same lattice under either name: sigma' = sigma / c_ratio
+    assert _vertices(pos, 1.0 / P.default_scale_constant(), 1.0) == adams
 
 
 def test_scene_is_kitti_shaped():
