@@ -43,6 +43,8 @@ double tln_lattice_scale_constant(const tln_lattice_t* l);
 int tln_lattice_destroy(tln_lattice_t* l);
 /* reset_hashmap=True of DistributeLatticeModule (models.py:287-298): clears every level */
 int tln_lattice_clear(tln_lattice_t* l, void* stream);
+/* the same for n lattices (lock-stepped sequences), as few launches as their levels allow */
+int tln_lattice_clear_multi(tln_lattice_t* const* l, int n, void* stream);
 int64_t tln_lattice_nr_vertices(const tln_lattice_t* l);      /* Lattice.nr_lattice_vertices(), train_ln.py:220 */
 int64_t tln_lattice_capacity(const tln_lattice_t* l);
 int tln_lattice_level(const tln_lattice_t* l);
@@ -70,6 +72,21 @@ int tln_distribute_begin(tln_lattice_t* l, const float* d_positions, const float
                    int val_dim, int subtract_mean, float* d_distributed, int32_t* d_indices,
                    float* d_weights, void* stream);
 int tln_distribute_finish(tln_lattice_t* l, void* stream);
+/* the first halves of the distributes of n lock-stepped sequences (n different lattices, one stream) as ONE batch: the
+ * four K1 kernels take the frames of up to eight lattices in one launch each (blockIdx.y = frame).  Every lattice is
+ * then finished by its own tln_distribute_finish.  Same results as n tln_distribute_begin calls, bit for bit. */
+typedef struct {
+  tln_lattice_t* l;
+  const float* d_positions;
+  const float* d_values;
+  int64_t n;
+  int val_dim;
+  int subtract_mean;
+  float* d_distributed;
+  int32_t* d_indices;
+  float* d_weights;
+} tln_distribute_call;
+int tln_distribute_begin_multi(const tln_distribute_call* calls, int n, void* stream);
 
 /* forget the bins of the last distribute (the caller edited d_distributed in place): the next pool goes through a CSR */
 int tln_lattice_drop_bins(tln_lattice_t* l);
@@ -399,6 +416,13 @@ int tln_program_begin_frame(tln_program_t* p, tln_lattice_t* l, const float* d_p
 int tln_program_begin_frame_start(tln_program_t* p, tln_lattice_t* l, const float* d_positions, const float* d_values,
                                   int64_t n, int val_dim, int reset_hashmap, int subtract_mean, void* stream);
 int tln_program_begin_frame_finish(tln_program_t* p, int64_t* v_out, void* stream);
+/* the frames of `count` (1..8) lock-stepped sequences begun together: one batch of K1 launches for all of them
+ * (tln_distribute_begin_multi), one wait for the vertex counters; v_out is [count][TLN_MAX_LEVELS].  With stage timing
+ * on, programs[0] holds the events around the batched stages (tln_program_timing_read: duration of the batch). */
+int tln_program_begin_frame_group(tln_program_t* const* programs, tln_lattice_t* const* lattices,
+                                  const float* const* d_positions, const float* const* d_values, const int64_t* n,
+                                  int count, int val_dim, int reset_hashmap, int subtract_mean, int64_t* v_out,
+                                  void* stream);
 /* the rest of the frame.  early != 0: stop at the program's STOP_IF_EARLY op and copy that slot to d_out;
  * else the TLN_SLOT_OUT slot is d_out.  d_out must hold out_rows x out_cols floats (checked). */
 int tln_program_run(tln_program_t* p, int early, float* d_out, int64_t out_rows, int out_cols, void* stream);

@@ -40,6 +40,13 @@ class GnDesc(C.Structure):
     ]
 
 
+class DistributeCall(C.Structure):
+    """tln_distribute_call"""
+    _fields_ = [("l", C.c_void_p), ("d_positions", C.c_void_p), ("d_values", C.c_void_p), ("n", C.c_int64),
+                ("val_dim", C.c_int), ("subtract_mean", C.c_int), ("d_distributed", C.c_void_p),
+                ("d_indices", C.c_void_p), ("d_weights", C.c_void_p)]
+
+
 class Slot(C.Structure):
     """tln_slot"""
     _fields_ = [("rows", C.c_int), ("cols", C.c_int), ("kind", C.c_int), ("state", C.c_int)]
@@ -70,6 +77,9 @@ _PROTOS = {
     "tln_lattice_scale_constant": (C.c_double, [_vp]),
     "tln_lattice_destroy": (_i, [_vp]),
     "tln_lattice_clear": (_i, [_vp, _vp]),
+    "tln_lattice_clear_multi": (_i, [_vp, _i, _vp]),
+    "tln_distribute_begin_multi": (_i, [_vp, _i, _vp]),
+    "tln_program_begin_frame_group": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "tln_lattice_nr_vertices": (_i64, [_vp]),
     "tln_lattice_capacity": (_i64, [_vp]),
     "tln_lattice_level": (_i, [_vp]),

@@ -58,10 +58,7 @@ struct __attribute__((aligned(16))) TlnSlot {
 #define TLN_BK_MAXB 8192
 #define TLN_BK_MAX_PPB 4096   // points of a split block at most
 #define TLN_BK_SPLIT_BLOCKS TLN_BK_THREADS   // at most this many split blocks (columns of the bucket-offset table)
-struct __attribute__((aligned(16))) TlnRec {
-  float4 a;   // x, y, z, value
-  uint4 b;    // barycentric weight (bits), row id, then the packed key (lo, hi) -> (LDS hash entry, rank inside the vertex)
-};
+// (the row record is a uint4: barycentric weight bits, row id, packed key lo / hi)
 
 struct tln_lattice {
   int pos_dim = 3, level = 0;
@@ -91,6 +88,7 @@ struct tln_lattice {
   hipEvent_t levels_event = nullptr;
   // tln_distribute_begin .. _finish: the counter fetch in flight and what the second half needs
   hipEvent_t ctr_event = nullptr;
+  hipEvent_t ctr_wait = nullptr;   // a batched first half: the event of the batch's first lattice (borrowed)
   bool dist_pending = false;
   const float* dist_pos = nullptr;
   float* dist_out = nullptr;
@@ -124,7 +122,7 @@ struct tln_lattice {
   struct TlnBinRec* bin_rec = nullptr;   // [rows_cap] {position, value | barycentric weight, row id, vertex (-1: none), 0}
   int64_t bins_rows = -1;         // rows of the frame the bins hold (-1: none)
   // ---- partitioned K1 (k_bk_*): the rows of a frame split by key hash into buckets, one workgroup per bucket
-  struct TlnRec* rec = nullptr;   // [rec_cap] 32-byte row records, grouped by (split block, bucket)
+  uint4* rec = nullptr;           // [rec_cap] 16-byte row records {weight, row, key}, grouped by (split block, bucket)
   int64_t rec_cap = 0;
   uint32_t* bk_off = nullptr;     // [bk_maxb + 1][split blocks] first record of a bucket inside a split block's region
   int bk_maxb = 0;
@@ -217,7 +215,7 @@ static int ensure_rows(tln_lattice* l, int64_t rows) {
     // of every split block, the first-touch flags (zero between frames) and the bucket directories
     l->rec_cap = cap + cap / 128 + 4 * TLN_BK_MAX_PPB;
     l->bk_maxb = (int)(cap / 128 < TLN_BK_MINB ? TLN_BK_MINB : (cap / 128 > TLN_BK_MAXB ? TLN_BK_MAXB : cap / 128));
-    TLN_HIP(hipMalloc(&l->rec, (size_t)l->rec_cap * sizeof(TlnRec)));
+    TLN_HIP(hipMalloc(&l->rec, (size_t)l->rec_cap * sizeof(uint4)));
     TLN_HIP(hipMalloc(&l->bk_off, (size_t)TLN_BK_SPLIT_BLOCKS * (l->bk_maxb + 1) * sizeof(uint32_t)));
     TLN_HIP(hipMalloc(&l->first_flag, cap * sizeof(uint32_t)));
     TLN_HIP(hipMemset(l->first_flag, 0, cap * sizeof(uint32_t)));
@@ -277,13 +275,14 @@ static int lattice_alloc(tln_lattice** out, int pos_dim, const double* sigmas, i
 }
 
 // every level of a lattice emptied by ONE launch (slot tables to 0xFF.., counters to 0) instead of four memsets each
+#define TLN_CLEAR_JOBS 24
 struct ClearJobs {
   struct {
     TlnSlot* slots;
     uint32_t* cnt;   // per-slot row counts (level 0), may be NULL
     int32_t* ctr;
     int64_t nslots;
-  } j[4];
+  } j[TLN_CLEAR_JOBS];
   int n;
 };
 __global__ void __launch_bounds__(256) k_clear_levels(ClearJobs jobs) {
@@ -303,36 +302,44 @@ __global__ void __launch_bounds__(256) k_clear_levels(ClearJobs jobs) {
   }
 }
 
-extern "C" int tln_lattice_clear(tln_lattice_t* l, void* stream_) {
+// clears the level stacks of n lattices: one launch per TLN_CLEAR_JOBS levels (8 sequences x 3 levels = one launch)
+extern "C" int tln_lattice_clear_multi(tln_lattice_t* const* ll, int n, void* stream_) {
+  TLN_REQUIRE(ll && n >= 1, "null argument");
   hipStream_t s = (hipStream_t)stream_;
-  if (l->levels_pending) {  // a fetch of coarse counters is in flight: let it land before the counters are reset
-    if (l->levels_pending > 0 && l->levels_event) TLN_HIP(hipEventSynchronize(l->levels_event));
-    l->levels_pending = 0;
-  }
   ClearJobs jobs{};
-  for (tln_lattice* p = l; p; p = p->coarse) {
-    if (jobs.n == 4) {  // deeper chains than the kernel takes at once
-      hipLaunchKernelGGL(k_clear_levels, dim3(2048), dim3(256), 0, s, jobs);
-      jobs.n = 0;
+  for (int i = 0; i < n; ++i) {
+    tln_lattice* l = ll[i];
+    TLN_REQUIRE(l, "null lattice");
+    if (l->levels_pending) {  // a fetch of coarse counters is in flight: let it land before the counters are reset
+      if (l->levels_pending > 0 && l->levels_event) TLN_HIP(hipEventSynchronize(l->levels_event));
+      l->levels_pending = 0;
     }
-    jobs.j[jobs.n].slots = p->slots;
-    jobs.j[jobs.n].cnt = p->slot_cnt;
-    jobs.j[jobs.n].ctr = p->d_ctr;
-    jobs.j[jobs.n].nslots = p->nslots;
-    ++jobs.n;
-    p->nr_vertices = 0;
-    p->overflow_rows = 0;
-    p->occupied = 0;
-    ++p->gen;
-    p->bins_rows = -1;
-    p->overflow_stale = false;
-    p->embedded_fine = 0;
-    p->csr_rows = -1;
+    for (tln_lattice* p = l; p; p = p->coarse) {
+      if (jobs.n == TLN_CLEAR_JOBS) {
+        hipLaunchKernelGGL(k_clear_levels, dim3(2048), dim3(256), 0, s, jobs);
+        jobs.n = 0;
+      }
+      jobs.j[jobs.n].slots = p->slots;
+      jobs.j[jobs.n].cnt = p->slot_cnt;
+      jobs.j[jobs.n].ctr = p->d_ctr;
+      jobs.j[jobs.n].nslots = p->nslots;
+      ++jobs.n;
+      p->nr_vertices = 0;
+      p->overflow_rows = 0;
+      p->occupied = 0;
+      ++p->gen;
+      p->bins_rows = -1;
+      p->overflow_stale = false;
+      p->embedded_fine = 0;
+      p->csr_rows = -1;
+    }
   }
   if (jobs.n) hipLaunchKernelGGL(k_clear_levels, dim3(2048), dim3(256), 0, s, jobs);
   TLN_LAUNCH_CHECK();
   return TLN_OK;
 }
+
+extern "C" int tln_lattice_clear(tln_lattice_t* l, void* stream_) { return tln_lattice_clear_multi(&l, 1, stream_); }
 
 extern "C" double tln_lattice_default_scale_constant(void) { return 4.0 * sqrt(2.0 / 3.0); }
 
@@ -1554,23 +1561,65 @@ __device__ __forceinline__ uint32_t bk_block_scan(uint32_t v, uint32_t* wtmp /* 
   return pre + incl - v;
 }
 
-__global__ void __launch_bounds__(1024) k_bk_split(const float* __restrict__ pos, const float* __restrict__ val, int64_t n,
-                                                  int val_dim, float s0, float s1, float s2, int ppb, int B,
-                                                  TlnRec* __restrict__ rec, uint32_t* __restrict__ off,
-                                                  float* __restrict__ weights, float* __restrict__ dist,
-                                                  uint64_t slot_mask, int shift, int nr_words,
-                                                  uint32_t* __restrict__ first_bits, int32_t* __restrict__ ctr) {
+// One frame of one lattice as the four kernels see it.  The kernels take up to TLN_BK_MAXJOBS of them (blockIdx.y = job):
+// a host that steps several sequences in lock-step (the frame program's group mode, bench.py's timed mode) distributes
+// the frames of all of them with FOUR launches instead of four per frame — every one of these kernels is a chain of
+// dependent memory round trips (~4.5 us from launch to the first loaded byte), and a 120k-point frame alone does not
+// fill the chip (117 split blocks; the buckets of one frame in one round of workgroups).
+#define TLN_BK_MAXJOBS 8
+struct BkJob {
+  const float* pos;
+  const float* val;
+  float* weights;
+  float* dist;
+  uint4* rec;                // 16-byte row records {weight bits, row, key lo, key hi}, grouped by (split block, bucket)
+  uint32_t* off;
+  uint32_t* first_bits;
+  uint32_t* bucket_rows;
+  uint32_t* bits_pre;
+  int32_t* ctr;
+  int32_t* host_ctr;
+  int32_t* vstart;
+  int32_t* vcnt;
+  int32_t* vstamp;
+  int32_t* indices;
+  int32_t* vkeys;
+  int32_t* vslot;
+  float* mean;
+  TlnBinRec* bin_rec;
+  TableRef t;
+  uint64_t slot_mask;
+  int64_t n, rows, rpb;
+  float s0, s1, s2;
+  int val_dim, ppb, B, nblk, shift, nr_words, vold, capacity, stamp;
+};
+struct BkJobs {
+  BkJob j[TLN_BK_MAXJOBS];
+};
+
+__global__ void __launch_bounds__(1024) k_bk_split(const BkJobs jobs) {
+  const BkJob& J = jobs.j[blockIdx.y];
+  const int nblk = J.nblk;
+  if ((int)blockIdx.x >= nblk) return;   // (the grid is sized for the job with the most split blocks)
   extern __shared__ uint32_t bk_hist[];   // [B] bucket counts of this block, then the write cursors
   __shared__ uint32_t wtmp[16];
   const int tid = threadIdx.x, T = blockDim.x;   // T: 256, 512 or 1024 (a power of two, as B)
-  const int nblk = gridDim.x;
+  const int B = J.B, ppb = J.ppb, val_dim = J.val_dim;
+  const float* __restrict__ pos = J.pos;
+  const float* __restrict__ val = J.val;
+  const float s0 = J.s0, s1 = J.s1, s2 = J.s2;
+  const uint64_t slot_mask = J.slot_mask;
+  const int shift = J.shift;
+  const int64_t n = J.n;
   // what k_bk_insert accumulates into: the bit mask of the first-touch rows, their number
-  for (int i = blockIdx.x * T + tid; i < nr_words; i += nblk * T) first_bits[i] = 0u;
-  if (blockIdx.x == 0 && tid == 0) ctr[CTR_OVERFLOW] = 0;   // accumulated by k_bk_place
+  for (int i = blockIdx.x * T + tid; i < J.nr_words; i += nblk * T) J.first_bits[i] = 0u;
+  if (blockIdx.x == 0 && tid == 0) J.ctr[CTR_OVERFLOW] = 0;   // accumulated by k_bk_place
   for (int i = tid; i < B; i += T) bk_hist[i] = 0;
   __syncthreads();
   const int64_t p0 = (int64_t)blockIdx.x * ppb;
   const int64_t p1 = p0 + ppb < n ? p0 + ppb : n;
+  float* __restrict__ weights = J.weights;
+  float* __restrict__ dist = J.dist;
   for (int64_t p = p0 + tid; p < p1; p += T) {
     const float x = pos[3 * p], y = pos[3 * p + 1], z = pos[3 * p + 2];
     int rem0[4], rank[4];
@@ -1601,6 +1650,7 @@ __global__ void __launch_bounds__(1024) k_bk_split(const float* __restrict__ pos
   __syncthreads();
   // exclusive scan of the B counts: a thread owns B/T consecutive buckets (one, for B < T).  off is bucket-major ([B + 1][nblk]) so that
   // a bucket's workgroup reads its runs with contiguous loads.
+  uint32_t* __restrict__ off = J.off;
   const int per = B >= T ? B / T : (tid < B ? 1 : 0);
   uint32_t mine = 0;
   for (int k = 0; k < per; ++k) mine += bk_hist[tid * per + k];
@@ -1614,21 +1664,21 @@ __global__ void __launch_bounds__(1024) k_bk_split(const float* __restrict__ pos
   }
   if (tid == 0) off[(size_t)B * nblk + blockIdx.x] = total;
   __syncthreads();
-  TlnRec* region = rec + (size_t)blockIdx.x * (4 * (size_t)ppb);
+  // the 16-byte records: weight, row, key.  The position / value of a row are re-read by k_bk_place from the frame's
+  // own arrays (1.9 MB, cache resident) — carrying them along made the record 32 bytes, written once and pulled twice
+  uint4* region = J.rec + (size_t)blockIdx.x * (4 * (size_t)ppb);
   for (int64_t p = p0 + tid; p < p1; p += T) {
     const float x = pos[3 * p], y = pos[3 * p + 1], z = pos[3 * p + 2];
     int rem0[4], rank[4];
     float bary[4];
     point_simplex(x, y, z, s0, s1, s2, rem0, rank, bary);
-    const float4 a = make_float4(x, y, z, val_dim ? val[p] : 0.0f);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       int k0, k1, k2;
       vertex_key(rem0, rank, r, k0, k1, k2);
       const uint64_t K = tln_key_in_range(k0, k1, k2) ? tln_pack_key(k0, k1, k2) : TLN_KEY_EMPTY;
       const uint32_t at = atomicAdd(&bk_hist[bk_bucket(K, slot_mask, shift)], 1u);
-      region[at].a = a;
-      region[at].b = make_uint4(__float_as_uint(bary[r]), (uint32_t)(4 * p + r), (uint32_t)K, (uint32_t)(K >> 32));
+      region[at] = make_uint4(__float_as_uint(bary[r]), (uint32_t)(4 * p + r), (uint32_t)K, (uint32_t)(K >> 32));
     }
   }
 }
@@ -1665,10 +1715,10 @@ __device__ __forceinline__ int bk_lds_find(const unsigned long long* hk, uint64_
                     // threads of a run share it; with three k_bk_place needed 84 VGPRs: three workgroups per CU, and a
                     // frame's 1024 buckets ran in two rounds)
 struct BkRuns {
-  const TlnRec* at;
+  const uint4* at;
   int total, step;
 };
-__device__ __forceinline__ void bk_runs_of(const uint32_t* __restrict__ off, const TlnRec* __restrict__ rec, int nblk,
+__device__ __forceinline__ void bk_runs_of(const uint32_t* __restrict__ off, const uint4* __restrict__ rec, int nblk,
                                            int64_t rpb, int b, BkRuns& rn) {
   int sh = 0;
   while ((nblk << (sh + 1)) <= TLN_BK_THREADS) ++sh;
@@ -1683,30 +1733,30 @@ __device__ __forceinline__ void bk_runs_of(const uint32_t* __restrict__ off, con
   rn.step = 1 << sh;
   rn.total = len > q ? (len - q + rn.step - 1) >> sh : 0;
 }
-__device__ __forceinline__ const TlnRec* bk_rec_of(const BkRuns& rn, int k) { return rn.at + k * rn.step; }
+__device__ __forceinline__ const uint4* bk_rec_of(const BkRuns& rn, int k) { return rn.at + k * rn.step; }
 
-__global__ void __launch_bounds__(TLN_BK_THREADS) k_bk_insert(const TlnRec* __restrict__ rec, const uint32_t* __restrict__ off,
-                                                              int nblk, int64_t rpb, TableRef t,
-                                                              uint32_t* __restrict__ first_bits,
-                                                              uint32_t* __restrict__ bucket_rows) {
+__global__ void __launch_bounds__(TLN_BK_THREADS) k_bk_insert(const BkJobs jobs) {
+  const BkJob& J = jobs.j[blockIdx.y];
+  if ((int)blockIdx.x >= J.B) return;
   __shared__ unsigned long long hk[TLN_BK_HT];
   __shared__ uint32_t htouch[TLN_BK_HT];
   __shared__ uint32_t claimed[TLN_BK_HT];   // slots this workgroup has taken in this launch (open addressing, 0 = free)
   __shared__ uint32_t wtmp[16];
   const int tid = threadIdx.x, b = blockIdx.x;
+  const TableRef t = J.t;
   for (int i = tid; i < TLN_BK_HT; i += TLN_BK_THREADS) {
     hk[i] = TLN_KEY_EMPTY;
     htouch[i] = 0xFFFFFFFFu;
     claimed[i] = 0u;
   }
-  // the thread's run (~4 rows): every offset load is issued before the first record load, every
+  // the thread's run: every offset load is issued before the first record load, every
   // record load before the first LDS operation — the kernel is a chain of dependent memory round trips otherwise
   BkRuns rn;
-  bk_runs_of(off, rec, nblk, rpb, b, rn);
+  bk_runs_of(J.off, J.rec, J.nblk, J.rpb, b, rn);
   uint4 kb[BK_KEEP];
 #pragma unroll
   for (int k = 0; k < BK_KEEP; ++k)
-    if (k < rn.total) kb[k] = bk_rec_of(rn, k)->b;
+    if (k < rn.total) kb[k] = *bk_rec_of(rn, k);
   __syncthreads();
   auto touch_row = [&](const uint4& bb) {
     const uint64_t K = ((uint64_t)bb.w << 32) | bb.z;
@@ -1718,11 +1768,12 @@ __global__ void __launch_bounds__(TLN_BK_THREADS) k_bk_insert(const TlnRec* __re
 #pragma unroll
   for (int k = 0; k < BK_KEEP; ++k)
     if (k < rn.total) touch_row(kb[k]);
-  for (int k = BK_KEEP; k < rn.total; ++k) touch_row(bk_rec_of(rn, k)->b);
+  for (int k = BK_KEEP; k < rn.total; ++k) touch_row(*bk_rec_of(rn, k));
   const uint32_t nrows = (uint32_t)rn.total;
   uint32_t R;
   bk_block_scan(nrows, wtmp, &R);   // (barriers: the table is complete behind it)
-  if (tid == 0) bucket_rows[b] = R;
+  if (tid == 0) J.bucket_rows[b] = R;
+  uint32_t* __restrict__ first_bits = J.first_bits;
   // The distinct keys of the bucket, one global probe each.  Only this workgroup writes the bucket's slot range in
   // this launch, so a key is entered with ONE plain 16-byte store; two of its threads heading for the same empty
   // slot settle it in LDS (`claimed`), the loser moves on along its group.
@@ -1780,18 +1831,18 @@ __global__ void __launch_bounds__(TLN_BK_THREADS) k_bk_insert(const TlnRec* __re
 }
 
 // The first-touch rows of the frame as a bit mask -> for every uint4 of the mask the number of set bits before it (one
-// workgroup: 15k words on a 120k-point frame), and the counters the host fetches while k_bk_place runs.  A key's
-// vertex index is then: vertices before the frame + set bits before its own first-touch row (what a scan over the rows
-// in order would hand out).  The occupancy count takes every key without a vertex as newly entered: keys turned away by
-// the capacity in an earlier frame count again, which only brings the next table rebuild (exact again) forward.
-__global__ void __launch_bounds__(TLN_BK_THREADS) k_bk_prefix(const uint32_t* __restrict__ first_bits, int nr_words,
-                                                              uint32_t* __restrict__ bits_pre, int32_t* __restrict__ ctr,
-                                                              int vold, int capacity, int32_t* __restrict__ host_ctr) {
+// workgroup per frame: 15k words on a 120k-point frame), and the counters the host fetches while k_bk_place runs.  A
+// key's vertex index is then: vertices before the frame + set bits before its own first-touch row (what a scan over the
+// rows in order would hand out).  The occupancy count takes every key without a vertex as newly entered: keys turned
+// away by the capacity in an earlier frame count again, which only brings the next table rebuild (exact again) forward.
+__global__ void __launch_bounds__(TLN_BK_THREADS) k_bk_prefix(const BkJobs jobs) {
+  const BkJob& J = jobs.j[blockIdx.y];
   __shared__ uint32_t wtmp[16];
   // a thread owns `per` consecutive uint4s of the mask: one pass over them for the sum, one block scan, one pass to write
-  const int nq = nr_words >> 2;
+  const int nq = J.nr_words >> 2;
   const int per = (nq + TLN_BK_THREADS - 1) / TLN_BK_THREADS;
-  const uint4* q4 = reinterpret_cast<const uint4*>(first_bits);
+  const uint4* q4 = reinterpret_cast<const uint4*>(J.first_bits);
+  uint32_t* __restrict__ bits_pre = J.bits_pre;
   const int i0 = threadIdx.x * per, i1 = i0 + per < nq ? i0 + per : nq;
   uint32_t mine = 0;
   for (int i = i0; i < i1; ++i) {
@@ -1806,24 +1857,20 @@ __global__ void __launch_bounds__(TLN_BK_THREADS) k_bk_prefix(const uint32_t* __
     run += (uint32_t)(__popc(q.x) + __popc(q.y) + __popc(q.z) + __popc(q.w));
   }
   if (threadIdx.x == 0) {
-    const long long vnew = (long long)vold + carry;
-    ctr[CTR_VOLD] = vold;
+    int32_t* ctr = J.ctr;
+    const long long vnew = (long long)J.vold + carry;
+    ctr[CTR_VOLD] = J.vold;
     ctr[CTR_NEW] = (int)carry;
-    ctr[CTR_NV] = (int)(vnew < capacity ? vnew : capacity);
+    ctr[CTR_NV] = (int)(vnew < J.capacity ? vnew : J.capacity);
     ctr[CTR_OCCUPIED] += (int)carry;
     // the host's copy (pinned, mapped): written from here instead of a copy kernel between this launch and k_bk_place
-    for (int i = 0; i < CTR_COUNT; ++i) host_ctr[i] = ctr[i];
+    for (int i = 0; i < CTR_COUNT; ++i) J.host_ctr[i] = ctr[i];
   }
 }
 
-__global__ void __launch_bounds__(TLN_BK_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) k_bk_place(const TlnRec* __restrict__ rec, const uint32_t* __restrict__ off, int nblk,
-                                                  int B, int64_t rpb, TableRef t, const uint32_t* __restrict__ bucket_rows,
-                                                  int64_t rows, int32_t* __restrict__ vstart, int32_t* __restrict__ vcnt,
-                                                  int32_t* __restrict__ vstamp, int stamp, float* __restrict__ mean,
-                                                  int32_t* __restrict__ indices, TlnBinRec* __restrict__ bin_rec,
-                                                  const uint32_t* __restrict__ first_bits,
-                                                  const uint32_t* __restrict__ bits_pre, int vold, int capacity,
-                                                  int32_t* __restrict__ vkeys, int32_t* __restrict__ vslot) {
+__global__ void __launch_bounds__(TLN_BK_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) k_bk_place(const BkJobs jobs) {
+  const BkJob& J = jobs.j[blockIdx.y];
+  if ((int)blockIdx.x >= J.B) return;
   __shared__ unsigned long long hk[TLN_BK_HT];
   __shared__ uint32_t hcnt[TLN_BK_HT];                 // rows per entry, then the entry's write cursor
   extern __shared__ unsigned long long bk_dyn[];       // (dynamic: the block needs more than 64 KB of LDS in all)
@@ -1833,29 +1880,36 @@ __global__ void __launch_bounds__(TLN_BK_THREADS) __attribute__((amdgpu_waves_pe
   __shared__ uint32_t wtmp[16];
   __shared__ uint32_t s_tail;
   const int tid = threadIdx.x, b = blockIdx.x;
+  const TableRef t = J.t;
+  const float* __restrict__ pos = J.pos;
+  const float* __restrict__ val = J.val_dim ? J.val : nullptr;
   for (int i = tid; i < TLN_BK_HT; i += TLN_BK_THREADS) {
     hk[i] = TLN_KEY_EMPTY;
     hcnt[i] = 0;
     hsum[0][i] = hsum[1][i] = hsum[2][i] = 0ull;
   }
   if (tid == 0) s_tail = 0;
-  // the thread's rows (bk_runs_of: offsets first, then every record, then the LDS work) and, meanwhile, the bins of this
-  // bucket: behind the rows of all buckets before it
+  // the thread's rows (bk_runs_of: offsets first, then every record, then the rows' positions, then the LDS work) and,
+  // meanwhile, the bins of this bucket: behind the rows of all buckets before it
   BkRuns rn;
-  bk_runs_of(off, rec, nblk, rpb, b, rn);
+  bk_runs_of(J.off, J.rec, J.nblk, J.rpb, b, rn);
   uint32_t before = 0;
-  for (int i = tid; i < b; i += TLN_BK_THREADS) before += bucket_rows[i];
+  for (int i = tid; i < b; i += TLN_BK_THREADS) before += J.bucket_rows[i];
   float4 ka[BK_KEEP];
   uint4 kb[BK_KEEP];
 #pragma unroll
   for (int k = 0; k < BK_KEEP; ++k)
-    if (k < rn.total) {
-      ka[k] = bk_rec_of(rn, k)->a;
-      kb[k] = bk_rec_of(rn, k)->b;
-    }
+    if (k < rn.total) kb[k] = *bk_rec_of(rn, k);
+  auto payload = [&](uint32_t row) {
+    const uint32_t p = row >> 2;
+    return make_float4(pos[3 * p], pos[3 * p + 1], pos[3 * p + 2], val ? val[p] : 0.0f);
+  };
+#pragma unroll
+  for (int k = 0; k < BK_KEEP; ++k)
+    if (k < rn.total) ka[k] = payload(kb[k].y);
   uint32_t bin0;
   bk_block_scan(before, wtmp, &bin0);   // (barriers: the table is initialised behind it)
-  const uint32_t R = bucket_rows[b];
+  const uint32_t R = J.bucket_rows[b];
   // sweep 1: rows per key, position sums
   auto count_row = [&](const float4& a, const uint4& bb) {
     const uint64_t K = ((uint64_t)bb.w << 32) | bb.z;
@@ -1870,9 +1924,16 @@ __global__ void __launch_bounds__(TLN_BK_THREADS) __attribute__((amdgpu_waves_pe
 #pragma unroll
   for (int k = 0; k < BK_KEEP; ++k)
     if (k < rn.total) count_row(ka[k], kb[k]);
-  for (int k = BK_KEEP; k < rn.total; ++k) count_row(bk_rec_of(rn, k)->a, bk_rec_of(rn, k)->b);
+  for (int k = BK_KEEP; k < rn.total; ++k) {
+    const uint4 bb = *bk_rec_of(rn, k);
+    count_row(payload(bb.y), bb);
+  }
   __syncthreads();
   // the distinct keys: vertex (one global lookup), segment
+  const uint32_t* __restrict__ first_bits = J.first_bits;
+  const uint32_t* __restrict__ bits_pre = J.bits_pre;
+  const int vold = J.vold, capacity = J.capacity;
+  float* __restrict__ mean = J.mean;
   constexpr int EPT = TLN_BK_HT / TLN_BK_THREADS;
   int v[EPT];
   uint32_t c[EPT];
@@ -1913,10 +1974,10 @@ __global__ void __launch_bounds__(TLN_BK_THREADS) __attribute__((amdgpu_waves_pe
         if (vn < capacity) {
           v[k] = (int)vn;
           t.slots[slot].val = v[k];
-          vslot[vn] = (int32_t)slot;
+          J.vslot[vn] = (int32_t)slot;
           int k0, k1, k2;
           tln_unpack_key(K, k0, k1, k2);
-          *reinterpret_cast<int4*>(vkeys + 4 * vn) = make_int4(k0, k1, k2, -(k0 + k1 + k2));
+          *reinterpret_cast<int4*>(J.vkeys + 4 * vn) = make_int4(k0, k1, k2, -(k0 + k1 + k2));
         } else {
           t.slots[slot].touch = 0xFFFFFFFFu;  // stays un-numbered; may be retried by a later insertion
         }
@@ -1943,14 +2004,16 @@ __global__ void __launch_bounds__(TLN_BK_THREADS) __attribute__((amdgpu_waves_pe
     hstart[e] = (int)(bin0 + st);
     if (v[k] >= 0) {
       const int vv = v[k];
-      vstart[vv] = (int)(bin0 + st);
-      vcnt[vv] = (int)c[k];
-      vstamp[vv] = stamp;
+      J.vstart[vv] = (int)(bin0 + st);
+      J.vcnt[vv] = (int)c[k];
+      J.vstamp[vv] = J.stamp;
       st += c[k];
     }
   }
   __syncthreads();
   // sweep 2: the rows move to their segments (any order inside), rows without a vertex behind the bucket's segments
+  TlnBinRec* __restrict__ bin_rec = J.bin_rec;
+  int32_t* __restrict__ indices = J.indices;
   auto place_row = [&](const float4& a, const uint4& bb) {
     const uint64_t K = ((uint64_t)bb.w << 32) | bb.z;
     int he = -1, vv = -1;
@@ -1966,7 +2029,10 @@ __global__ void __launch_bounds__(TLN_BK_THREADS) __attribute__((amdgpu_waves_pe
 #pragma unroll
   for (int k = 0; k < BK_KEEP; ++k)
     if (k < rn.total) place_row(ka[k], kb[k]);
-  for (int k = BK_KEEP; k < rn.total; ++k) place_row(bk_rec_of(rn, k)->a, bk_rec_of(rn, k)->b);
+  for (int k = BK_KEEP; k < rn.total; ++k) {
+    const uint4 bb = *bk_rec_of(rn, k);
+    place_row(payload(bb.y), bb);
+  }
   __syncthreads();
 }
 
@@ -2011,20 +2077,13 @@ extern "C" int tln_distribute_config(int legacy) {
   return TLN_OK;
 }
 
-// first half: hash insertion, numbering, the bins; the vertex counters start their way to the host.  d_distributed may be NULL: the [4N, 3+val_dim+1] rows are then not produced
-// (the pool of the same frame reads the bins).
-extern "C" int tln_distribute_begin(tln_lattice_t* l, const float* d_positions, const float* d_values, int64_t n,
-                                    int val_dim, int subtract_mean, float* d_distributed, int32_t* d_indices,
-                                    float* d_weights, void* stream_) {
-  TLN_REQUIRE(l && d_positions && d_indices && d_weights, "null argument");
-  TLN_REQUIRE(l->level == 0, "distribute works on the finest level");
-  TLN_REQUIRE(n > 0 && 4 * n < (1ll << 31), "nr of points %lld out of range", (long long)n);
-  TLN_REQUIRE(val_dim >= 0 && val_dim <= 1024 && (val_dim == 0 || d_values), "bad val_dim %d", val_dim);
-  hipStream_t s = (hipStream_t)stream_;
+// ---- host side of K1 -------------------------------------------------------------------------------------------------
+// what every first half does before its kernels: an abandoned first half settled, workspaces, slot table
+static int distribute_prepare(tln_lattice* l, int64_t n, hipStream_t s) {
   if (l->dist_pending) {
     // an abandoned first half (its caller failed in between): its kernels have numbered vertices on the device, so the
     // host's counts must follow before anything else is inserted
-    TLN_HIP(hipEventSynchronize(l->ctr_event));
+    TLN_HIP(hipEventSynchronize(l->ctr_wait ? l->ctr_wait : l->ctr_event));
     l->dist_pending = false;
     publish_counts(l);
     l->bins_rows = -1;
@@ -2037,52 +2096,139 @@ extern "C" int tln_distribute_begin(tln_lattice_t* l, const float* d_positions, 
   if (rc) return rc;
   l->bins_rows = -1;
   l->csr_rows = -1;
-  TableRef t = table_ref(l);
-  if (k1_partitioned() && val_dim <= 1 && rows <= (int64_t)TLN_BK_MAXB * TLN_BK_ROWS) {
+  return TLN_OK;
+}
+
+static bool bk_eligible(const tln_lattice* l, int64_t n, int val_dim) {
+  return k1_partitioned() && val_dim <= 1 && 4 * n <= (int64_t)TLN_BK_MAXB * TLN_BK_ROWS;
+}
+
+// the bucket geometry of a frame and everything its four kernels address; *split_t = threads of its split blocks
+static int bk_fill_job(tln_lattice* l, const float* d_positions, const float* d_values, int64_t n, int val_dim,
+                       float* d_distributed, int32_t* d_indices, float* d_weights, BkJob& J, int* split_t) {
+  const int64_t rows = 4 * n;
+  static const int env_rows = getenv("TLN_BK_ROWS") ? atoi(getenv("TLN_BK_ROWS")) : 0;   // measurement overrides
+  static const int env_ppb = getenv("TLN_BK_PPB") ? atoi(getenv("TLN_BK_PPB")) : 0;
+  const int bucket_rows = env_rows >= 128 && env_rows <= 8192 ? env_rows : TLN_BK_ROWS;
+  int B = TLN_BK_MINB;
+  while ((int64_t)B * bucket_rows < rows && B < l->bk_maxb) B <<= 1;
+  // points per split block: a block's run inside a bucket is ~ppb / 128 records long, and the longer the runs, the
+  // fewer partly used cache lines the bucket kernels pull; ~100 split blocks are kept at least
+  int64_t ppb = 256;
+  while (ppb < 2048 && n / (2 * ppb) >= 96) ppb *= 2;
+  if (env_ppb >= 256 && env_ppb <= TLN_BK_MAX_PPB) ppb = env_ppb & ~255;
+  if (tln_cdiv(n, ppb) > TLN_BK_SPLIT_BLOCKS) ppb = (tln_cdiv(n, TLN_BK_SPLIT_BLOCKS) + 255) & ~(int64_t)255;
+  static const int env_st = getenv("TLN_BK_SPLIT_T") ? atoi(getenv("TLN_BK_SPLIT_T")) : 0;
+  *split_t = env_st == 256 || env_st == 512 || env_st == 1024 ? env_st : (ppb >= 1024 ? 1024 : (ppb >= 512 ? 512 : 256));
+  const int nblk = (int)tln_cdiv(n, ppb);
+  const int64_t rpb = 4 * ppb;
+  TLN_REQUIRE(B <= l->bk_maxb && (int64_t)nblk * rpb <= l->rec_cap && nblk <= TLN_BK_SPLIT_BLOCKS,
+              "bucket geometry out of range (B %d, %d split blocks)", B, nblk);
+  int slot_bits = 0, b_bits = 0;
+  while ((1ll << slot_bits) < l->nslots) ++slot_bits;
+  while ((1 << b_bits) < B) ++b_bits;
+  TLN_REQUIRE((int64_t)B * TLN_SLOT_GROUP <= l->nslots, "more buckets (%d) than slot groups", B);
+  ++l->bins_stamp;
+  l->bins_stamped = true;
+  J = BkJob{};
+  J.pos = d_positions;
+  J.val = d_values;
+  J.weights = d_weights;
+  J.dist = d_distributed;
+  J.rec = l->rec;
+  J.off = l->bk_off;
+  J.first_bits = l->first_flag;
+  J.bucket_rows = l->bucket_rows;
+  J.bits_pre = l->bits_pre;
+  J.ctr = l->d_ctr;
+  J.host_ctr = l->h_ctr_dev;
+  J.vstart = l->vstart;
+  J.vcnt = l->vcnt;
+  J.vstamp = l->vstamp;
+  J.indices = d_indices;
+  J.vkeys = l->vkeys;
+  J.vslot = l->vslot;
+  J.mean = l->mean;
+  J.bin_rec = l->bin_rec;
+  J.t = table_ref(l);
+  J.slot_mask = J.t.mask;
+  J.n = n;
+  J.rows = rows;
+  J.rpb = rpb;
+  J.s0 = l->scale[0];
+  J.s1 = l->scale[1];
+  J.s2 = l->scale[2];
+  J.val_dim = val_dim;
+  J.ppb = (int)ppb;
+  J.B = B;
+  J.nblk = nblk;
+  J.shift = slot_bits - b_bits;
+  J.nr_words = (int)(tln_cdiv(rows, 128) * 4);   // bit mask of the rows, whole uint4s
+  J.vold = (int)l->nr_vertices;
+  J.capacity = (int)l->capacity;
+  J.stamp = l->bins_stamp;
+  return TLN_OK;
+}
+
+// the four launches for 1..TLN_BK_MAXJOBS frames (blockIdx.y = frame); `ev` is recorded behind k_bk_prefix: the vertex
+// counters of every frame are in the hosts' mapped words by then, k_bk_place runs behind the wait
+static int bk_launch(BkJobs& jobs, int n, int split_t, hipEvent_t ev, hipStream_t s) {
+  int maxblk = 0, maxB = 0;
+  for (int i = 0; i < n; ++i) {
+    if (jobs.j[i].nblk > maxblk) maxblk = jobs.j[i].nblk;
+    if (jobs.j[i].B > maxB) maxB = jobs.j[i].B;
+  }
+  for (int i = n; i < TLN_BK_MAXJOBS; ++i) jobs.j[i] = jobs.j[0];   // (never indexed: the grids have n rows)
+  hipLaunchKernelGGL(k_bk_split, dim3((unsigned)maxblk, (unsigned)n), dim3(split_t), (size_t)maxB * sizeof(uint32_t), s, jobs);
+  hipLaunchKernelGGL(k_bk_insert, dim3((unsigned)maxB, (unsigned)n), dim3(TLN_BK_THREADS), 0, s, jobs);
+  hipLaunchKernelGGL(k_bk_prefix, dim3(1, (unsigned)n), dim3(TLN_BK_THREADS), 0, s, jobs);
+  TLN_LAUNCH_CHECK();
+  TLN_HIP(hipEventRecord(ev, s));
+  const size_t place_lds = (size_t)3 * TLN_BK_HT * sizeof(unsigned long long);
+  static thread_local TlnLdsAttr place_attr;
+  TLN_HIP(tln_set_max_lds(place_attr, reinterpret_cast<const void*>(k_bk_place), (int)place_lds));
+  hipLaunchKernelGGL(k_bk_place, dim3((unsigned)maxB, (unsigned)n), dim3(TLN_BK_THREADS), place_lds, s, jobs);
+  TLN_LAUNCH_CHECK();
+  return TLN_OK;
+}
+
+static void distribute_remember(tln_lattice* l, const float* d_positions, int64_t n, int val_dim, int subtract_mean,
+                                float* d_distributed, const int32_t* d_indices, const float* d_weights) {
+  l->dist_pending = true;
+  l->dist_pos = d_positions;
+  l->dist_out = d_distributed;
+  l->dist_idx = d_indices;
+  l->dist_rows = 4 * n;
+  l->dist_val_dim = val_dim;
+  l->dist_subtract = subtract_mean;
+  l->bins_weights = d_weights;
+}
+
+// first half: hash insertion, numbering, the bins; the vertex counters start their way to the host.  d_distributed may be NULL: the [4N, 3+val_dim+1] rows are then not produced
+// (the pool of the same frame reads the bins).
+extern "C" int tln_distribute_begin(tln_lattice_t* l, const float* d_positions, const float* d_values, int64_t n,
+                                    int val_dim, int subtract_mean, float* d_distributed, int32_t* d_indices,
+                                    float* d_weights, void* stream_) {
+  TLN_REQUIRE(l && d_positions && d_indices && d_weights, "null argument");
+  TLN_REQUIRE(l->level == 0, "distribute works on the finest level");
+  TLN_REQUIRE(n > 0 && 4 * n < (1ll << 31), "nr of points %lld out of range", (long long)n);
+  TLN_REQUIRE(val_dim >= 0 && val_dim <= 1024 && (val_dim == 0 || d_values), "bad val_dim %d", val_dim);
+  hipStream_t s = (hipStream_t)stream_;
+  int rc = distribute_prepare(l, n, s);
+  if (rc) return rc;
+  const int64_t rows = 4 * n;
+  if (!l->ctr_event) TLN_HIP(hipEventCreateWithFlags(&l->ctr_event, hipEventDisableTiming));
+  l->ctr_wait = nullptr;
+  if (bk_eligible(l, n, val_dim)) {
     // partitioned K1 (k_bk_*): four launches, no global atomic per row
-    static const int env_rows = getenv("TLN_BK_ROWS") ? atoi(getenv("TLN_BK_ROWS")) : 0;   // measurement overrides
-    static const int env_ppb = getenv("TLN_BK_PPB") ? atoi(getenv("TLN_BK_PPB")) : 0;
-    const int bucket_rows = env_rows >= 128 && env_rows <= 8192 ? env_rows : TLN_BK_ROWS;
-    int B = TLN_BK_MINB;
-    while ((int64_t)B * bucket_rows < rows && B < l->bk_maxb) B <<= 1;
-    // points per split block: a block's run inside a bucket is ~ppb / 128 records long, and the longer the runs, the
-    // fewer partly used cache lines the bucket kernels pull; ~100 split blocks are kept at least
-    int64_t ppb = 256;
-    while (ppb < 2048 && n / (2 * ppb) >= 96) ppb *= 2;
-    if (env_ppb >= 256 && env_ppb <= TLN_BK_MAX_PPB) ppb = env_ppb & ~255;
-    if (tln_cdiv(n, ppb) > TLN_BK_SPLIT_BLOCKS) ppb = (tln_cdiv(n, TLN_BK_SPLIT_BLOCKS) + 255) & ~(int64_t)255;
-    static const int env_st = getenv("TLN_BK_SPLIT_T") ? atoi(getenv("TLN_BK_SPLIT_T")) : 0;
-    const int split_t = env_st == 256 || env_st == 512 || env_st == 1024 ? env_st : (ppb >= 1024 ? 1024 : (ppb >= 512 ? 512 : 256));
-    const int nblk = (int)tln_cdiv(n, ppb);
-    const int64_t rpb = 4 * ppb;
-    TLN_REQUIRE(B <= l->bk_maxb && (int64_t)nblk * rpb <= l->rec_cap && nblk <= TLN_BK_SPLIT_BLOCKS,
-                "bucket geometry out of range (B %d, %d split blocks)", B, nblk);
-    const int nr_words = (int)(tln_cdiv(rows, 128) * 4);   // bit mask of the rows, whole uint4s
-    int slot_bits = 0, b_bits = 0;
-    while ((1ll << slot_bits) < l->nslots) ++slot_bits;
-    while ((1 << b_bits) < B) ++b_bits;
-    TLN_REQUIRE((int64_t)B * TLN_SLOT_GROUP <= l->nslots, "more buckets (%d) than slot groups", B);
-    hipLaunchKernelGGL(k_bk_split, dim3((unsigned)nblk), dim3(split_t), (size_t)B * sizeof(uint32_t), s, d_positions, d_values, n,
-                       val_dim, l->scale[0], l->scale[1], l->scale[2], (int)ppb, B, l->rec, l->bk_off, d_weights,
-                       d_distributed, t.mask, slot_bits - b_bits, nr_words, l->first_flag, l->d_ctr);
-    hipLaunchKernelGGL(k_bk_insert, dim3((unsigned)B), dim3(TLN_BK_THREADS), 0, s, l->rec, l->bk_off, nblk, rpb, t, l->first_flag,
-                       l->bucket_rows);
-    hipLaunchKernelGGL(k_bk_prefix, dim3(1), dim3(TLN_BK_THREADS), 0, s, l->first_flag, nr_words, l->bits_pre, l->d_ctr,
-                       (int)l->nr_vertices, (int)l->capacity, l->h_ctr_dev);
-    TLN_LAUNCH_CHECK();
-    if (!l->ctr_event) TLN_HIP(hipEventCreateWithFlags(&l->ctr_event, hipEventDisableTiming));
-    TLN_HIP(hipEventRecord(l->ctr_event, s));
-    ++l->bins_stamp;
-    l->bins_stamped = true;
-    const size_t place_lds = (size_t)3 * TLN_BK_HT * sizeof(unsigned long long);
-    static thread_local TlnLdsAttr place_attr;
-    TLN_HIP(tln_set_max_lds(place_attr, reinterpret_cast<const void*>(k_bk_place), (int)place_lds));
-    hipLaunchKernelGGL(k_bk_place, dim3((unsigned)B), dim3(TLN_BK_THREADS), place_lds, s, l->rec, l->bk_off, nblk, B, rpb, t,
-                       l->bucket_rows, rows, l->vstart, l->vcnt, l->vstamp, l->bins_stamp, l->mean, d_indices, l->bin_rec,
-                       l->first_flag, l->bits_pre, (int)l->nr_vertices, (int)l->capacity,
-                       l->vkeys, l->vslot);
-    TLN_LAUNCH_CHECK();
+    BkJobs jobs;
+    int split_t = 0;
+    rc = bk_fill_job(l, d_positions, d_values, n, val_dim, d_distributed, d_indices, d_weights, jobs.j[0], &split_t);
+    if (rc) return rc;
+    rc = bk_launch(jobs, 1, split_t, l->ctr_event, s);
+    if (rc) return rc;
   } else {
+    TableRef t = table_ref(l);
     l->bins_stamped = false;
     hipLaunchKernelGGL(k_distribute_insert, dim3((unsigned)tln_cdiv(4 * n, 256)), dim3(256), 0, s, d_positions, d_values, n,
                        val_dim, l->scale[0], l->scale[1], l->scale[2], t, l->row_slot, d_weights, d_distributed,
@@ -2091,7 +2237,6 @@ extern "C" int tln_distribute_begin(tln_lattice_t* l, const float* d_positions, 
     rc = number_new(l, rows, s);
     if (rc) return rc;
     TLN_HIP(hipMemcpyAsync(l->h_ctr, l->d_ctr, CTR_COUNT * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    if (!l->ctr_event) TLN_HIP(hipEventCreateWithFlags(&l->ctr_event, hipEventDisableTiming));
     TLN_HIP(hipEventRecord(l->ctr_event, s));
     // the bins: the host does not know the new vertex count yet; the kernels read it and stride over the vertices
     hipLaunchKernelGGL(k_bins_alloc, dim3(256), dim3(256), 0, s, l->d_ctr, l->vslot, l->slot_cnt, l->vcnt, l->vstart);
@@ -2101,14 +2246,57 @@ extern "C" int tln_distribute_begin(tln_lattice_t* l, const float* d_positions, 
       hipLaunchKernelGGL(k_bins_mean, dim3(8192), dim3(256), 0, s, l->d_ctr, l->vcnt, l->vstart, l->bin_rec, l->mean);
     TLN_LAUNCH_CHECK();
   }
-  l->dist_pending = true;
-  l->dist_pos = d_positions;
-  l->dist_out = d_distributed;
-  l->dist_idx = d_indices;
-  l->dist_rows = rows;
-  l->dist_val_dim = val_dim;
-  l->dist_subtract = subtract_mean;
-  l->bins_weights = d_weights;
+  distribute_remember(l, d_positions, n, val_dim, subtract_mean, d_distributed, d_indices, d_weights);
+  return TLN_OK;
+}
+
+// the first halves of up to TLN_BK_MAXJOBS distributes (different lattices, one stream) with FOUR launches for all of
+// them; each lattice is finished by its own tln_distribute_finish.  Frames the partitioned kernels do not take
+// (val_dim > 1, more than 4M rows, the legacy switch) go through tln_distribute_begin one by one.
+extern "C" int tln_distribute_begin_multi(const tln_distribute_call* c, int n, void* stream_) {
+  TLN_REQUIRE(c && n >= 1, "bad distribute batch");
+  hipStream_t s = (hipStream_t)stream_;
+  bool batch = n >= 2 && n <= TLN_BK_MAXJOBS;
+  for (int i = 0; i < n; ++i) {
+    TLN_REQUIRE(c[i].l && c[i].d_positions && c[i].d_indices && c[i].d_weights, "null argument");
+    TLN_REQUIRE(c[i].l->level == 0, "distribute works on the finest level");
+    TLN_REQUIRE(c[i].n > 0 && 4 * c[i].n < (1ll << 31), "nr of points %lld out of range", (long long)c[i].n);
+    TLN_REQUIRE(c[i].val_dim >= 0 && c[i].val_dim <= 1024 && (c[i].val_dim == 0 || c[i].d_values), "bad val_dim %d", c[i].val_dim);
+    for (int k = 0; k < i; ++k) TLN_REQUIRE(c[k].l != c[i].l, "the same lattice twice in one batch");
+    if (!bk_eligible(c[i].l, c[i].n, c[i].val_dim)) batch = false;
+  }
+  if (!batch) {
+    for (int i = 0; i < n; ++i) {
+      int rc = tln_distribute_begin(c[i].l, c[i].d_positions, c[i].d_values, c[i].n, c[i].val_dim, c[i].subtract_mean,
+                                    c[i].d_distributed, c[i].d_indices, c[i].d_weights, stream_);
+      if (rc) return rc;
+    }
+    return TLN_OK;
+  }
+  BkJobs jobs;
+  int split_t = 0;
+  for (int i = 0; i < n; ++i) {
+    int rc = distribute_prepare(c[i].l, c[i].n, s);
+    if (rc) return rc;
+  }
+  for (int i = 0; i < n; ++i) {
+    int st = 0;
+    int rc = bk_fill_job(c[i].l, c[i].d_positions, c[i].d_values, c[i].n, c[i].val_dim, c[i].d_distributed, c[i].d_indices,
+                         c[i].d_weights, jobs.j[i], &st);
+    if (rc) return rc;
+    if (st > split_t) split_t = st;
+  }
+  tln_lattice* l0 = c[0].l;
+  if (!l0->ctr_event) TLN_HIP(hipEventCreateWithFlags(&l0->ctr_event, hipEventDisableTiming));
+  int rc = bk_launch(jobs, n, split_t, l0->ctr_event, s);
+  if (rc) return rc;
+  for (int i = 0; i < n; ++i) {
+    // ONE event for the batch: the other lattices wait on the first one's (they are finished together; a later
+    // re-record by the first lattice only makes a straggler wait for more than it needs)
+    c[i].l->ctr_wait = i ? l0->ctr_event : nullptr;
+    distribute_remember(c[i].l, c[i].d_positions, c[i].n, c[i].val_dim, c[i].subtract_mean, c[i].d_distributed,
+                        c[i].d_indices, c[i].d_weights);
+  }
   return TLN_OK;
 }
 
@@ -2118,7 +2306,8 @@ extern "C" int tln_distribute_finish(tln_lattice_t* l, void* stream_) {
   TLN_REQUIRE(l && l->dist_pending, "tln_distribute_finish without tln_distribute_begin");
   hipStream_t s = (hipStream_t)stream_;
   l->dist_pending = false;
-  TLN_HIP(hipEventSynchronize(l->ctr_event));
+  TLN_HIP(hipEventSynchronize(l->ctr_wait ? l->ctr_wait : l->ctr_event));
+  l->ctr_wait = nullptr;
   publish_counts(l);
   if (l->h_ctr[CTR_PROBE_FAIL] != 0) {
     tln_set_error("hash probing failed for %d rows (table too full)", l->h_ctr[CTR_PROBE_FAIL]);

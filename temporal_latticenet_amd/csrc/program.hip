@@ -155,6 +155,7 @@ struct tln_program {
   bool timing = false;
   hipEvent_t tev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   bool tset[3] = {false, false, false};
+  int timing_group = 1;   // sequences whose stage the events of this program bracket (group mode: the batch, on programs[0])
   // state of a walk that is split in two (prefix, rest)
   bool w_wrote[TLN_MAX_STATES] = {false};
   int64_t w_new_rows[TLN_MAX_STATES] = {0};
@@ -680,12 +681,8 @@ extern "C" int tln_program_reset(tln_program_t* p) {
   return TLN_OK;
 }
 
-// first half of tln_program_begin_frame: K1 up to the point where the vertex counters start their way to the host
-extern "C" int tln_program_begin_frame_start(tln_program_t* p, tln_lattice_t* l, const float* d_positions,
-                                             const float* d_values, int64_t n, int val_dim, int reset_hashmap,
-                                             int subtract_mean, void* stream_) {
-  TLN_REQUIRE(p && l && d_positions && n > 0 && val_dim >= 0, "bad frame arguments");
-  hipStream_t s = (hipStream_t)stream_;
+// the frame's K1 outputs (distributed rows if wanted | indices | weights) placed in the program's buffer
+static int frame_buffers(tln_program* p, int64_t n, int val_dim, hipStream_t s) {
   const int cols = 3 + val_dim + 1;
   // the [4N, 5] `distributed` rows are not materialised when the pool can take the frame's rows from the lattice's
   // vertex bins (one value channel: every supported PointNet shape); the pool then gets d_distributed = NULL
@@ -698,10 +695,30 @@ extern "C" int tln_program_begin_frame_start(tln_program_t* p, tln_lattice_t* l,
   p->d_dist = want_dist ? reinterpret_cast<float*>(b) : nullptr;
   p->d_idx = reinterpret_cast<int32_t*>(b + dist_b);
   p->d_w = reinterpret_cast<float*>(b + dist_b + idx_b);
+  return TLN_OK;
+}
+
+static void frame_started(tln_program* p, tln_lattice_t* l, int64_t n, int val_dim) {
+  p->lat = l;
+  p->N = n;
+  p->dist_cols = 3 + val_dim + 1;
+  p->frame_open = false;
+  p->frame_started = true;
+}
+
+// first half of tln_program_begin_frame: K1 up to the point where the vertex counters start their way to the host
+extern "C" int tln_program_begin_frame_start(tln_program_t* p, tln_lattice_t* l, const float* d_positions,
+                                             const float* d_values, int64_t n, int val_dim, int reset_hashmap,
+                                             int subtract_mean, void* stream_) {
+  TLN_REQUIRE(p && l && d_positions && n > 0 && val_dim >= 0, "bad frame arguments");
+  hipStream_t s = (hipStream_t)stream_;
+  int rc = frame_buffers(p, n, val_dim, s);
+  if (rc) return rc;
   if (reset_hashmap) {
     rc = tln_lattice_clear(l, s);
     if (rc) return rc;
   }
+  p->timing_group = 1;
   if (p->timing) {
     p->tset[0] = p->tset[1] = p->tset[2] = false;
     TLN_HIP(hipEventRecord(p->tev[0], s));
@@ -712,11 +729,48 @@ extern "C" int tln_program_begin_frame_start(tln_program_t* p, tln_lattice_t* l,
     TLN_HIP(hipEventRecord(p->tev[1], s));
     p->tset[0] = true;
   }
-  p->lat = l;
-  p->N = n;
-  p->dist_cols = cols;
-  p->frame_open = false;
-  p->frame_started = true;
+  frame_started(p, l, n, val_dim);
+  return TLN_OK;
+}
+
+// the frames of `count` lock-stepped sequences begun together: ONE batch of K1 launches for all of them
+// (tln_distribute_begin_multi: blockIdx.y = sequence), one wait for the vertex counters, then every program's second
+// half.  v_out: [count][TLN_MAX_LEVELS].  With stage timing on, programs[0] holds the events around the whole batch.
+extern "C" int tln_program_begin_frame_group(tln_program_t* const* pp, tln_lattice_t* const* ll,
+                                             const float* const* d_positions, const float* const* d_values,
+                                             const int64_t* n, int count, int val_dim, int reset_hashmap, int subtract_mean,
+                                             int64_t* v_out, void* stream_) {
+  TLN_REQUIRE(pp && ll && d_positions && n && v_out && count >= 1 && count <= 8 && val_dim >= 0, "bad frame group");
+  hipStream_t s = (hipStream_t)stream_;
+  tln_distribute_call calls[8];
+  for (int k = 0; k < count; ++k) {
+    TLN_REQUIRE(pp[k] && ll[k] && d_positions[k] && n[k] > 0, "bad frame arguments (sequence %d)", k);
+    int rc = frame_buffers(pp[k], n[k], val_dim, s);
+    if (rc) return rc;
+  }
+  if (reset_hashmap) {
+    int rc = tln_lattice_clear_multi(ll, count, s);
+    if (rc) return rc;
+  }
+  tln_program* p0 = pp[0];
+  for (int k = 0; k < count; ++k) {
+    pp[k]->tset[0] = pp[k]->tset[1] = pp[k]->tset[2] = false;
+    pp[k]->timing_group = count;
+    calls[k] = tln_distribute_call{ll[k], d_positions[k], d_values ? d_values[k] : nullptr, n[k], val_dim, subtract_mean,
+                                   pp[k]->d_dist, pp[k]->d_idx, pp[k]->d_w};
+  }
+  if (p0->timing) TLN_HIP(hipEventRecord(p0->tev[0], s));
+  int rc = tln_distribute_begin_multi(calls, count, s);
+  if (rc) return rc;
+  if (p0->timing) {
+    TLN_HIP(hipEventRecord(p0->tev[1], s));
+    p0->tset[0] = true;
+  }
+  for (int k = 0; k < count; ++k) frame_started(pp[k], ll[k], n[k], val_dim);
+  for (int k = 0; k < count; ++k) {
+    rc = tln_program_begin_frame_finish(pp[k], v_out + (size_t)k * TLN_MAX_LEVELS, s);
+    if (rc) return rc;
+  }
   return TLN_OK;
 }
 

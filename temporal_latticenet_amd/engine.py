@@ -23,6 +23,7 @@ from .seq_modules import (CrossframeGlobalAttentionModule, CrossframeLocalInterp
                           TemporalLinearModule, TemporalMaxPoolModule)
 
 ROWS_POINTS, ROWS_POINT_ROWS, ROWS_STATE = -1, -2, -16
+MAX_LEVELS = 8          # TLN_MAX_LEVELS (include/tln.h)
 SLOT_F32, SLOT_STATS, SLOT_STATE_NEW, SLOT_STATE_PREV, SLOT_OUT = 0, 1, 2, 3, 4
 TABLE_NONE, TABLE_NBR, TABLE_C2F, TABLE_F2C = 0, 1, 2, 3
 (OP_GEMM, OP_GN_PARTIALS, OP_POOL, OP_GRU, OP_AFLOW, OP_SLICE_GATHER, OP_SLICE, OP_COPY, OP_ZERO_ROW0,
@@ -455,9 +456,36 @@ class FrameProgram:
     def run_frame_group(progs, lattices, positions, values, reset_hashmap, early_return):
         """2..8 sequences in lock-step on the current stream (tln_program_run_group): -> [(tensor, ls), ...]"""
         n = len(progs)
-        # all frames started before the first one is finished: the host waits for vertex counters once, not n times
-        started = [p._start(ls, pos, val, reset_hashmap) for p, ls, pos, val in zip(progs, lattices, positions, values)]
-        begun = [p._finish(st[0], early_return) for p, st in zip(progs, started)]
+        # the frames of all sequences begun by ONE native call: a single batch of K1 launches (blockIdx.y = sequence),
+        # one wait for the vertex counters
+        lib, s = _lib.lib(), stream_ptr()
+        pos = [p_.contiguous().float() for p_ in positions]
+        if values[0] is None or values[0].numel() == 0:
+            vals, val_dim = None, 0
+        else:
+            vals = [v_.contiguous().float() for v_ in values]
+            val_dim = vals[0].shape[1]
+            assert all(v_.shape[1] == val_dim for v_ in vals)
+        hs = (C.c_void_p * n)(*[p._h for p in progs])
+        lh = (C.c_void_p * n)(*[ls._h for ls in lattices])
+        pp = (C.c_void_p * n)(*[x.data_ptr() for x in pos])
+        vp = (C.c_void_p * n)(*[x.data_ptr() for x in vals]) if vals is not None else None
+        ns = (C.c_int64 * n)(*[x.shape[0] for x in pos])
+        vout = (C.c_int64 * (n * MAX_LEVELS))()
+        _lib.check(lib.tln_program_begin_frame_group(hs, lh, pp, vp, ns, n, val_dim, 1 if reset_hashmap else 0,
+                                                     1 if progs[0].subtract_mean else 0, vout, s),
+                   "tln_program_begin_frame_group")
+        begun = []
+        for k, (p, ls) in enumerate(zip(progs, lattices)):
+            ls._csr_key = None
+            ls._bins_key = None
+            ls._last_indices = None
+            for i in range(p.nr_coarse + 1):
+                p._v[i] = vout[k * MAX_LEVELS + i]
+            early_k = bool(early_return) and p.stop_shape is not None
+            rows_code, cols = p.stop_shape if early_k else p.out_shape
+            begun.append((early_k, torch.empty((p._rows(rows_code, int(ns[k])), cols), dtype=torch.float32, device="cuda")))
+        started = (pos, vals)                          # the inputs stay alive until the frames have been enqueued
         early, outs = begun[0][0], [x[1] for x in begun]
         assert all(x[0] == early for x in begun) and all(o.shape[1] == outs[0].shape[1] for o in outs)
         for p, o in zip(progs, outs):

@@ -269,6 +269,37 @@ class Lattice:
         self._last_indices = indices
         return distributed, indices, weights
 
+    @staticmethod
+    def distribute_batch(lattices, positions, values, reset_hashmap=True, subtract_mean=True):
+        """distribute() for 1..8 lattices of lock-stepped sequences with ONE batch of K1 launches
+        (tln_distribute_begin_multi: blockIdx.y = lattice) -> [(distributed, indices, weights), ...], bit for bit what
+        the single calls return"""
+        n = len(lattices)
+        pos = [p.contiguous().float() for p in positions]
+        vals = [v.contiguous().float() for v in values]
+        val_dim = vals[0].shape[1]
+        if reset_hashmap:
+            hs = (C.c_void_p * n)(*[l._h for l in lattices])
+            _lib.check(_lib.lib().tln_lattice_clear_multi(hs, n, stream_ptr()), "tln_lattice_clear_multi")
+        calls = (_lib.DistributeCall * n)()
+        outs = []
+        for k, (l, p, v) in enumerate(zip(lattices, pos, vals)):
+            rows = 4 * p.shape[0]
+            d = torch.empty((rows, 3 + val_dim + 1), dtype=torch.float32, device="cuda")
+            i = torch.empty((rows,), dtype=torch.int32, device="cuda")
+            w = torch.empty((rows,), dtype=torch.float32, device="cuda")
+            c = calls[k]
+            c.l, c.d_positions, c.d_values, c.n, c.val_dim = l._h, _ptr(p), _ptr(v), p.shape[0], val_dim
+            c.subtract_mean, c.d_distributed, c.d_indices, c.d_weights = 1 if subtract_mean else 0, _ptr(d), _ptr(i), _ptr(w)
+            outs.append((d, i, w))
+        _lib.check(_lib.lib().tln_distribute_begin_multi(calls, n, stream_ptr()), "tln_distribute_begin_multi")
+        for l, (d, i, w) in zip(lattices, outs):
+            _lib.check(_lib.lib().tln_distribute_finish(l._h, stream_ptr()), "tln_distribute_finish")
+            l._csr_key = None
+            l._bins_key = (d, d._version, i, i._version)
+            l._last_indices = i
+        return outs
+
     def bins_valid_for(self, distributed):
         k = getattr(self, "_bins_key", None)
         return k is not None and k[0].data_ptr() == distributed.data_ptr()

@@ -297,3 +297,31 @@ def test_partitioned_and_legacy_k1_agree(gpu, n, sigma, capacity, val_dim):
     assert np.array_equal(got[0][1], got[1][1]) and np.array_equal(got[0][2], got[1][2])
     if capacity == 12000:
         assert got[0][0][-1][4] > 0, "the fixture is meant to overflow"
+
+
+def test_batched_distribute_of_eight_lattices_equals_the_single_calls(gpu):
+    """tln_distribute_begin_multi: the frames of eight lock-stepped sequences (different clouds, different sizes: other
+    bucket counts, split-block sizes and threads per split block in one launch) through ONE batch of the four K1
+    kernels (blockIdx.y = sequence), two frames each -- indices / weights / keys bit for bit the oracle's, the
+    distributed rows and the CSR as from the single calls"""
+    from temporal_latticenet_amd.lattice import Lattice
+    sizes = [120000, 60000, 5000, 120000, 30000, 1000, 90000, 257]
+    seqs = [make_sequence(n, 2, seed=300 + k) for k, n in enumerate(sizes)]
+    lats = [Lattice.from_params([0.6] * 3, 1 << 17) for _ in sizes]
+    solo = [Lattice.from_params([0.6] * 3, 1 << 17) for _ in sizes]
+    tabs = [P.VertexTable(3, 1 << 17) for _ in sizes]
+    for t in range(2):
+        pos = [torch.from_numpy(s[t][0]).to(gpu) for s in seqs]
+        val = [torch.from_numpy(s[t][1]).to(gpu) for s in seqs]
+        outs = Lattice.distribute_batch(lats, pos, val, reset_hashmap=(t == 0))
+        for k, (d, i, w) in enumerate(outs):
+            od, oi, ow = O.distribute(tabs[k], seqs[k][t][0], seqs[k][t][1], [0.6] * 3)
+            assert lats[k].nr_lattice_vertices() == tabs[k].nr_vertices, (k, t)
+            assert np.array_equal(i.cpu().numpy(), oi), (k, t)
+            assert np.array_equal(w.cpu().numpy(), ow), (k, t)
+            np.testing.assert_allclose(d.cpu().numpy(), od, rtol=0, atol=2e-5)
+            sd, si, sw = solo[k].distribute(pos[k], val[k], reset_hashmap=(t == 0))
+            assert torch.equal(d, sd) and torch.equal(i, si) and torch.equal(w, sw), (k, t)
+            assert np.array_equal(lats[k].keys().cpu().numpy(), tabs[k].keys)
+            _check_csr(lats[k], oi)
+            assert lats[k].overflow_rows() == 0

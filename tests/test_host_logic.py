@@ -152,7 +152,8 @@ def test_ctypes_mirrors_match_the_header_layout(tmp_path):
     if shutil.which("gcc") is None:
         pytest.skip("no gcc")
     pairs = {"tln_gemm_src": _lib.GemmSrc, "tln_gemm_call": _lib.GemmCall, "tln_slot": _lib.Slot,
-             "tln_op_src": _lib.OpSrc, "tln_op": _lib.Op, "tln_gn_desc": _lib.GnDesc}
+             "tln_op_src": _lib.OpSrc, "tln_op": _lib.Op, "tln_gn_desc": _lib.GnDesc,
+             "tln_distribute_call": _lib.DistributeCall}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "tln.h"', 'int main(void) {']
     for cname, cls in pairs.items():
         lines.append('  printf("%s size %%zu\\n", sizeof(%s));' % (cname, cname))
