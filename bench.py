@@ -283,13 +283,19 @@ def main():
                 gmodels, gseqs = pool.models[:per], per_stream[:per]
                 glats = [make_lattice(contents) for _ in range(per)]
                 g_ms, g_n, g_fl = 0.0, 0, 0.0
+                gs_ms, gs_by, gs_n = [0.0, 0.0, 0.0], [0.0, 0.0, 0.0], [0, 0, 0]
                 with torch.no_grad():
-                    for rep in range(2):                 # first round: warm (tables, workspaces of these lattices)
+                    # round 0: warm (tables, workspaces of these lattices); round 1: the products captured and replayed;
+                    # rounds 2-4: the scatter / gather stages of the group timed as the group issues them — ONE batch of
+                    # launches per stage for the frames of all its sequences (HIP events on the launch stream around the
+                    # batch, held by the group's first program), best round per stage
+                    for rep in range(5):
                         for m in gmodels:
                             m.reset_sequence()
-                            if rep == 1:
-                                m._program.capture_gemms(True)
+                            m._program.capture_gemms(rep == 1)
+                        gmodels[0]._program.stage_timing(rep >= 2)
                         cur = [make_lattice(contents) for _ in range(per)] if rep == 0 else glats
+                        r_ms, r_by, r_n = [0.0, 0.0, 0.0], [0.0, 0.0, 0.0], [0, 0, 0]
                         for t in range(len(frames)):
                             res = forward_group(gmodels, cur, [q[t][0] for q in gseqs], [q[t][1] for q in gseqs],
                                                 t != len(frames) - 1)
@@ -297,6 +303,19 @@ def main():
                             if rep == 1:
                                 ms, n, fl, by = FrameProgram.replay_gemms_group([m._program for m in gmodels], reps)
                                 g_ms, g_n, g_fl = g_ms + ms, g_n + n, g_fl + fl
+                            if rep >= 2:
+                                v0s = [l.nr_lattice_vertices() for l in cur]
+                                by3 = (sum(128.0 * n_pts for _ in cur), sum(96.0 * n_pts + 512.0 * v for v in v0s),
+                                       sum(768.0 * v + 148.0 * n_pts for v in v0s))
+                                for k, (ms, by) in enumerate(zip(gmodels[0]._program.stage_times_ms(), by3)):
+                                    if ms is not None:
+                                        r_ms[k] += ms
+                                        r_by[k] += by
+                                        r_n[k] += len(cur)
+                        for k in range(3):
+                            if rep >= 2 and r_n[k] and (gs_n[k] == 0 or r_ms[k] < gs_ms[k]):
+                                gs_ms[k], gs_by[k], gs_n[k] = r_ms[k], r_by[k], r_n[k]
+                gmodels[0]._program.stage_timing(False)
                 for m in gmodels:
                     m._program.capture_gemms(False)
                     m.reset_sequence()
@@ -367,6 +386,24 @@ def main():
                            "frac": round(tot_b / tot_t / 1e9 / HBM_PEAK_GBPS, 4), "stages": stages,
                            "note": "HIP events on the launch stream around each stage of every frame of one sequence "
                                    "running alone; bytes = SURVEY.md 8d (K1 128 N; K2 96 N + 512 V0; K8 768 V0 + 148 N)"}
+                # the same stages as the TIMED mode launches them: one batch of launches per stage for the frames of a
+                # stream's lock-step group (blockIdx.y = sequence), events around the batch, time per frame = batch / group
+                if grp is not None and gs_n[0]:
+                    gst = {}
+                    for k, nm in enumerate(names):
+                        if gs_n[k]:
+                            gbps = gs_by[k] / (gs_ms[k] * 1e-3) / 1e9
+                            gst[nm] = {"algorithmic_bytes": round(gs_by[k] / gs_n[k]), "us_per_frame": round(gs_ms[k] * 1e3 / gs_n[k], 2),
+                                       "GBps": round(gbps, 1), "frac": round(gbps / HBM_PEAK_GBPS, 4), "frames": gs_n[k]}
+                    g_b = sum(gs_by[k] / gs_n[k] for k in range(3) if gs_n[k])
+                    g_t = sum(gs_ms[k] / gs_n[k] for k in range(3) if gs_n[k]) * 1e-3
+                    scatter["group_mode"] = {
+                        "achieved": round(g_b / g_t / 1e9, 1), "frac": round(g_b / g_t / 1e9 / HBM_PEAK_GBPS, 4), "stages": gst,
+                        "sequences": per,
+                        "note": "the launches of the timed mode: every stage of the %d frames a lock-step group steps "
+                                "together goes out as ONE batch of launches (tln_distribute_begin_multi, "
+                                "tln_pointnet_pool_multi, tln_slice_deform_multi); HIP events around the batch on one "
+                                "stream running alone, time per frame = batch time / %d" % (per, per)}
             if args.breakdown:
                 model.use_frame_program = False
                 ops.profile_begin()

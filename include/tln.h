@@ -118,6 +118,17 @@ int tln_pointnet_pool(tln_lattice_t* l, const float* d_distributed, int64_t rows
                       int nr_layers, const float* const* d_w, const float* const* d_b,
                       const int* dims /* [nr_layers+1] */, int min_points, float* d_out, void* stream);
 
+/* the pools of n lock-stepped sequences (same MLP; every lattice's own bins / rows / output) with one launch per
+ * kernel (blockIdx.y = sequence).  Same results as n tln_pointnet_pool calls. */
+typedef struct {
+  tln_lattice_t* l;
+  const float* d_distributed;
+  int64_t rows;
+  float* d_out;
+} tln_pool_call;
+int tln_pointnet_pool_multi(const tln_pool_call* calls, int n, int dist_cols, int nr_layers, const float* const* d_w,
+                            const float* const* d_b, const int* dims, int min_points, void* stream);
+
 /* same, and d_argrow [V, cout_last] int32 = the row whose MLP output is the pooled value (-1: empty / masked
  * vertex) — what the backward pass of the pool needs */
 int tln_pointnet_pool_ex(tln_lattice_t* l, const float* d_distributed, int64_t rows, int dist_cols,
@@ -141,6 +152,11 @@ int tln_lattice_prepare_levels(tln_lattice_t* level0, int nr_coarse_levels, void
  * counts and builds the coarse tables.  Every entry point that looks at a coarse level finishes a pending fetch. */
 int tln_lattice_prepare_levels_begin(tln_lattice_t* l, int nr_coarse_levels, int64_t* v_bound_out, void* stream);
 int tln_lattice_prepare_levels_finish(tln_lattice_t* l, void* stream);
+/* both halves for the level stacks of n lock-stepped sequences (n level-0 lattices): every launch carries the work of
+ * all of them (blockIdx.y / job list = lattice).  v_bound_out is [n][TLN_MAX_LEVELS] (or NULL). */
+int tln_lattice_prepare_levels_begin_multi(tln_lattice_t* const* l, int n, int nr_coarse_levels, int64_t* v_bound_out,
+                                           void* stream);
+int tln_lattice_prepare_levels_finish_multi(tln_lattice_t* const* l, int n, void* stream);
 /* the coarse level of `l` as it stands (NULL if none yet); no side effects */
 tln_lattice_t* tln_lattice_coarse_level(tln_lattice_t* l);
 /* [V_coarse,9] rows into the fine level (coarsen conv) / [V_fine,9] rows into the coarse level (finefy) */
@@ -239,6 +255,13 @@ int tln_groupnorm_stats(const float* d_x, int64_t V, int C, int groups, const fl
  * d_partials = [ceil(V/32)][C] (sum, sumsq) doubles */
 /* first half only: per-32-row partial sums of x [V,C] -> d_partials [ceil(V/32)][C] pairs of doubles */
 int tln_groupnorm_partials(const float* d_x, int64_t V, int C, void* d_partials, void* stream);
+/* the first half for n tensors of one width (the lock-stepped sequences of a stream) in one launch */
+typedef struct {
+  const float* d_x;
+  int64_t V;
+  void* d_partials;
+} tln_gn_partials_call;
+int tln_groupnorm_partials_multi(const tln_gn_partials_call* calls, int n, int C, void* stream);
 int tln_groupnorm_from_partials(const void* d_partials, int64_t V, int C, int groups, const float* d_gamma,
                                 const float* d_beta, float eps, float* d_scale, float* d_shift, void* stream);
 /* GroupNorm (+ReLU) folded into a gather-GEMM: statistics -> per-channel scale/shift -> tln_gather_gemm_ex in ONE
@@ -268,6 +291,18 @@ int tln_gru_cell(const float* d_x, const float* d_h, int64_t V, int64_t Vh, int 
                  const float* d_w_hh, const float* d_b_ih, const float* d_b_hh, float* d_out,
                  float* d_ws /* [V,6C] */, int64_t ws_floats, void* stream);
 
+/* the cells of n lock-stepped sequences (same GRUCell weights; every call's own x / h / out / workspace) */
+typedef struct {
+  const float* d_x;
+  const float* d_h;
+  int64_t V, Vh;
+  float* d_out;
+  float* d_ws;
+  int64_t ws_floats;
+} tln_gru_call;
+int tln_gru_cell_multi(const tln_gru_call* calls, int n, int C, const float* d_w_ih, const float* d_w_hh,
+                       const float* d_b_ih, const float* d_b_hh, void* stream);
+
 /* ---- element-wise steps of the alternative fusion modules (rnn_modules = lstm / maxpool / cga, lm:17-185) ---- */
 /* LSTMModule lm:36-38: gates [V,4C] in torch LSTMCell order i|f|g|o, zero cell state: out = sig(o)*tanh(sig(i)*tanh(g)) */
 int tln_lstm_gates(const float* d_gates, int64_t V, int C, float* d_out, void* stream);
@@ -287,6 +322,19 @@ int tln_fill_empty_rows(const float* d_x, int64_t V, int C, int half, float valu
 int tln_aflow(const float* d_x, const float* d_h, int64_t V, int64_t Vh, int C, const int32_t* d_table,
               float alpha, float beta, float pad_value, int use_center, const float* d_bias,
               float* d_out, float* d_weights, int32_t* d_nbr_idx, void* stream);
+
+/* the correlations of n lock-stepped sequences (same alpha / beta / bias; every call's own tensors) in one launch */
+typedef struct {
+  const float* d_x;
+  const float* d_h;
+  int64_t V, Vh;
+  const int32_t* d_table;
+  float* d_out;
+  float* d_weights;
+  int32_t* d_nbr_idx;
+} tln_aflow_call;
+int tln_aflow_multi(const tln_aflow_call* calls, int n, int C, float alpha, float beta, float pad_value, int use_center,
+                    const float* d_bias, void* stream);
 
 /* ---- K8 slice: SliceFastCUDALatticeModule (models.py:465) / SliceLatticeModule ---------- */
 /* gather for the delta-weight head: out [n, 4*(cb+1)] = for r: [w_r * b[idx_r, :cb], w_r] */
@@ -308,6 +356,20 @@ int tln_slice_deform(const float* d_b, int cb, const float* d_scores, int64_t V,
 int tln_slice_deform_ls(const float* d_b, int cb, const float* d_scores, int64_t V, int C, const int32_t* d_indices,
                      const float* d_weights, const float* d_w_pre, const float* d_w_dw, const float* d_b_dw,
                      const float* d_bias, int64_t n, float* d_out, float* d_logsm, void* stream);
+
+/* the heads of n lock-stepped sequences (same head weights) in one launch; d_logsm NULL in all calls or in none */
+typedef struct {
+  const float* d_b;
+  const float* d_scores;
+  int64_t V;
+  const int32_t* d_indices;
+  const float* d_weights;
+  int64_t n;
+  float* d_out;
+  float* d_logsm;
+} tln_slice_call;
+int tln_slice_deform_multi(const tln_slice_call* calls, int n, int cb, int C, const float* d_w_pre, const float* d_w_dw,
+                           const float* d_b_dw, const float* d_bias, void* stream);
 
 /* ---- K11 plain splat (SplatLatticeModule) ---------------------------------------------- */
 /* out [V, val_dim+1] = sum over rows of w * [values, 1]  (uses the CSR of the last distribute) */

@@ -79,6 +79,13 @@ _PROTOS = {
     "tln_lattice_clear": (_i, [_vp, _vp]),
     "tln_lattice_clear_multi": (_i, [_vp, _i, _vp]),
     "tln_distribute_begin_multi": (_i, [_vp, _i, _vp]),
+    "tln_groupnorm_partials_multi": (_i, [_vp, _i, _i, _vp]),
+    "tln_aflow_multi": (_i, [_vp, _i, _i, _f, _f, _f, _i, _vp, _vp]),
+    "tln_slice_deform_multi": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "tln_gru_cell_multi": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "tln_lattice_prepare_levels_begin_multi": (_i, [_vp, _i, _i, _vp, _vp]),
+    "tln_lattice_prepare_levels_finish_multi": (_i, [_vp, _i, _vp]),
+    "tln_pointnet_pool_multi": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp]),
     "tln_program_begin_frame_group": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "tln_lattice_nr_vertices": (_i64, [_vp]),
     "tln_lattice_capacity": (_i64, [_vp]),

@@ -14,8 +14,20 @@
 
 // grid (row blocks of 32, channel tiles of 64); block = 4 waves, wave w takes rows r0+w, r0+w+4, ... (8 rows):
 // every load is independent, so a lattice level of a few thousand vertices still spreads over hundreds of blocks
-__global__ void __launch_bounds__(256) k_gn_partial(const float* __restrict__ x, int64_t V, int C,
-                                                    double2* __restrict__ partial) {
+// (up to TLN_FUSED_MAXJOBS tensors of one width per launch: blockIdx.z = tensor — the lock-stepped sequences of a stream)
+#define TLN_FUSED_MAXJOBS 8
+struct GnPartJobs {
+  struct {
+    const float* x;
+    int64_t V;
+    double2* partial;
+  } j[TLN_FUSED_MAXJOBS];
+};
+__global__ void __launch_bounds__(256) k_gn_partial(const GnPartJobs jobs, int C) {
+  const float* __restrict__ x = jobs.j[blockIdx.z].x;
+  const int64_t V = jobs.j[blockIdx.z].V;
+  double2* __restrict__ partial = jobs.j[blockIdx.z].partial;
+  if ((int64_t)blockIdx.x * GN_ROWS_PER_BLOCK >= V) return;   // (the grid is sized for the tallest tensor)
   __shared__ double2 red[4][64];
   const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
   const int c = blockIdx.y * 64 + lx;
@@ -132,7 +144,13 @@ extern "C" int tln_groupnorm_stats(const float* d_x, int64_t V, int C, int group
   TLN_REQUIRE(ws_bytes >= tln_groupnorm_ws_bytes(V, C), "groupnorm workspace too small");
   hipStream_t s = (hipStream_t)stream_;
   const int nblk = (int)tln_cdiv(V, GN_ROWS_PER_BLOCK);
-  hipLaunchKernelGGL(k_gn_partial, dim3(nblk, (unsigned)tln_cdiv(C, 64)), dim3(256), 0, s, d_x, V, C, (double2*)d_ws);
+  GnPartJobs jobs;
+  for (int i = 0; i < TLN_FUSED_MAXJOBS; ++i) {
+    jobs.j[i].x = d_x;
+    jobs.j[i].V = V;
+    jobs.j[i].partial = (double2*)d_ws;
+  }
+  hipLaunchKernelGGL(k_gn_partial, dim3(nblk, (unsigned)tln_cdiv(C, 64), 1), dim3(256), 0, s, jobs, C);
   hipLaunchKernelGGL(k_gn_finalize, dim3((unsigned)groups), dim3(256), 0, s,
                      GnFin{(const double2*)d_ws, nblk, V, C, groups, d_gamma, d_beta, eps, d_scale, d_shift});
   TLN_LAUNCH_CHECK();
@@ -140,11 +158,30 @@ extern "C" int tln_groupnorm_stats(const float* d_x, int64_t V, int C, int group
 }
 
 extern "C" int tln_groupnorm_partials(const float* d_x, int64_t V, int C, void* d_partials, void* stream_) {
-  TLN_REQUIRE(d_x && d_partials && V > 0 && C > 0 && C <= GN_MAX_C, "bad groupnorm partials call");
-  const int nblk = (int)tln_cdiv(V, GN_ROWS_PER_BLOCK);
-  hipLaunchKernelGGL(k_gn_partial, dim3(nblk, (unsigned)tln_cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream_, d_x, V, C,
-                     (double2*)d_partials);
-  TLN_LAUNCH_CHECK();
+  const tln_gn_partials_call c{d_x, V, d_partials};
+  return tln_groupnorm_partials_multi(&c, 1, C, stream_);
+}
+
+// the partial sums of n tensors of one width (lock-stepped sequences) in one launch (blockIdx.z = tensor)
+extern "C" int tln_groupnorm_partials_multi(const tln_gn_partials_call* c, int n, int C, void* stream_) {
+  TLN_REQUIRE(c && n >= 1 && C > 0 && C <= GN_MAX_C, "bad groupnorm partials call");
+  for (int i0 = 0; i0 < n; i0 += TLN_FUSED_MAXJOBS) {
+    const int m = n - i0 < TLN_FUSED_MAXJOBS ? n - i0 : TLN_FUSED_MAXJOBS;
+    GnPartJobs jobs;
+    int64_t vmax = 0;
+    for (int i = 0; i < TLN_FUSED_MAXJOBS; ++i) {
+      const tln_gn_partials_call& a = c[i0 + (i < m ? i : 0)];
+      TLN_REQUIRE(a.d_x && a.d_partials && a.V >= 0, "bad groupnorm partials call");
+      jobs.j[i].x = a.d_x;
+      jobs.j[i].V = a.V;
+      jobs.j[i].partial = (double2*)a.d_partials;
+      if (i < m && a.V > vmax) vmax = a.V;
+    }
+    if (vmax <= 0) continue;
+    hipLaunchKernelGGL(k_gn_partial, dim3((unsigned)tln_cdiv(vmax, GN_ROWS_PER_BLOCK), (unsigned)tln_cdiv(C, 64), (unsigned)m),
+                       dim3(256), 0, (hipStream_t)stream_, jobs, C);
+    TLN_LAUNCH_CHECK();
+  }
   return TLN_OK;
 }
 
@@ -265,6 +302,41 @@ extern "C" int tln_gru_cell(const float* d_x, const float* d_h, int64_t V, int64
   return TLN_OK;
 }
 
+// the GRU cells of n lock-stepped sequences (same weights): ONE launch of the fused cell kernel (blockIdx.z = sequence)
+// when every lattice is large enough for it, else one tln_gru_cell per sequence
+extern "C" int tln_gru_cell_multi(const tln_gru_call* c, int n, int C, const float* d_w_ih, const float* d_w_hh,
+                                  const float* d_b_ih, const float* d_b_hh, void* stream_) {
+  TLN_REQUIRE(c && n >= 1 && d_w_ih && d_w_hh && C > 0, "bad GRU batch");
+  bool fused = n >= 2 && n <= TLN_GEMM_MULTI_MAX && d_b_ih && d_b_hh && ((uintptr_t)d_w_ih % 16 == 0) &&
+               ((uintptr_t)d_w_hh % 16 == 0);
+  for (int i = 0; i < n && fused; ++i)
+    fused = c[i].d_x && c[i].d_h && c[i].d_out && tln_gemm_v2_gru_ok(c[i].V, c[i].Vh, C) && ((uintptr_t)c[i].d_x % 16 == 0) &&
+            ((uintptr_t)c[i].d_h % 16 == 0);
+  if (fused) {
+    const float* x[TLN_GEMM_MULTI_MAX];
+    const float* h[TLN_GEMM_MULTI_MAX];
+    float* out[TLN_GEMM_MULTI_MAX];
+    int64_t V[TLN_GEMM_MULTI_MAX], Vh[TLN_GEMM_MULTI_MAX];
+    for (int i = 0; i < n; ++i) {
+      x[i] = c[i].d_x;
+      h[i] = c[i].d_h;
+      out[i] = c[i].d_out;
+      V[i] = c[i].V;
+      Vh[i] = c[i].Vh;
+    }
+    int rc = tln_gemm_v2_launch_gru_multi(n, x, h, Vh, V, C, d_w_ih, d_w_hh, d_b_ih, d_b_hh, out, (hipStream_t)stream_);
+    if (rc) return rc;
+    TLN_LAUNCH_CHECK();
+    return TLN_OK;
+  }
+  for (int i = 0; i < n; ++i) {
+    int rc = tln_gru_cell(c[i].d_x, c[i].d_h, c[i].V, c[i].Vh, C, d_w_ih, d_w_hh, d_b_ih, d_b_hh, c[i].d_out, c[i].d_ws,
+                          c[i].ws_floats, stream_);
+    if (rc) return rc;
+  }
+  return TLN_OK;
+}
+
 // =======================================================================================
 // Element-wise steps of the alternative fusion modules (reference lm:17-185), so that every `rnn_modules` choice runs
 // on this library's kernels end to end:
@@ -367,11 +439,27 @@ __device__ __forceinline__ float aflow_row_elem(const float* __restrict__ h, int
   return h[(int64_t)idx * C + c];
 }
 
-__global__ void __launch_bounds__(256) k_aflow(const float* __restrict__ x, const float* __restrict__ h, int64_t V,
-                                               int64_t Vh, int C, const int32_t* __restrict__ table, float alpha,
-                                               float beta, float pad, int use_center, const float* __restrict__ bias,
-                                               float* __restrict__ out, float* __restrict__ weights,
-                                               int32_t* __restrict__ nbr_idx) {
+struct AflowJobs {
+  struct {
+    const float* x;
+    const float* h;
+    int64_t V, Vh;
+    const int32_t* table;
+    float* out;
+    float* weights;
+    int32_t* nbr_idx;
+  } j[TLN_FUSED_MAXJOBS];
+};
+__global__ void __launch_bounds__(256) k_aflow(const AflowJobs jobs, int C, float alpha, float beta, float pad,
+                                               int use_center, const float* __restrict__ bias) {
+  const auto& J = jobs.j[blockIdx.y];
+  const float* __restrict__ x = J.x;
+  const float* __restrict__ h = J.h;
+  const int64_t V = J.V, Vh = J.Vh;
+  const int32_t* __restrict__ table = J.table;
+  float* __restrict__ out = J.out;
+  float* __restrict__ weights = J.weights;
+  int32_t* __restrict__ nbr_idx = J.nbr_idx;
   const int64_t v = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (v >= V) return;
   const int lane = threadIdx.x & 63;
@@ -428,11 +516,36 @@ __global__ void __launch_bounds__(256) k_aflow(const float* __restrict__ x, cons
 extern "C" int tln_aflow(const float* d_x, const float* d_h, int64_t V, int64_t Vh, int C, const int32_t* d_table,
                          float alpha, float beta, float pad_value, int use_center, const float* d_bias, float* d_out,
                          float* d_weights, int32_t* d_nbr_idx, void* stream_) {
-  TLN_REQUIRE(d_x && d_h && d_table && d_out && d_weights && d_nbr_idx, "null argument");
-  TLN_REQUIRE(V > 0 && Vh >= 0 && C > 0, "bad AFlow shape");
-  hipLaunchKernelGGL(k_aflow, dim3((unsigned)tln_cdiv(V * 64, 256)), dim3(256), 0, (hipStream_t)stream_, d_x, d_h, V, Vh,
-                     C, d_table, alpha, beta, pad_value, use_center, d_bias, d_out, d_weights, d_nbr_idx);
-  TLN_LAUNCH_CHECK();
+  const tln_aflow_call c{d_x, d_h, V, Vh, d_table, d_out, d_weights, d_nbr_idx};
+  return tln_aflow_multi(&c, 1, C, alpha, beta, pad_value, use_center, d_bias, stream_);
+}
+
+// the AFlow correlations of n lock-stepped sequences (same alpha / beta / bias) in one launch (blockIdx.y = sequence)
+extern "C" int tln_aflow_multi(const tln_aflow_call* c, int n, int C, float alpha, float beta, float pad_value,
+                               int use_center, const float* d_bias, void* stream_) {
+  TLN_REQUIRE(c && n >= 1 && C > 0, "bad AFlow batch");
+  for (int i0 = 0; i0 < n; i0 += TLN_FUSED_MAXJOBS) {
+    const int m = n - i0 < TLN_FUSED_MAXJOBS ? n - i0 : TLN_FUSED_MAXJOBS;
+    AflowJobs jobs;
+    int64_t vmax = 0;
+    for (int i = 0; i < TLN_FUSED_MAXJOBS; ++i) {
+      const tln_aflow_call& a = c[i0 + (i < m ? i : 0)];
+      TLN_REQUIRE(a.d_x && a.d_h && a.d_table && a.d_out && a.d_weights && a.d_nbr_idx, "null argument");
+      TLN_REQUIRE(a.V > 0 && a.Vh >= 0, "bad AFlow shape");
+      jobs.j[i].x = a.d_x;
+      jobs.j[i].h = a.d_h;
+      jobs.j[i].V = a.V;
+      jobs.j[i].Vh = a.Vh;
+      jobs.j[i].table = a.d_table;
+      jobs.j[i].out = a.d_out;
+      jobs.j[i].weights = a.d_weights;
+      jobs.j[i].nbr_idx = a.d_nbr_idx;
+      if (i < m && a.V > vmax) vmax = a.V;
+    }
+    hipLaunchKernelGGL(k_aflow, dim3((unsigned)tln_cdiv(vmax * 64, 256), (unsigned)m), dim3(256), 0, (hipStream_t)stream_,
+                       jobs, C, alpha, beta, pad_value, use_center, d_bias);
+    TLN_LAUNCH_CHECK();
+  }
   return TLN_OK;
 }
 
@@ -507,13 +620,30 @@ extern "C" int tln_slice(const float* d_lv, int64_t V, int C, const int32_t* d_i
 // launches).  One thread per point, the 36 x 36 + 4 x 36 weights are wave-uniform (scalar loads).
 // ---------------------------------------------------------------------------------------
 #define TLN_SLICE_MAX_C 64
+struct SliceJobs {
+  struct {
+    const float* b;
+    const float* scores;
+    int64_t V, n;
+    const int32_t* indices;
+    const float* weights;
+    float* out;
+    float* logsm;
+  } j[TLN_FUSED_MAXJOBS];
+};
 template <int CB>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) k_slice_deform(const float* __restrict__ b, const float* __restrict__ scores,
-                                                      int64_t V, int C, const int32_t* __restrict__ indices,
-                                                      const float* __restrict__ weights,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) k_slice_deform(const SliceJobs jobs, int C,
                                                       const float* __restrict__ w_pre, const float* __restrict__ w_dw,
-                                                      const float* __restrict__ b_dw, const float* __restrict__ bias,
-                                                      int64_t n, float* __restrict__ out, float* __restrict__ logsm) {
+                                                      const float* __restrict__ b_dw, const float* __restrict__ bias) {
+  const auto& J = jobs.j[blockIdx.y];
+  const int64_t n = J.n, V = J.V;
+  if ((int64_t)blockIdx.x * 64 >= n) return;   // (the grid is sized for the largest cloud; uniform per block)
+  const float* __restrict__ b = J.b;
+  const float* __restrict__ scores = J.scores;
+  const int32_t* __restrict__ indices = J.indices;
+  const float* __restrict__ weights = J.weights;
+  float* __restrict__ out = J.out;
+  float* __restrict__ logsm = J.logsm;
   constexpr int G = 4 * (CB + 1);            // 36 gathered features
   constexpr int GP = (G + 3) / 4 * 4;        // LDS rows padded to 16-byte multiples
   constexpr int PPB = 64;                    // points per block: FOUR lanes per point, each owns G/4 hidden units
@@ -642,16 +772,42 @@ extern "C" int tln_slice_deform_ls(const float* d_b, int cb, const float* d_scor
                                    const int32_t* d_indices, const float* d_weights, const float* d_w_pre,
                                    const float* d_w_dw, const float* d_b_dw, const float* d_bias, int64_t n, float* d_out,
                                    float* d_logsm, void* stream_) {
-  TLN_REQUIRE(d_b && d_scores && d_indices && d_weights && d_w_pre && d_w_dw && d_b_dw && d_out && C > 0,
-              "null argument");
+  const tln_slice_call c{d_b, d_scores, V, d_indices, d_weights, n, d_out, d_logsm};
+  return tln_slice_deform_multi(&c, 1, cb, C, d_w_pre, d_w_dw, d_b_dw, d_bias, stream_);
+}
+
+// the DeformSlice heads of n lock-stepped sequences (same head weights) in one launch (blockIdx.y = sequence); either
+// every call asks for the log-softmax or none does
+extern "C" int tln_slice_deform_multi(const tln_slice_call* c, int n, int cb, int C, const float* d_w_pre,
+                                      const float* d_w_dw, const float* d_b_dw, const float* d_bias, void* stream_) {
+  TLN_REQUIRE(c && n >= 1 && d_w_pre && d_w_dw && d_b_dw && C > 0, "null argument");
   TLN_REQUIRE(cb == 8, "the deform head is built for the 8-channel bottleneck (got %d)", cb);
-  TLN_REQUIRE(d_logsm == nullptr || C <= TLN_SLICE_MAX_C, "fused log-softmax: at most %d classes (got %d)",
-              TLN_SLICE_MAX_C, C);
-  if (n <= 0) return TLN_OK;
-  const size_t lds = d_logsm ? (size_t)64 * (C | 1) * sizeof(float) : 0;
-  hipLaunchKernelGGL(k_slice_deform<8>, dim3((unsigned)tln_cdiv(n, 64)), dim3(256), lds, (hipStream_t)stream_, d_b,
-                     d_scores, V, C, d_indices, d_weights, d_w_pre, d_w_dw, d_b_dw, d_bias, n, d_out, d_logsm);
-  TLN_LAUNCH_CHECK();
+  for (int i0 = 0; i0 < n; i0 += TLN_FUSED_MAXJOBS) {
+    const int m = n - i0 < TLN_FUSED_MAXJOBS ? n - i0 : TLN_FUSED_MAXJOBS;
+    SliceJobs jobs;
+    int64_t nmax = 0;
+    const bool ls = c[i0].d_logsm != nullptr;
+    for (int i = 0; i < TLN_FUSED_MAXJOBS; ++i) {
+      const tln_slice_call& a = c[i0 + (i < m ? i : 0)];
+      TLN_REQUIRE(a.d_b && a.d_scores && a.d_indices && a.d_weights && a.d_out, "null argument");
+      TLN_REQUIRE((a.d_logsm != nullptr) == ls, "log-softmax asked for by some calls of a batch only");
+      jobs.j[i].b = a.d_b;
+      jobs.j[i].scores = a.d_scores;
+      jobs.j[i].V = a.V;
+      jobs.j[i].n = a.n;
+      jobs.j[i].indices = a.d_indices;
+      jobs.j[i].weights = a.d_weights;
+      jobs.j[i].out = a.d_out;
+      jobs.j[i].logsm = a.d_logsm;
+      if (i < m && a.n > nmax) nmax = a.n;
+    }
+    TLN_REQUIRE(!ls || C <= TLN_SLICE_MAX_C, "fused log-softmax: at most %d classes (got %d)", TLN_SLICE_MAX_C, C);
+    if (nmax <= 0) continue;
+    const size_t lds = ls ? (size_t)64 * (C | 1) * sizeof(float) : 0;
+    hipLaunchKernelGGL(k_slice_deform<8>, dim3((unsigned)tln_cdiv(nmax, 64), (unsigned)m), dim3(256), lds,
+                       (hipStream_t)stream_, jobs, C, d_w_pre, d_w_dw, d_b_dw, d_bias);
+    TLN_LAUNCH_CHECK();
+  }
   return TLN_OK;
 }
 

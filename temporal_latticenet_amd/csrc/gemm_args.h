@@ -67,3 +67,6 @@ int tln_gemm_v2_launch_multi(GemmArgs* g, int n, bool w_is_nk, hipStream_t s);
 bool tln_gemm_v2_gru_ok(int64_t V, int64_t Vh, int C);
 int tln_gemm_v2_launch_gru(const float* d_x, const float* d_h, int64_t Vh, int64_t V, int C, const float* d_w_ih,
                            const float* d_w_hh, const float* d_b_ih, const float* d_b_hh, float* d_out, hipStream_t s);
+int tln_gemm_v2_launch_gru_multi(int n, const float* const* d_x, const float* const* d_h, const int64_t* Vh, const int64_t* V,
+                                 int C, const float* d_w_ih, const float* d_w_hh, const float* d_b_ih, const float* d_b_hh,
+                                 float* const* d_out, hipStream_t s);

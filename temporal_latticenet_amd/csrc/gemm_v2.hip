@@ -387,6 +387,13 @@ __global__ void __launch_bounds__(512) k_gather_gemm_v2_gru(const GemmArgs g) {
   v2_body<4, 2, 1, 3, true, false, true>(g);
 }
 
+// the GRU cells of lock-stepped sequences in one launch (blockIdx.z = sequence; same weights, own x / h / out)
+__global__ void __launch_bounds__(512) k_gather_gemm_v2_gru_multi(const GemmArgsN<TLN_GEMM_MULTI_MAX> gg) {
+  const GemmArgs& g = gg.a[blockIdx.z];
+  if ((int64_t)blockIdx.x * 128 >= g.M) return;   // (the grid is sized for the largest lattice)
+  v2_body<4, 2, 1, 3, true, false, true>(g);
+}
+
 // several products of one shape class in one launch (blockIdx.z = product): the coarse levels of lock-stepped
 // sequences, whose rows only together fill the chip with 128-row tiles
 template <int WM, int WN, int TM, int TN, bool W_NK, bool PRO, int STAGES = V2_STAGES>
@@ -552,9 +559,9 @@ bool tln_gemm_v2_gru_ok(int64_t V, int64_t Vh, int C) {
   static const bool off = getenv("TLN_GRU_FUSED_OFF") != nullptr;
   return !off && !(g_v2_off & 1) && V >= g_v2_min_m && V < (1ll << 31) && Vh >= 1 && Vh <= V && C % 64 == 0 && C <= 1024;
 }
-int tln_gemm_v2_launch_gru(const float* d_x, const float* d_h, int64_t Vh, int64_t V, int C, const float* d_w_ih,
-                           const float* d_w_hh, const float* d_b_ih, const float* d_b_hh, float* d_out, hipStream_t s) {
-  GemmArgs g{};
+static void v2_gru_args(GemmArgs& g, const float* d_x, const float* d_h, int64_t Vh, int64_t V, int C, const float* d_w_ih,
+                        const float* d_w_hh, const float* d_b_ih, const float* d_b_hh, float* d_out) {
+  g = GemmArgs{};
   g.M = V;
   g.N = 3 * C;
   g.K0 = 2 * C;
@@ -577,12 +584,38 @@ int tln_gemm_v2_launch_gru(const float* d_x, const float* d_h, int64_t Vh, int64
   g.out = d_out;
   g.ld_out = C;
   g.splits = 1;
+}
+
+int tln_gemm_v2_launch_gru(const float* d_x, const float* d_h, int64_t Vh, int64_t V, int C, const float* d_w_ih,
+                           const float* d_w_hh, const float* d_b_ih, const float* d_b_hh, float* d_out, hipStream_t s) {
+  GemmArgs g;
+  v2_gru_args(g, d_x, d_h, Vh, V, C, d_w_ih, d_w_hh, d_b_ih, d_b_hh, d_out);
   constexpr int BM = 128, BN = 192;
   const size_t lds = (size_t)V2_STAGES * (BM + BN) * 128 + (size_t)BM * TLN_TAPS * 4 + (size_t)2 * C * 4 + (size_t)(BM + 32) * 4;
   static thread_local TlnLdsAttr attr;
   TLN_HIP(tln_set_max_lds(attr, reinterpret_cast<const void*>(k_gather_gemm_v2_gru), (int)lds));
   dim3 grid((unsigned)tln_cdiv(V, BM), (unsigned)(3 * C / BN), 1);
   hipLaunchKernelGGL(k_gather_gemm_v2_gru, grid, dim3(512), lds, s, g);
+  return TLN_OK;
+}
+
+// the cells of n <= TLN_GEMM_MULTI_MAX sequences (same weights) in ONE launch
+int tln_gemm_v2_launch_gru_multi(int n, const float* const* d_x, const float* const* d_h, const int64_t* Vh, const int64_t* V,
+                                 int C, const float* d_w_ih, const float* d_w_hh, const float* d_b_ih, const float* d_b_hh,
+                                 float* const* d_out, hipStream_t s) {
+  GemmArgsN<TLN_GEMM_MULTI_MAX> gg;
+  int64_t vmax = 0;
+  for (int i = 0; i < TLN_GEMM_MULTI_MAX; ++i) {
+    const int k = i < n ? i : 0;
+    v2_gru_args(gg.a[i], d_x[k], d_h[k], Vh[k], V[k], C, d_w_ih, d_w_hh, d_b_ih, d_b_hh, d_out[k]);
+    if (i < n && V[k] > vmax) vmax = V[k];
+  }
+  constexpr int BM = 128, BN = 192;
+  const size_t lds = (size_t)V2_STAGES * (BM + BN) * 128 + (size_t)BM * TLN_TAPS * 4 + (size_t)2 * C * 4 + (size_t)(BM + 32) * 4;
+  static thread_local TlnLdsAttr attr;
+  TLN_HIP(tln_set_max_lds(attr, reinterpret_cast<const void*>(k_gather_gemm_v2_gru_multi), (int)lds));
+  dim3 grid((unsigned)tln_cdiv(vmax, BM), (unsigned)(3 * C / BN), (unsigned)n);
+  hipLaunchKernelGGL(k_gather_gemm_v2_gru_multi, grid, dim3(512), lds, s, gg);
   return TLN_OK;
 }
 

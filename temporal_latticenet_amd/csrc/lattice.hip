@@ -86,6 +86,7 @@ struct tln_lattice {
   // tln_lattice_prepare_levels_begin without its _finish yet: coarse counters are in flight (root level only)
   int levels_pending = 0;
   hipEvent_t levels_event = nullptr;
+  hipEvent_t levels_wait = nullptr;   // a batched _begin: the event of the batch's first lattice (borrowed)
   // tln_distribute_begin .. _finish: the counter fetch in flight and what the second half needs
   hipEvent_t ctr_event = nullptr;
   hipEvent_t ctr_wait = nullptr;   // a batched first half: the event of the batch's first lattice (borrowed)
@@ -281,6 +282,7 @@ struct ClearJobs {
     TlnSlot* slots;
     uint32_t* cnt;   // per-slot row counts (level 0), may be NULL
     int32_t* ctr;
+    int32_t* host_ctr;   // the host's mapped copy of the counters follows
     int64_t nslots;
   } j[TLN_CLEAR_JOBS];
   int n;
@@ -298,7 +300,10 @@ __global__ void __launch_bounds__(256) k_clear_levels(ClearJobs jobs) {
       raw[2 * i + 1] = make_ulonglong2(~0ull, ~0ull);
       if (cnt2) cnt2[i] = make_uint2(0u, 0u);
     }
-    if (id < CTR_COUNT) jobs.j[k].ctr[id] = 0;
+    if (id < CTR_COUNT) {
+      jobs.j[k].ctr[id] = 0;
+      jobs.j[k].host_ctr[id] = 0;
+    }
   }
 }
 
@@ -311,7 +316,9 @@ extern "C" int tln_lattice_clear_multi(tln_lattice_t* const* ll, int n, void* st
     tln_lattice* l = ll[i];
     TLN_REQUIRE(l, "null lattice");
     if (l->levels_pending) {  // a fetch of coarse counters is in flight: let it land before the counters are reset
-      if (l->levels_pending > 0 && l->levels_event) TLN_HIP(hipEventSynchronize(l->levels_event));
+      if (l->levels_pending > 0 && (l->levels_wait || l->levels_event))
+        TLN_HIP(hipEventSynchronize(l->levels_wait ? l->levels_wait : l->levels_event));
+      l->levels_wait = nullptr;
       l->levels_pending = 0;
     }
     for (tln_lattice* p = l; p; p = p->coarse) {
@@ -322,6 +329,7 @@ extern "C" int tln_lattice_clear_multi(tln_lattice_t* const* ll, int n, void* st
       jobs.j[jobs.n].slots = p->slots;
       jobs.j[jobs.n].cnt = p->slot_cnt;
       jobs.j[jobs.n].ctr = p->d_ctr;
+      jobs.j[jobs.n].host_ctr = p->h_ctr_dev;
       jobs.j[jobs.n].nslots = p->nslots;
       ++jobs.n;
       p->nr_vertices = 0;
@@ -640,6 +648,7 @@ static int ensure_slots(tln_lattice* l, int64_t rows, hipStream_t s) {
   TLN_HIP(hipMemcpyAsync(l->d_ctr + CTR_OCCUPIED, &occ, sizeof(int32_t), hipMemcpyHostToDevice, s));
   TLN_HIP(hipStreamSynchronize(s));
   l->occupied = l->nr_vertices;
+  l->h_ctr[CTR_OCCUPIED] = occ;   // (the host's mapped copy follows the device counters)
   ++l->gen;   // slot numbers changed: nothing cached by slot survives (the tables hold vertex indices, rebuilt anyway)
   return TLN_OK;
 }
@@ -754,10 +763,9 @@ __global__ void __launch_bounds__(256) k_distribute_insert(const float* __restri
 // coarse embedding of the fine vertices [first, first+count)
 // With fine_ctr != NULL `count` is only an upper bound known to the host; the true number of fine vertices is read
 // from the fine level's device counters and the rows beyond it are marked empty.
-__global__ void __launch_bounds__(256) k_coarsen_insert(const int32_t* __restrict__ fine_keys, int64_t first,
-                                                        int64_t count, TableRef t, int32_t* __restrict__ row_slot,
-                                                        const int32_t* __restrict__ fine_ctr) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void coarsen_insert_body(const int32_t* __restrict__ fine_keys, int64_t first, int64_t count,
+                                                    const TableRef& t, int32_t* __restrict__ row_slot,
+                                                    const int32_t* __restrict__ fine_ctr, int64_t i) {
   if (i >= count) return;
   if (fine_ctr != nullptr && first + i >= (int64_t)fine_ctr[CTR_NV]) {
 #pragma unroll
@@ -778,6 +786,36 @@ __global__ void __launch_bounds__(256) k_coarsen_insert(const int32_t* __restric
     }
     row_slot[id] = slot;
   }
+}
+__global__ void __launch_bounds__(256) k_coarsen_insert(const int32_t* __restrict__ fine_keys, int64_t first,
+                                                        int64_t count, TableRef t, int32_t* __restrict__ row_slot,
+                                                        const int32_t* __restrict__ fine_ctr) {
+  coarsen_insert_body(fine_keys, first, count, t, row_slot, fine_ctr, (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// One coarse level of one lattice being extended (embedding of the new fine vertices, then the numbering): the kernels
+// below take up to TLN_LVL_MAXJOBS of them per launch (blockIdx.y = lattice) — the lock-stepped sequences of a stream
+// extend the same level at the same time, each a chain of two or three launches of a few workgroups otherwise.
+#define TLN_LVL_MAXJOBS 8
+struct LevelJob {
+  const int32_t* fine_keys;
+  const int32_t* fine_ctr;
+  int32_t* row_slot;
+  int32_t* ctr;
+  int32_t* host_ctr;     // the host's mapped copy of the counters, written by the numbering (NULL: not wanted)
+  int32_t* vkeys;
+  int32_t* vslot;
+  int32_t* block_cnt;
+  TableRef t;
+  int64_t first, bound, rows;
+  int capacity, vold, nblocks, small;   // small: numbered by ONE workgroup (k_number_small), else count + assign
+};
+struct LevelJobs {
+  LevelJob j[TLN_LVL_MAXJOBS];
+};
+__global__ void __launch_bounds__(256) k_coarsen_insert_m(const LevelJobs jobs) {
+  const LevelJob& J = jobs.j[blockIdx.y];
+  coarsen_insert_body(J.fine_keys, J.first, J.bound, J.t, J.row_slot, J.fine_ctr, (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 __global__ void __launch_bounds__(256) k_insert_keys(const int32_t* __restrict__ keys, int64_t n, TableRef t,
@@ -802,14 +840,20 @@ __device__ __forceinline__ bool is_first_touch(const TableRef& t, const int32_t*
   return t.slots[slot].val < 0 && t.slots[slot].touch == (uint32_t)id;
 }
 
-__global__ void __launch_bounds__(TLN_SCAN_BLOCK) k_count_new(TableRef t, const int32_t* __restrict__ row_slot,
-                                                              int64_t rows, int32_t* __restrict__ block_cnt) {
+__device__ __forceinline__ void publish_counters(const int32_t* ctr, int32_t* host_ctr) {
+  if (host_ctr == nullptr) return;
+  __threadfence();
+  for (int i = 0; i < CTR_COUNT; ++i) host_ctr[i] = __hip_atomic_load(ctr + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ void count_new_body(const TableRef& t, const int32_t* __restrict__ row_slot, int64_t rows,
+                                               int32_t* __restrict__ block_cnt, int bx) {
   __shared__ int wave_cnt[TLN_SCAN_BLOCK / 64];
-  if (blockIdx.x == 0 && threadIdx.x == 0) {   // the bin allocator of this frame starts from zero
+  if (bx == 0 && threadIdx.x == 0) {   // the bin allocator of this frame starts from zero
     t.ctr[CTR_CURSOR] = 0;
     t.ctr[CTR_TAIL] = 0;
   }
-  const int64_t id = (int64_t)blockIdx.x * TLN_SCAN_BLOCK + threadIdx.x;
+  const int64_t id = (int64_t)bx * TLN_SCAN_BLOCK + threadIdx.x;
   int slot;
   const bool f = is_first_touch(t, row_slot, id, rows, slot);
   const unsigned long long m = __ballot(f);
@@ -818,27 +862,35 @@ __global__ void __launch_bounds__(TLN_SCAN_BLOCK) k_count_new(TableRef t, const 
   if (threadIdx.x == 0) {
     int s = 0;
     for (int w = 0; w < TLN_SCAN_BLOCK / 64; ++w) s += wave_cnt[w];
-    block_cnt[blockIdx.x] = s;
+    block_cnt[bx] = s;
   }
+}
+__global__ void __launch_bounds__(TLN_SCAN_BLOCK) k_count_new(TableRef t, const int32_t* __restrict__ row_slot,
+                                                              int64_t rows, int32_t* __restrict__ block_cnt) {
+  count_new_body(t, row_slot, rows, block_cnt, (int)blockIdx.x);
+}
+__global__ void __launch_bounds__(TLN_SCAN_BLOCK) k_count_new_m(const LevelJobs jobs) {
+  const LevelJob& J = jobs.j[blockIdx.y];
+  if (J.small || (int)blockIdx.x >= J.nblocks) return;
+  count_new_body(J.t, J.row_slot, J.rows, J.block_cnt, (int)blockIdx.x);
 }
 
 // numbering of the new slots: rank of a first-touch row = first-touch rows before it.  Every block sums the counts of
 // the blocks before it itself (a few hundred integers) — no separate scan launch; the last block also publishes the
 // new vertex count.  `vold` is the vertex count before this insertion (exact on the host).
-__global__ void __launch_bounds__(TLN_SCAN_BLOCK) k_assign_new(TableRef t, const int32_t* __restrict__ row_slot,
-                                                               int64_t rows, const int32_t* __restrict__ block_cnt,
-                                                               int32_t* __restrict__ ctr, int vold, int capacity,
-                                                               int32_t* __restrict__ vkeys,
-                                                               int32_t* __restrict__ vslot) {
+__device__ __forceinline__ void assign_new_body(const TableRef& t, const int32_t* __restrict__ row_slot, int64_t rows,
+                                                const int32_t* __restrict__ block_cnt, int32_t* __restrict__ ctr, int vold,
+                                                int capacity, int32_t* __restrict__ vkeys, int32_t* __restrict__ vslot,
+                                                int bx, int nblocks, int32_t* host_ctr) {
   __shared__ int wave_cnt[TLN_SCAN_BLOCK / 64];
   __shared__ int wave_pre[TLN_SCAN_BLOCK / 64];
-  const int64_t id = (int64_t)blockIdx.x * TLN_SCAN_BLOCK + threadIdx.x;
+  const int64_t id = (int64_t)bx * TLN_SCAN_BLOCK + threadIdx.x;
   int slot;
   const bool f = is_first_touch(t, row_slot, id, rows, slot);
   const unsigned long long m = __ballot(f);
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   int pre = 0;
-  for (int bq = threadIdx.x; bq < (int)blockIdx.x; bq += TLN_SCAN_BLOCK) pre += block_cnt[bq];
+  for (int bq = threadIdx.x; bq < bx; bq += TLN_SCAN_BLOCK) pre += block_cnt[bq];
   pre = tln_wave_sum(pre);
   if (lane == 0) {
     wave_cnt[wid] = __popcll(m);
@@ -850,13 +902,14 @@ __global__ void __launch_bounds__(TLN_SCAN_BLOCK) k_assign_new(TableRef t, const
     block_off += wave_pre[w];
     block_total += wave_cnt[w];
   }
-  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+  if (bx == nblocks - 1 && threadIdx.x == 0) {
     const int total = block_off + block_total;
     ctr[CTR_VOLD] = vold;
     ctr[CTR_NEW] = total;
     ctr[CTR_OVERFLOW] = 0;  // accumulated by k_row_indices, which runs after the numbering
     const long long vnew = (long long)vold + total;
     ctr[CTR_NV] = (int)(vnew < capacity ? vnew : capacity);
+    publish_counters(ctr, host_ctr);
   }
   if (!f) return;
   int woff = 0;
@@ -873,6 +926,19 @@ __global__ void __launch_bounds__(TLN_SCAN_BLOCK) k_assign_new(TableRef t, const
   } else {
     t.slots[slot].touch = 0xFFFFFFFFu;  // stays un-numbered; may be retried by a later insertion
   }
+}
+__global__ void __launch_bounds__(TLN_SCAN_BLOCK) k_assign_new(TableRef t, const int32_t* __restrict__ row_slot,
+                                                               int64_t rows, const int32_t* __restrict__ block_cnt,
+                                                               int32_t* __restrict__ ctr, int vold, int capacity,
+                                                               int32_t* __restrict__ vkeys,
+                                                               int32_t* __restrict__ vslot) {
+  assign_new_body(t, row_slot, rows, block_cnt, ctr, vold, capacity, vkeys, vslot, (int)blockIdx.x, (int)gridDim.x, nullptr);
+}
+__global__ void __launch_bounds__(TLN_SCAN_BLOCK) k_assign_new_m(const LevelJobs jobs) {
+  const LevelJob& J = jobs.j[blockIdx.y];
+  if (J.small || (int)blockIdx.x >= J.nblocks) return;
+  assign_new_body(J.t, J.row_slot, J.rows, J.block_cnt, J.ctr, J.vold, J.capacity, J.vkeys, J.vslot, (int)blockIdx.x,
+                  J.nblocks, J.host_ctr);
 }
 
 // phase C: per-row vertex index (+ sort input for the CSR)
@@ -897,10 +963,9 @@ __global__ void __launch_bounds__(256) k_row_indices(TableRef t, const int32_t* 
 
 // small insertions (the coarse levels embed only the new fine vertices of a frame): count, scan and assign in ONE
 // launch of a single block that walks the rows in order
-__global__ void __launch_bounds__(TLN_SCAN_BLOCK) k_number_small(TableRef t, const int32_t* __restrict__ row_slot,
-                                                                 int64_t rows, int32_t* __restrict__ ctr, int capacity,
-                                                                 int32_t* __restrict__ vkeys,
-                                                                 int32_t* __restrict__ vslot) {
+__device__ __forceinline__ void number_small_body(const TableRef& t, const int32_t* __restrict__ row_slot, int64_t rows,
+                                                  int32_t* __restrict__ ctr, int capacity, int32_t* __restrict__ vkeys,
+                                                  int32_t* __restrict__ vslot, int32_t* host_ctr) {
   __shared__ int wave_cnt[TLN_SCAN_BLOCK / 64];
   __shared__ int running_s;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -947,7 +1012,19 @@ __global__ void __launch_bounds__(TLN_SCAN_BLOCK) k_number_small(TableRef t, con
     ctr[CTR_OVERFLOW] = 0;  // accumulated by k_row_indices, which runs after the numbering
     const long long vnew = (long long)vold + total;
     ctr[CTR_NV] = (int)(vnew < capacity ? vnew : capacity);
+    publish_counters(ctr, host_ctr);
   }
+}
+__global__ void __launch_bounds__(TLN_SCAN_BLOCK) k_number_small(TableRef t, const int32_t* __restrict__ row_slot,
+                                                                 int64_t rows, int32_t* __restrict__ ctr, int capacity,
+                                                                 int32_t* __restrict__ vkeys,
+                                                                 int32_t* __restrict__ vslot) {
+  number_small_body(t, row_slot, rows, ctr, capacity, vkeys, vslot, nullptr);
+}
+__global__ void __launch_bounds__(TLN_SCAN_BLOCK) k_number_small_m(const LevelJobs jobs) {
+  const LevelJob& J = jobs.j[blockIdx.y];
+  if (!J.small || J.rows <= 0) return;
+  number_small_body(J.t, J.row_slot, J.rows, J.ctr, J.capacity, J.vkeys, J.vslot, J.host_ctr);
 }
 
 static int number_new(tln_lattice* l, int64_t rows, hipStream_t s) {
@@ -2430,15 +2507,15 @@ struct TableJob {
   int mode;
   int block_begin;
 };
+#define TLN_TABLE_MAXJOBS 48   // 8 lock-stepped sequences x (3 tables on each of 2 coarse levels)
 struct TableJobs {
-  TableJob j[8];
+  TableJob j[TLN_TABLE_MAXJOBS];
   int n;
 };
 __global__ void __launch_bounds__(256) k_tables_multi(const TableJobs jobs) {
   int k = 0;
-#pragma unroll
-  for (int i = 1; i < 8; ++i)
-    if (i < jobs.n && (int)blockIdx.x >= jobs.j[i].block_begin) k = i;
+  for (int i = 1; i < jobs.n; ++i)
+    if ((int)blockIdx.x >= jobs.j[i].block_begin) k = i;
   const TableJob& jb = jobs.j[k];
   table_entry(jb.qkeys, jb.nq, jb.t, jb.mode, jb.out, (int64_t)(blockIdx.x - jb.block_begin) * blockDim.x + threadIdx.x);
 }
@@ -2465,7 +2542,7 @@ struct PermJob {
   int32_t* perm;
 };
 struct PermJobs {
-  PermJob j[8];
+  PermJob j[TLN_TABLE_MAXJOBS];
   int n;
 };
 // sort key of a row: the position of its tap set (presence bits of the eight neighbour taps) in the Gray sequence —
@@ -2596,7 +2673,7 @@ static void perm_forget(const int32_t* table) {
   std::lock_guard<std::mutex> lk(g_perm_mu);
   g_perm.erase(table);
 }
-// the row orders of up to 8 freshly built tables: two launches for all of them
+// the row orders of up to TLN_TABLE_MAXJOBS freshly built tables: two launches for all of them
 struct PermWant {
   const int32_t* table;
   int64_t rows;
@@ -2785,120 +2862,243 @@ extern "C" int tln_fine_to_coarse_table(tln_lattice_t* c, const int32_t** d_tabl
 }
 
 // Build the coarse levels and every stale table of the stack in as few launches as possible: per coarse level one
-// insertion + one numbering launch and one counter read-back, then ONE launch for all neighbour / cross-level
-// tables.  Called once per frame right after tln_distribute; the per-table getters then only return pointers.
+// insertion + one numbering launch, then ONE launch for all neighbour / cross-level tables.  Called once per frame right
+// after tln_distribute; the per-table getters then only return pointers.
 // prepare_levels in two halves so that a caller can launch work that only needs level 0 while the coarse levels'
 // vertex counts are still on their way to the host:
-//   _begin   extends every coarse level (no host round trip in between), starts ONE asynchronous fetch of all their
-//            counters, records an event, builds the level-0 neighbour table; v_bound_out[0] = V0 (exact),
-//            v_bound_out[i] >= the new vertex count of level i
+//   _begin   extends every coarse level (no host round trip in between; the numbering kernels write the counters into
+//            the host's mapped words), records an event, builds the level-0 neighbour table; v_bound_out[0] = V0
+//            (exact), v_bound_out[i] >= the new vertex count of level i
 //   _finish  waits for that event (not for the stream), publishes the exact counts, builds the coarse tables
+// Both halves take the level stacks of up to TLN_LVL_MAXJOBS lattices (the lock-stepped sequences of a stream): every
+// launch then carries the work of all of them (blockIdx.y / job list = lattice).
+
+// the tables of `jobs` (built into them by add_table) + their row orders, TLN_TABLE_MAXJOBS per launch
+struct TableBatch {
+  TableJobs jobs{};
+  PermWant pw[TLN_TABLE_MAXJOBS];
+  int blocks = 0;
+};
+static int flush_tables(TableBatch& tb, hipStream_t s) {
+  if (tb.jobs.n == 0) return TLN_OK;
+  hipLaunchKernelGGL(k_tables_multi, dim3((unsigned)tb.blocks), dim3(256), 0, s, tb.jobs);
+  TLN_LAUNCH_CHECK();
+  int rc = build_perms(tb.pw, tb.jobs.n, s);
+  tb.jobs.n = 0;
+  tb.blocks = 0;
+  return rc;
+}
+static int add_table(TableBatch& tb, const int32_t* qkeys, int64_t nq, tln_lattice* target, int mode, int32_t* out,
+                     const PermWant& w, hipStream_t s) {
+  if (tb.jobs.n == TLN_TABLE_MAXJOBS) {
+    int rc = flush_tables(tb, s);
+    if (rc) return rc;
+  }
+  tb.pw[tb.jobs.n] = w;
+  TableJob& j = tb.jobs.j[tb.jobs.n++];
+  j.qkeys = qkeys;
+  j.nq = nq;
+  j.t = table_ref(target);
+  j.mode = mode;
+  j.out = out;
+  j.block_begin = tb.blocks;
+  tb.blocks += (int)tln_cdiv(nq * TLN_TAPS, 256);
+  return TLN_OK;
+}
+
+static int prepare_levels_begin_multi(tln_lattice* const* ll, int n, int nr_coarse_levels, int64_t* v_bound_out, int vstride,
+                                      hipStream_t s) {
+  TLN_REQUIRE(ll && n >= 1 && n <= TLN_LVL_MAXJOBS && nr_coarse_levels >= 0 && nr_coarse_levels <= 3,
+              "bad prepare_levels arguments");
+  tln_lattice* lv[TLN_LVL_MAXJOBS];
+  int64_t bound[TLN_LVL_MAXJOBS], growth[TLN_LVL_MAXJOBS];
+  for (int i = 0; i < n; ++i) {
+    tln_lattice* l0 = ll[i];
+    TLN_REQUIRE(l0 && !l0->parent, "prepare_levels wants the finest level");
+    if (l0->levels_pending) {
+      int rc = tln_lattice_prepare_levels_finish(l0, s);
+      if (rc) return rc;
+    }
+    if (v_bound_out) v_bound_out[(size_t)i * vstride] = l0->nr_vertices;
+    lv[i] = l0;
+    bound[i] = l0->nr_vertices;                       // exact
+    growth[i] = l0->nr_vertices - (l0->coarse ? l0->coarse->embedded_fine : 0);
+  }
+  for (int lev = 0; lev < nr_coarse_levels; ++lev) {
+    LevelJobs jobs;
+    int64_t max_bound = 0;
+    int max_blocks = 0, m = 0;
+    bool any_small = false, any_large = false;
+    for (int i = 0; i < n; ++i) {
+      tln_lattice* fine = lv[i];
+      if (!fine->coarse) {
+        double sg[3] = {fine->sigmas[0] * 2, fine->sigmas[1] * 2, fine->sigmas[2] * 2};
+        tln_lattice* c = nullptr;
+        int rc = lattice_alloc(&c, fine->pos_dim, sg, fine->capacity, fine->level + 1, fine->scale_constant);
+        if (rc) return rc;
+        c->parent = fine;
+        fine->coarse = c;
+        tln_lattice* cc = c;
+        rc = tln_lattice_clear_multi(&cc, 1, s);
+        if (rc) return rc;
+      }
+      tln_lattice* c = fine->coarse;
+      int64_t fb = bound[i] > fine->capacity ? fine->capacity : bound[i];
+      const int64_t first = c->embedded_fine, b = fb - first;
+      if (b > 0) {
+        const int64_t rows = 4 * b;
+        int rc = ensure_rows(c, rows);
+        if (rc) return rc;
+        rc = ensure_slots(c, rows, s);
+        if (rc) return rc;
+        LevelJob& J = jobs.j[m++];
+        J.fine_keys = fine->vkeys;
+        J.fine_ctr = fine->d_ctr;
+        J.row_slot = c->row_slot;
+        J.ctr = c->d_ctr;
+        J.host_ctr = c->h_ctr_dev;
+        J.vkeys = c->vkeys;
+        J.vslot = c->vslot;
+        J.block_cnt = c->block_cnt;
+        J.t = table_ref(c);
+        J.first = first;
+        J.bound = b;
+        J.rows = rows;
+        J.capacity = (int)c->capacity;
+        J.vold = (int)c->nr_vertices;
+        J.nblocks = (int)tln_cdiv(rows, TLN_SCAN_BLOCK);
+        J.small = rows <= 16 * TLN_SCAN_BLOCK ? 1 : 0;
+        if (J.small) any_small = true;
+        else any_large = true;
+        if (b > max_bound) max_bound = b;
+        if (!J.small && J.nblocks > max_blocks) max_blocks = J.nblocks;
+        c->csr_rows = -1;
+      }
+      if (growth[i] < 0) growth[i] = 0;
+      growth[i] *= 4;                                      // a fine vertex touches at most 4 coarse vertices
+      bound[i] = c->nr_vertices + growth[i];               // >= the coarse level's new count
+      if (bound[i] > c->capacity) bound[i] = c->capacity;
+      if (v_bound_out) v_bound_out[(size_t)i * vstride + lev + 1] = bound[i];
+      lv[i] = c;
+    }
+    if (m > 0) {
+      for (int k = m; k < TLN_LVL_MAXJOBS; ++k) jobs.j[k] = jobs.j[0];   // (never indexed: the grids have m rows)
+      hipLaunchKernelGGL(k_coarsen_insert_m, dim3((unsigned)tln_cdiv(max_bound, 256), (unsigned)m), dim3(256), 0, s, jobs);
+      if (any_small) hipLaunchKernelGGL(k_number_small_m, dim3(1, (unsigned)m), dim3(TLN_SCAN_BLOCK), 0, s, jobs);
+      if (any_large) {
+        hipLaunchKernelGGL(k_count_new_m, dim3((unsigned)max_blocks, (unsigned)m), dim3(TLN_SCAN_BLOCK), 0, s, jobs);
+        hipLaunchKernelGGL(k_assign_new_m, dim3((unsigned)max_blocks, (unsigned)m), dim3(TLN_SCAN_BLOCK), 0, s, jobs);
+      }
+      TLN_LAUNCH_CHECK();
+    }
+  }
+  // ONE event for the batch (the counters of every coarse level are in the hosts' mapped words behind it)
+  tln_lattice* first = ll[0];
+  if (!first->levels_event) TLN_HIP(hipEventCreateWithFlags(&first->levels_event, hipEventDisableTiming));
+  TLN_HIP(hipEventRecord(first->levels_event, s));
+  TableBatch tb;
+  for (int i = 0; i < n; ++i) {
+    tln_lattice* l0 = ll[i];
+    l0->levels_wait = i ? first->levels_event : nullptr;
+    l0->levels_pending = nr_coarse_levels > 0 ? nr_coarse_levels : -1;   // -1: nothing to wait for, tables only
+    if (l0->nr_vertices > 0) {
+      int rc = ensure_table(&l0->nbr, l0->capacity);
+      if (rc) return rc;
+      if (l0->nbr_gen != l0->gen) {
+        rc = add_table(tb, l0->vkeys, l0->nr_vertices, l0, 0, l0->nbr,
+                       PermWant{l0->nbr, l0->nr_vertices, &l0->perm_nbr, &l0->phist_nbr, l0->capacity}, s);
+        if (rc) return rc;
+        l0->nbr_gen = l0->gen;
+      }
+    }
+  }
+  return flush_tables(tb, s);
+}
+
+static int prepare_levels_finish_multi(tln_lattice* const* ll, int n, hipStream_t s) {
+  TableBatch tb;
+  for (int i = 0; i < n; ++i) {
+    tln_lattice* l0 = ll[i];
+    TLN_REQUIRE(l0 && !l0->parent, "prepare_levels wants the finest level");
+    if (!l0->levels_pending) continue;
+    const int nr_coarse_levels = l0->levels_pending > 0 ? l0->levels_pending : 0;
+    l0->levels_pending = 0;
+    if (nr_coarse_levels > 0) {
+      TLN_HIP(hipEventSynchronize(l0->levels_wait ? l0->levels_wait : l0->levels_event));
+      l0->levels_wait = nullptr;
+      int lvl = 0;
+      for (tln_lattice* c = l0->coarse; c && lvl < nr_coarse_levels; c = c->coarse, ++lvl) {
+        set_vertices(c, c->h_ctr[CTR_NV]);
+        c->occupied = c->h_ctr[CTR_OCCUPIED];
+        c->embedded_fine = c->parent->nr_vertices;
+        if (c->h_ctr[CTR_PROBE_FAIL] != 0) {
+          tln_set_error("hash probing failed for %d rows at level %d (table too full)", c->h_ctr[CTR_PROBE_FAIL], c->level);
+          return TLN_E_CAPACITY;
+        }
+      }
+    }
+    for (tln_lattice* p = l0; p; p = p->coarse) {
+      if (p->nr_vertices <= 0) continue;
+      int rc = ensure_table(&p->nbr, p->capacity);
+      if (rc) return rc;
+      if (p->nbr_gen != p->gen) {
+        rc = add_table(tb, p->vkeys, p->nr_vertices, p, 0, p->nbr,
+                       PermWant{p->nbr, p->nr_vertices, &p->perm_nbr, &p->phist_nbr, p->capacity}, s);
+        if (rc) return rc;
+        p->nbr_gen = p->gen;
+      }
+      if (p->parent && p->parent->nr_vertices > 0) {
+        tln_lattice* f = p->parent;
+        rc = ensure_table(&p->c2f, p->capacity);
+        if (rc) return rc;
+        rc = ensure_table(&p->f2c, f->capacity);
+        if (rc) return rc;
+        if (p->c2f_gen_c != p->gen || p->c2f_gen_f != f->gen) {
+          rc = add_table(tb, p->vkeys, p->nr_vertices, f, 1, p->c2f,
+                         PermWant{p->c2f, p->nr_vertices, &p->perm_c2f, &p->phist_c2f, p->capacity}, s);
+          if (rc) return rc;
+          p->c2f_gen_c = p->gen;
+          p->c2f_gen_f = f->gen;
+        }
+        if (p->f2c_gen_c != p->gen || p->f2c_gen_f != f->gen) {
+          rc = add_table(tb, f->vkeys, f->nr_vertices, p, 2, p->f2c,
+                         PermWant{p->f2c, f->nr_vertices, &p->perm_f2c, &p->phist_f2c, f->capacity}, s);
+          if (rc) return rc;
+          p->f2c_gen_c = p->gen;
+          p->f2c_gen_f = f->gen;
+        }
+      }
+    }
+  }
+  return flush_tables(tb, s);
+}
+
 extern "C" int tln_lattice_prepare_levels_begin(tln_lattice_t* l0, int nr_coarse_levels, int64_t* v_bound_out,
                                                 void* stream_) {
-  TLN_REQUIRE(l0 && nr_coarse_levels >= 0 && nr_coarse_levels <= 3, "bad prepare_levels arguments");
-  TLN_REQUIRE(!l0->parent, "prepare_levels wants the finest level");
-  hipStream_t s = (hipStream_t)stream_;
-  if (l0->levels_pending) {
-    int rc = tln_lattice_prepare_levels_finish(l0, stream_);
-    if (rc) return rc;
-  }
-  if (v_bound_out) v_bound_out[0] = l0->nr_vertices;
-  tln_lattice* lv = l0;
-  int64_t bound = l0->nr_vertices;                       // exact
-  int64_t growth = l0->nr_vertices - (l0->coarse ? l0->coarse->embedded_fine : 0);
-  for (int i = 0; i < nr_coarse_levels; ++i) {
-    int rc = coarsen_deferred(lv, bound, s);
-    if (rc) return rc;
-    tln_lattice* c = lv->coarse;
-    if (growth < 0) growth = 0;
-    growth *= 4;                                         // a fine vertex touches at most 4 coarse vertices
-    bound = c->nr_vertices + growth;                     // >= the coarse level's new count
-    if (bound > c->capacity) bound = c->capacity;
-    if (v_bound_out) v_bound_out[i + 1] = bound;
-    lv = c;
-  }
-  for (tln_lattice* c = l0->coarse; c; c = c->coarse)
-    TLN_HIP(hipMemcpyAsync(c->h_ctr, c->d_ctr, CTR_COUNT * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-  if (!l0->levels_event) TLN_HIP(hipEventCreateWithFlags(&l0->levels_event, hipEventDisableTiming));
-  TLN_HIP(hipEventRecord(l0->levels_event, s));
-  l0->levels_pending = nr_coarse_levels > 0 ? nr_coarse_levels : -1;   // -1: nothing to wait for, tables only
-  if (l0->nr_vertices > 0) {
-    const int32_t* unused = nullptr;
-    int rc = tln_neighbour_table(l0, &unused, stream_);
+  return prepare_levels_begin_multi(&l0, 1, nr_coarse_levels, v_bound_out, TLN_MAX_LEVELS, (hipStream_t)stream_);
+}
+
+extern "C" int tln_lattice_prepare_levels_finish(tln_lattice_t* l0, void* stream_) {
+  return prepare_levels_finish_multi(&l0, 1, (hipStream_t)stream_);
+}
+
+// the same for the level stacks of n lock-stepped sequences; v_bound_out is [n][TLN_MAX_LEVELS] (or NULL)
+extern "C" int tln_lattice_prepare_levels_begin_multi(tln_lattice_t* const* l0, int n, int nr_coarse_levels,
+                                                      int64_t* v_bound_out, void* stream_) {
+  TLN_REQUIRE(l0 && n >= 1, "null argument");
+  for (int i0 = 0; i0 < n; i0 += TLN_LVL_MAXJOBS) {
+    const int m = n - i0 < TLN_LVL_MAXJOBS ? n - i0 : TLN_LVL_MAXJOBS;
+    int rc = prepare_levels_begin_multi(l0 + i0, m, nr_coarse_levels,
+                                        v_bound_out ? v_bound_out + (size_t)i0 * TLN_MAX_LEVELS : nullptr, TLN_MAX_LEVELS,
+                                        (hipStream_t)stream_);
     if (rc) return rc;
   }
   return TLN_OK;
 }
 
-extern "C" int tln_lattice_prepare_levels_finish(tln_lattice_t* l0, void* stream_) {
-  TLN_REQUIRE(l0 && !l0->parent, "prepare_levels wants the finest level");
-  if (!l0->levels_pending) return TLN_OK;
-  hipStream_t s = (hipStream_t)stream_;
-  const int nr_coarse_levels = l0->levels_pending > 0 ? l0->levels_pending : 0;
-  l0->levels_pending = 0;
-  if (nr_coarse_levels > 0) {
-    TLN_HIP(hipEventSynchronize(l0->levels_event));
-    int lvl = 0;
-    for (tln_lattice* c = l0->coarse; c && lvl < nr_coarse_levels; c = c->coarse, ++lvl) {
-      set_vertices(c, c->h_ctr[CTR_NV]);
-      c->occupied = c->h_ctr[CTR_OCCUPIED];
-      c->embedded_fine = c->parent->nr_vertices;
-      if (c->h_ctr[CTR_PROBE_FAIL] != 0) {
-        tln_set_error("hash probing failed for %d rows at level %d (table too full)", c->h_ctr[CTR_PROBE_FAIL], c->level);
-        return TLN_E_CAPACITY;
-      }
-    }
-  }
-  TableJobs jobs{};
-  PermWant pw[8];
-  int blocks = 0;
-  auto add = [&](const int32_t* qkeys, int64_t nq, tln_lattice* target, int mode, int32_t* out) {
-    TableJob& j = jobs.j[jobs.n++];
-    j.qkeys = qkeys;
-    j.nq = nq;
-    j.t = table_ref(target);
-    j.mode = mode;
-    j.out = out;
-    j.block_begin = blocks;
-    blocks += (int)tln_cdiv(nq * TLN_TAPS, 256);
-  };
-  for (tln_lattice* p = l0; p; p = p->coarse) {
-    if (p->nr_vertices <= 0) continue;
-    int rc = ensure_table(&p->nbr, p->capacity);
-    if (rc) return rc;
-    if (p->nbr_gen != p->gen) {
-      pw[jobs.n] = PermWant{p->nbr, p->nr_vertices, &p->perm_nbr, &p->phist_nbr, p->capacity};
-      add(p->vkeys, p->nr_vertices, p, 0, p->nbr);
-      p->nbr_gen = p->gen;
-    }
-    if (p->parent && p->parent->nr_vertices > 0) {
-      tln_lattice* f = p->parent;
-      rc = ensure_table(&p->c2f, p->capacity);
-      if (rc) return rc;
-      rc = ensure_table(&p->f2c, f->capacity);
-      if (rc) return rc;
-      if (p->c2f_gen_c != p->gen || p->c2f_gen_f != f->gen) {
-        pw[jobs.n] = PermWant{p->c2f, p->nr_vertices, &p->perm_c2f, &p->phist_c2f, p->capacity};
-        add(p->vkeys, p->nr_vertices, f, 1, p->c2f);
-        p->c2f_gen_c = p->gen;
-        p->c2f_gen_f = f->gen;
-      }
-      if (p->f2c_gen_c != p->gen || p->f2c_gen_f != f->gen) {
-        pw[jobs.n] = PermWant{p->f2c, f->nr_vertices, &p->perm_f2c, &p->phist_f2c, f->capacity};
-        add(f->vkeys, f->nr_vertices, p, 2, p->f2c);
-        p->f2c_gen_c = p->gen;
-        p->f2c_gen_f = f->gen;
-      }
-    }
-    if (jobs.n >= 7) break;
-  }
-  if (jobs.n > 0) {
-    hipLaunchKernelGGL(k_tables_multi, dim3((unsigned)blocks), dim3(256), 0, s, jobs);
-    TLN_LAUNCH_CHECK();
-    int rc = build_perms(pw, jobs.n, s);
-    if (rc) return rc;
-  }
-  return TLN_OK;
+extern "C" int tln_lattice_prepare_levels_finish_multi(tln_lattice_t* const* l0, int n, void* stream_) {
+  TLN_REQUIRE(l0 && n >= 1, "null argument");
+  return prepare_levels_finish_multi(l0, n, (hipStream_t)stream_);
 }
 
 extern "C" int tln_lattice_prepare_levels(tln_lattice_t* l0, int nr_coarse_levels, void* stream_) {

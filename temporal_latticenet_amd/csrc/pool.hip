@@ -193,13 +193,32 @@ __global__ void __launch_bounds__(256) k_pool_finalize(const unsigned long long*
 // rows without a vertex, lm:480) go through the packed 64-bit atomicMax and k_pool_bins_finalize.
 // The rows of a segment arrive in arbitrary order: ties go to the smallest row id explicitly.
 // ---------------------------------------------------------------------------------------
+// The pool of up to TLN_POOL_MAXJOBS frames in one launch (blockIdx.y = frame): the lock-stepped sequences of a stream
+// share the PointNet weights, only the bins and the outputs differ
+#define TLN_POOL_MAXJOBS 8
+struct PoolJob {
+  TlnBins bn;
+  int64_t rows;
+  unsigned long long* packed;
+  float* out;
+  int32_t* argrow;
+  int nv;
+};
+struct PoolJobs {
+  PoolJob j[TLN_POOL_MAXJOBS];
+};
+
 template <int CIN, int H1, int H2, int COUT>
-__global__ void __launch_bounds__(256) k_pool_bins(const TlnBins bn, int64_t rows, int min_points,
+__global__ void __launch_bounds__(256) k_pool_bins(const PoolJobs jobs, int min_points,
                                                    const float* __restrict__ w1, const float* __restrict__ b1,
                                                    const float* __restrict__ w2, const float* __restrict__ b2,
-                                                   const float* __restrict__ w3, const float* __restrict__ b3,
-                                                   unsigned long long* __restrict__ packed, float* __restrict__ out,
-                                                   int32_t* __restrict__ argrow) {
+                                                   const float* __restrict__ w3, const float* __restrict__ b3) {
+  const PoolJob& J = jobs.j[blockIdx.y];
+  const TlnBins& bn = J.bn;
+  const int64_t rows = J.rows;
+  unsigned long long* __restrict__ packed = J.packed;
+  float* __restrict__ out = J.out;
+  int32_t* __restrict__ argrow = J.argrow;
   constexpr int HL = (H1 == 0) ? CIN : (H2 ? H2 : H1);
   constexpr int TS = ((HL + 3) / 4) * 4 + 4;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -593,9 +612,14 @@ static int launch_pool_bins_mfma(const TlnBins& bn, int64_t rows, const float* c
 
 // what k_pool_bins left open: vertices without rows (zeros, torch_scatter's empty segment), vertices whose segment
 // crosses a 64-row chunk boundary and vertex 0 (packed accumulators -> value, barycentric weight, mask)
-__global__ void __launch_bounds__(256) k_pool_bins_finalize(unsigned long long* packed, const TlnBins bn, int nv, int cout,
-                                                            int64_t rows, int min_points, float* __restrict__ out,
-                                                            int32_t* __restrict__ argrow) {
+__global__ void __launch_bounds__(256) k_pool_bins_finalize(const PoolJobs jobs, int cout, int min_points) {
+  const PoolJob& J = jobs.j[blockIdx.y];
+  const TlnBins& bn = J.bn;
+  const int nv = J.nv;
+  const int64_t rows = J.rows;
+  unsigned long long* packed = J.packed;
+  float* __restrict__ out = J.out;
+  int32_t* __restrict__ argrow = J.argrow;
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t v = gid / cout;
   const int c = (int)(gid - v * cout);
@@ -631,8 +655,8 @@ __global__ void __launch_bounds__(256) k_pool_bins_finalize(unsigned long long* 
 }
 
 template <int CIN, int H1, int H2, int COUT>
-static int launch_pool_bins(const TlnBins& bn, int64_t rows, const float* const* w, const float* const* b, int min_points,
-                            unsigned long long* packed, float* d_out, int32_t* d_argrow, hipStream_t s) {
+static int launch_pool_bins(const PoolJobs& jobs, int n, const float* const* w, const float* const* b, int min_points,
+                            hipStream_t s) {
   constexpr int HL = (H1 == 0) ? CIN : (H2 ? H2 : H1);
   constexpr int TS = ((HL + 3) / 4) * 4 + 4;
   const size_t lds = (size_t)(4 * (64 * TS + 64)) * sizeof(float);   // 37.9 KB for the 32-wide last hidden layer: four workgroups per CU
@@ -641,12 +665,15 @@ static int launch_pool_bins(const TlnBins& bn, int64_t rows, const float* const*
     mp.w[i] = (H1 && w) ? w[i < (H2 ? 3 : 2) ? i : 0] : nullptr;
     mp.b[i] = (H1 && b) ? b[i < (H2 ? 3 : 2) ? i : 0] : nullptr;
   }
+  int64_t rows = 0;
+  for (int i = 0; i < n; ++i)
+    if (jobs.j[i].rows > rows) rows = jobs.j[i].rows;   // the grid is sized for the longest frame
   const int64_t chunks = tln_cdiv(rows, 64);
   auto kern = k_pool_bins<CIN, H1, H2, COUT>;
   static thread_local TlnLdsAttr attr;   // (one per template instantiation)
   TLN_HIP(tln_set_max_lds(attr, reinterpret_cast<const void*>(kern), (int)lds));
-  hipLaunchKernelGGL(kern, dim3((unsigned)tln_cdiv(chunks, 4)), dim3(256), lds, s, bn, rows, min_points, mp.w[0], mp.b[0],
-                     mp.w[1], mp.b[1], mp.w[2], mp.b[2], packed, d_out, d_argrow);
+  hipLaunchKernelGGL(kern, dim3((unsigned)tln_cdiv(chunks, 4), (unsigned)n), dim3(256), lds, s, jobs, min_points, mp.w[0],
+                     mp.b[0], mp.w[1], mp.b[1], mp.w[2], mp.b[2]);
   TLN_LAUNCH_CHECK();
   return TLN_OK;
 }
@@ -687,6 +714,36 @@ extern "C" int tln_pool_config(int mfma) {
   return TLN_OK;
 }
 
+// the bins route for 1..TLN_POOL_MAXJOBS frames that share the MLP: *taken = false when the shape has no bins kernel
+static int pool_bins_jobs(PoolJobs& jobs, int n, int nr_layers, const float* const* d_w, const float* const* d_b,
+                          const int* dims, int min_points, bool* taken, hipStream_t s) {
+  const int cin = dims[0], cout = dims[nr_layers];
+  int rc = TLN_OK;
+  for (int i = n; i < TLN_POOL_MAXJOBS; ++i) jobs.j[i] = jobs.j[0];   // (never indexed: the grids have n rows)
+#define POOLB_CASE(CI, A, B, CO) rc = launch_pool_bins<CI, A, B, CO>(jobs, n, d_w, d_b, min_points, s)
+  *taken = true;
+  const bool wide = n == 1 && nr_layers == 3 && dims[1] == 16 && dims[2] == 32 && dims[3] == 64 && pool_mfma();
+  const PoolJob& j0 = jobs.j[0];
+  if (wide && cin == 4) rc = launch_pool_bins_mfma<4>(j0.bn, j0.rows, d_w, d_b, min_points, j0.packed, j0.out, j0.argrow, s);
+  else if (wide && cin == 3) rc = launch_pool_bins_mfma<3>(j0.bn, j0.rows, d_w, d_b, min_points, j0.packed, j0.out, j0.argrow, s);
+  else if (nr_layers == 3 && cin == 4 && dims[1] == 16 && dims[2] == 32 && dims[3] == 64) POOLB_CASE(4, 16, 32, 64);
+  else if (nr_layers == 2 && cin == 4 && dims[1] == 16 && dims[2] == 32) POOLB_CASE(4, 16, 0, 32);
+  else if (nr_layers == 3 && cin == 3 && dims[1] == 16 && dims[2] == 32 && dims[3] == 64) POOLB_CASE(3, 16, 32, 64);
+  else if (nr_layers == 0 && cin == 4) POOLB_CASE(4, 0, 0, 4);
+  else if (nr_layers == 0 && cin == 3) POOLB_CASE(3, 0, 0, 3);
+  else *taken = false;
+#undef POOLB_CASE
+  if (!*taken || rc) return rc;
+  int nvmax = 0;
+  for (int i = 0; i < n; ++i)
+    if (jobs.j[i].nv > nvmax) nvmax = jobs.j[i].nv;
+  const int64_t total = (int64_t)nvmax * cout;
+  hipLaunchKernelGGL(k_pool_bins_finalize, dim3((unsigned)tln_cdiv(total, 256), (unsigned)n), dim3(256), 0, s, jobs, cout,
+                     min_points);
+  TLN_LAUNCH_CHECK();
+  return TLN_OK;
+}
+
 extern "C" int tln_pointnet_pool_ex(tln_lattice_t* l, const float* d_distributed, int64_t rows, int dist_cols,
                                     int nr_layers, const float* const* d_w, const float* const* d_b, const int* dims,
                                     int min_points, float* d_out, int32_t* d_argrow, void* stream_) {
@@ -702,26 +759,11 @@ extern "C" int tln_pointnet_pool_ex(tln_lattice_t* l, const float* d_distributed
   // the rows of this very frame's distribute: pool them from the vertex bins (no sorted row list, no [4N,5] reads)
   TlnBins bn;
   if (cin <= 4 && dist_cols == 5 && tln_lat_bins(l, d_distributed, rows, &bn)) {
-#define POOLB_CASE(CI, A, B, CO) rc = launch_pool_bins<CI, A, B, CO>(bn, rows, d_w, d_b, min_points, packed, d_out, d_argrow, s)
-    bool taken = true;
-    const bool wide = nr_layers == 3 && dims[1] == 16 && dims[2] == 32 && dims[3] == 64 && pool_mfma();
-    if (wide && cin == 4) rc = launch_pool_bins_mfma<4>(bn, rows, d_w, d_b, min_points, packed, d_out, d_argrow, s);
-    else if (wide && cin == 3) rc = launch_pool_bins_mfma<3>(bn, rows, d_w, d_b, min_points, packed, d_out, d_argrow, s);
-    else if (nr_layers == 3 && cin == 4 && dims[1] == 16 && dims[2] == 32 && dims[3] == 64) POOLB_CASE(4, 16, 32, 64);
-    else if (nr_layers == 2 && cin == 4 && dims[1] == 16 && dims[2] == 32) POOLB_CASE(4, 16, 0, 32);
-    else if (nr_layers == 3 && cin == 3 && dims[1] == 16 && dims[2] == 32 && dims[3] == 64) POOLB_CASE(3, 16, 32, 64);
-    else if (nr_layers == 0 && cin == 4) POOLB_CASE(4, 0, 0, 4);
-    else if (nr_layers == 0 && cin == 3) POOLB_CASE(3, 0, 0, 3);
-    else taken = false;
-#undef POOLB_CASE
-    if (taken) {
-      if (rc) return rc;
-      const int64_t total = (int64_t)nv * cout;
-      hipLaunchKernelGGL(k_pool_bins_finalize, dim3((unsigned)tln_cdiv(total, 256)), dim3(256), 0, s, packed, bn, nv, cout,
-                         rows, min_points, d_out, d_argrow);
-      TLN_LAUNCH_CHECK();
-      return TLN_OK;
-    }
+    PoolJobs jobs;
+    jobs.j[0] = PoolJob{bn, rows, packed, d_out, d_argrow, nv};
+    bool taken = false;
+    rc = pool_bins_jobs(jobs, 1, nr_layers, d_w, d_b, dims, min_points, &taken, s);
+    if (taken) return rc;
   }
   TLN_REQUIRE(d_distributed, "the pool needs the distributed rows (or the bins of this frame's distribute)");
   TLN_REQUIRE(tln_lat_csr_rows(l) == rows, "pool needs the CSR of a tln_build_csr call over the same %lld rows",
@@ -751,6 +793,41 @@ extern "C" int tln_pointnet_pool(tln_lattice_t* l, const float* d_distributed, i
                                  int min_points, float* d_out, void* stream_) {
   return tln_pointnet_pool_ex(l, d_distributed, rows, dist_cols, nr_layers, d_w, d_b, dims, min_points, d_out, nullptr,
                               stream_);
+}
+
+// the pools of n lock-stepped sequences (same MLP, each lattice's own bins) as one launch per kernel; calls that cannot
+// take the bins route (rows edited by the caller, unsupported shape) go through tln_pointnet_pool one by one
+extern "C" int tln_pointnet_pool_multi(const tln_pool_call* c, int n, int dist_cols, int nr_layers, const float* const* d_w,
+                                       const float* const* d_b, const int* dims, int min_points, void* stream_) {
+  TLN_REQUIRE(c && n >= 1 && dims, "null argument");
+  hipStream_t s = (hipStream_t)stream_;
+  const int cin = dims[0], cout = dims[nr_layers];
+  bool batch = n >= 2 && n <= TLN_POOL_MAXJOBS && cin <= 4 && dist_cols == 5;
+  PoolJobs jobs;
+  for (int i = 0; i < n && batch; ++i) {
+    TLN_REQUIRE(c[i].l && c[i].d_out, "null argument");
+    const int nv = (int)tln_lattice_nr_vertices(c[i].l);
+    TlnBins bn;
+    if (nv <= 0 || !tln_lat_bins(c[i].l, c[i].d_distributed, c[i].rows, &bn)) {
+      batch = false;
+      break;
+    }
+    unsigned long long* packed = nullptr;
+    int rc = tln_lat_pool_ws(c[i].l, (int64_t)nv * cout, &packed);
+    if (rc) return rc;
+    jobs.j[i] = PoolJob{bn, c[i].rows, packed, c[i].d_out, nullptr, nv};
+  }
+  if (batch) {
+    bool taken = false;
+    int rc = pool_bins_jobs(jobs, n, nr_layers, d_w, d_b, dims, min_points, &taken, s);
+    if (taken) return rc;
+  }
+  for (int i = 0; i < n; ++i) {
+    int rc = tln_pointnet_pool(c[i].l, c[i].d_distributed, c[i].rows, dist_cols, nr_layers, d_w, d_b, dims, min_points,
+                               c[i].d_out, stream_);
+    if (rc) return rc;
+  }
+  return TLN_OK;
 }
 
 // ---------------------------------------------------------------------------------------

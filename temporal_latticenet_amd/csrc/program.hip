@@ -27,6 +27,27 @@ __global__ void __launch_bounds__(256) k_copy_rows(const float* __restrict__ src
   *reinterpret_cast<float4*>(dst + r * ld_dst + c) = v;
 }
 
+// the same for up to eight copies of one width (lock-stepped sequences): blockIdx.y = copy
+struct CopyJobs {
+  struct {
+    const float* src;
+    float* dst;
+    int64_t ld_src, ld_dst, rows;
+    int zero_row0;
+  } j[8];
+};
+__global__ void __launch_bounds__(256) k_copy_rows_multi(const CopyJobs jobs, int cols) {
+  const auto& J = jobs.j[blockIdx.y];
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c4 = cols >> 2;
+  const int64_t r = gid / c4;
+  if (r >= J.rows) return;
+  const int c = (int)(gid - r * c4) * 4;
+  float4 v = *reinterpret_cast<const float4*>(J.src + r * J.ld_src + c);
+  if (J.zero_row0 && r == 0) v = make_float4(0.f, 0.f, 0.f, 0.f);
+  *reinterpret_cast<float4*>(J.dst + r * J.ld_dst + c) = v;
+}
+
 namespace {
 
 constexpr size_t kAlign = 256;
@@ -163,6 +184,21 @@ struct tln_program {
   // pair mode (tln_program_run_pair): the walk stops at every gather-GEMM with its resolved call left here
   bool defer = false, has_pending = false;
   GemmCall pending{};
+  // group mode: the walk also stops at every op that has a batched form (pend_kind = its TLN_OP_*, pend_op = its index)
+  // with the resolved arguments left here; launch_pending issues the op of all programs of the group as ONE launch
+  int pend_kind = 0, pend_op = -1;
+  float* pend_pool_out = nullptr;
+  tln_gn_partials_call pend_gn{};
+  tln_gru_call pend_gru{};
+  tln_aflow_call pend_aflow{};
+  tln_slice_call pend_slice{};
+  struct {
+    const float* src;
+    int64_t ld_src;
+    float* dst;
+    int64_t ld_dst, rows;
+    int cols, zero_row0;
+  } pend_copy{};
   int w_next = 0;  // where the next walk continues
   float* aux_out = nullptr;   // where the slice head of the NEXT run also writes log-softmax(scores) (tln_program_set_aux_out)
   // segmented run (tln_program_run_begin / _until / _end: frame-sharded multi-GPU, dist.py)
@@ -354,6 +390,8 @@ int walk(tln_program* p, bool dry, int early, float* d_out, int64_t out_rows, in
                                 fptr(o.out) + o.out_col, so.cols, o.stats_out >= 0 ? p->rt[o.stats_out].ptr : nullptr};
           if (!p->pending.two) p->pending.a[1] = tln_gemm_src{};
           p->has_pending = true;
+          p->pend_kind = TLN_OP_GEMM;
+          p->pend_op = oi;
           stop_here = true;
           break;
         }
@@ -372,6 +410,14 @@ int walk(tln_program* p, bool dry, int early, float* d_out, int64_t out_rows, in
       case TLN_OP_GN_PARTIALS: {
         if (dry) break;
         const tln_slot& ss = p->slots[o.s0.slot];
+        if (p->defer) {
+          p->pend_gn = tln_gn_partials_call{fptr(o.s0.slot), p->rt[o.s0.slot].rows, p->rt[o.stats_out].ptr};
+          p->has_pending = true;
+          p->pend_kind = TLN_OP_GN_PARTIALS;
+          p->pend_op = oi;
+          stop_here = true;
+          break;
+        }
         if (p->rt[o.s0.slot].rows > 0) {
           rc = tln_groupnorm_partials(fptr(o.s0.slot), p->rt[o.s0.slot].rows, ss.cols, p->rt[o.stats_out].ptr, s);
           if (rc) return rc;
@@ -384,6 +430,14 @@ int walk(tln_program* p, bool dry, int early, float* d_out, int64_t out_rows, in
         const float* w[4] = {o.p[0], o.p[1], o.p[2], o.p[3]};
         const float* b[4] = {o.p[4], o.p[5], o.p[6], o.p[7]};
         int dims[6] = {o.i[1], o.i[2], o.i[3], o.i[4], o.i[5], 0};
+        if (p->defer) {
+          p->pend_pool_out = fptr(o.out);
+          p->has_pending = true;
+          p->pend_kind = TLN_OP_POOL;
+          p->pend_op = oi;
+          stop_here = true;
+          break;
+        }
         if (p->timing) TLN_HIP(hipEventRecord(p->tev[2], s));
         rc = tln_pointnet_pool(p->lat, p->d_dist, 4 * p->N, p->dist_cols, nl, w, b, dims, o.i[6], fptr(o.out), s);
         if (rc) return rc;
@@ -398,6 +452,15 @@ int walk(tln_program* p, bool dry, int early, float* d_out, int64_t out_rows, in
         const int Cn = p->slots[o.out].cols;
         want_scratch(0, (size_t)p->rt[o.out].rows_b * 6 * Cn * sizeof(float));
         if (dry) break;
+        if (p->defer && !p->capture) {
+          p->pend_gru = tln_gru_call{fptr(o.s0.slot), fptr(o.s1.slot), Vr, p->rt[o.s1.slot].rows, fptr(o.out),
+                                     reinterpret_cast<float*>(scratch[0]), Vr * 6 * Cn};
+          p->has_pending = true;
+          p->pend_kind = TLN_OP_GRU;
+          p->pend_op = oi;
+          stop_here = true;
+          break;
+        }
         rc = tln_gru_cell(fptr(o.s0.slot), fptr(o.s1.slot), Vr, p->rt[o.s1.slot].rows, Cn, o.p[0], o.p[1], o.p[2], o.p[3],
                           fptr(o.out), reinterpret_cast<float*>(scratch[0]), Vr * 6 * Cn, s);
         if (rc) return rc;
@@ -429,6 +492,15 @@ int walk(tln_program* p, bool dry, int early, float* d_out, int64_t out_rows, in
         TLN_REQUIRE(p->levels[o.s0.level], "op %d: level %d does not exist", oi, o.s0.level);
         rc = tln_neighbour_table(p->levels[o.s0.level], &tp, s);
         if (rc) return rc;
+        if (p->defer) {
+          p->pend_aflow = tln_aflow_call{fptr(o.s0.slot), fptr(o.s1.slot), Vr, p->rt[o.s1.slot].rows, tp, fptr(o.out),
+                                         reinterpret_cast<float*>(scratch[0]), reinterpret_cast<int32_t*>(scratch[1])};
+          p->has_pending = true;
+          p->pend_kind = TLN_OP_AFLOW;
+          p->pend_op = oi;
+          stop_here = true;
+          break;
+        }
         rc = tln_aflow(fptr(o.s0.slot), fptr(o.s1.slot), Vr, p->rt[o.s1.slot].rows, Cn, tp, o.f[0], o.f[1], o.f[2],
                        o.i[0], o.bias, fptr(o.out), reinterpret_cast<float*>(scratch[0]),
                        reinterpret_cast<int32_t*>(scratch[1]), s);
@@ -461,6 +533,17 @@ int walk(tln_program* p, bool dry, int early, float* d_out, int64_t out_rows, in
       }
       case TLN_OP_SLICE_DEFORM: {
         if (dry) break;
+        if (p->defer) {
+          const int ncls = p->slots[o.s1.slot].cols;
+          p->pend_slice = tln_slice_call{fptr(o.s0.slot), fptr(o.s1.slot), p->rt[o.s1.slot].rows, p->d_idx, p->d_w, p->N,
+                                         fptr(o.out), ncls <= 64 ? p->aux_out : nullptr};
+          p->aux_out = nullptr;
+          p->has_pending = true;
+          p->pend_kind = TLN_OP_SLICE_DEFORM;
+          p->pend_op = oi;
+          stop_here = true;
+          break;
+        }
         if (p->timing && !p->tset[2]) {
           TLN_HIP(hipEventRecord(p->tev[4], s));
           p->tset[2] = true;
@@ -514,6 +597,20 @@ int walk(tln_program* p, bool dry, int early, float* d_out, int64_t out_rows, in
           float* dp = fptr(o.out) + o.out_col;
           const bool vec = ss.cols % 4 == 0 && so.cols % 4 == 0 && o.out_col % 4 == 0 &&
                            (reinterpret_cast<uintptr_t>(sp) & 15) == 0 && (reinterpret_cast<uintptr_t>(dp) & 15) == 0;
+          if (vec && p->defer) {
+            p->pend_copy.src = sp;
+            p->pend_copy.ld_src = ss.cols;
+            p->pend_copy.dst = dp;
+            p->pend_copy.ld_dst = so.cols;
+            p->pend_copy.rows = rows;
+            p->pend_copy.cols = ss.cols;
+            p->pend_copy.zero_row0 = o.i[0];
+            p->has_pending = true;
+            p->pend_kind = TLN_OP_COPY;
+            p->pend_op = oi;
+            stop_here = true;
+            break;
+          }
           if (vec) {
             const int64_t total = rows * (ss.cols / 4);
             hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)tln_cdiv(total, 256)), dim3(256), 0, s, sp, (int64_t)ss.cols, dp,
@@ -767,9 +864,30 @@ extern "C" int tln_program_begin_frame_group(tln_program_t* const* pp, tln_latti
     p0->tset[0] = true;
   }
   for (int k = 0; k < count; ++k) frame_started(pp[k], ll[k], n[k], val_dim);
+  // second halves: every lattice's vertex counters (one wait: the batch shares an event), then the coarse levels of all
+  // of them extended by one batch of launches
   for (int k = 0; k < count; ++k) {
-    rc = tln_program_begin_frame_finish(pp[k], v_out + (size_t)k * TLN_MAX_LEVELS, s);
+    pp[k]->frame_started = false;
+    rc = tln_distribute_finish(ll[k], s);
     if (rc) return rc;
+    TLN_REQUIRE(pp[k]->n_coarse == p0->n_coarse, "the programs of a group differ in their level count");
+  }
+  int64_t vb[8 * TLN_MAX_LEVELS] = {0};
+  rc = tln_lattice_prepare_levels_begin_multi(ll, count, p0->n_coarse, vb, s);
+  if (rc) return rc;
+  for (int k = 0; k < count; ++k) {
+    tln_program* p = pp[k];
+    p->exact_known = p->n_coarse == 0;
+    tln_lattice_t* lv = ll[k];
+    for (int i = 0; i <= p->n_coarse; ++i) {
+      TLN_REQUIRE(lv, "level %d does not exist", i);
+      p->levels[i] = lv;
+      p->Vb[i] = vb[(size_t)k * TLN_MAX_LEVELS + i];
+      p->V[i] = i == 0 ? p->Vb[0] : -1;
+      v_out[(size_t)k * TLN_MAX_LEVELS + i] = p->Vb[i];
+      lv = tln_lattice_coarse_level(lv);
+    }
+    p->frame_open = true;
   }
   return TLN_OK;
 }
@@ -979,7 +1097,7 @@ extern "C" int tln_program_state_get_new(tln_program_t* p, int id, float* d_out,
 namespace {
 constexpr int kMaxGroup = 8;
 
-int launch_pending(tln_program* const* pp, int n, hipStream_t s) {
+int launch_pending_gemms(tln_program* const* pp, int n, hipStream_t s) {
   tln_gemm_call calls[kMaxGroup];
   int m = 0;
   for (int k = 0; k < n; ++k)
@@ -992,7 +1110,132 @@ int launch_pending(tln_program* const* pp, int n, hipStream_t s) {
   for (int k = 0; k < n; ++k) {
     tln_program* p = pp[k];
     if (p->has_pending && p->capture && p->pending.M > 0) p->calls.push_back(p->pending);
-    p->has_pending = false;
+  }
+  return rc;
+}
+
+// The op every program of the group stopped at, issued for all of them together: the products through
+// tln_gather_gemm_multi, every other kind through its batched entry point (one launch, blockIdx.y / .z = sequence).  The
+// batched forms share the op's parameters (weights, biases): programs compiled from different weights, or stopped at
+// different ops, are served one by one with the same calls.
+int launch_pending(tln_program* const* pp, int n, hipStream_t s) {
+  tln_program* q[kMaxGroup];
+  int m = 0;
+  for (int k = 0; k < n; ++k)
+    if (pp[k]->has_pending) q[m++] = pp[k];
+  if (m == 0) return TLN_OK;
+  bool same = true;
+  for (int k = 1; k < m; ++k) same = same && q[k]->pend_kind == q[0]->pend_kind && q[k]->pend_op == q[0]->pend_op;
+  int rc = TLN_OK;
+  // [b, e) = the programs served by one call
+  for (int b = 0; b < m && !rc;) {
+    int e = b + 1;
+    const tln_op& o = q[b]->ops[q[b]->pend_op];
+    auto same_params = [&](const tln_op& x) {
+      bool eq = x.bias == o.bias && x.w == o.w;
+      for (int i = 0; i < 8; ++i) eq = eq && x.p[i] == o.p[i] && x.i[i] == o.i[i];
+      for (int i = 0; i < 4; ++i) eq = eq && x.f[i] == o.f[i];
+      return eq;
+    };
+    if (same)
+      while (e < m && (q[b]->pend_kind == TLN_OP_GEMM || same_params(q[e]->ops[q[e]->pend_op]))) ++e;
+    const int cnt = e - b;
+    tln_program* p0 = q[b];
+    switch (p0->pend_kind) {
+      case TLN_OP_GEMM:
+        rc = launch_pending_gemms(q + b, cnt, s);
+        break;
+      case TLN_OP_GN_PARTIALS: {
+        tln_gn_partials_call c[kMaxGroup];
+        for (int k = 0; k < cnt; ++k) c[k] = q[b + k]->pend_gn;
+        rc = tln_groupnorm_partials_multi(c, cnt, p0->slots[o.s0.slot].cols, s);
+        break;
+      }
+      case TLN_OP_POOL: {
+        tln_pool_call c[kMaxGroup];
+        for (int k = 0; k < cnt; ++k)
+          c[k] = tln_pool_call{q[b + k]->lat, q[b + k]->d_dist, 4 * q[b + k]->N, q[b + k]->pend_pool_out};
+        const float* w[4] = {o.p[0], o.p[1], o.p[2], o.p[3]};
+        const float* bb[4] = {o.p[4], o.p[5], o.p[6], o.p[7]};
+        int dims[6] = {o.i[1], o.i[2], o.i[3], o.i[4], o.i[5], 0};
+        tln_program* t0 = pp[0];   // stage timing of a group lives on its first program
+        if (t0->timing) TLN_HIP(hipEventRecord(t0->tev[2], s));
+        rc = tln_pointnet_pool_multi(c, cnt, p0->dist_cols, o.i[0], w, bb, dims, o.i[6], s);
+        if (!rc && t0->timing) {
+          TLN_HIP(hipEventRecord(t0->tev[3], s));
+          t0->tset[1] = true;
+        }
+        break;
+      }
+      case TLN_OP_GRU: {
+        tln_gru_call c[kMaxGroup];
+        for (int k = 0; k < cnt; ++k) c[k] = q[b + k]->pend_gru;
+        rc = tln_gru_cell_multi(c, cnt, p0->slots[o.out].cols, o.p[0], o.p[1], o.p[2], o.p[3], s);
+        break;
+      }
+      case TLN_OP_AFLOW: {
+        tln_aflow_call c[kMaxGroup];
+        for (int k = 0; k < cnt; ++k) c[k] = q[b + k]->pend_aflow;
+        rc = tln_aflow_multi(c, cnt, p0->slots[o.out].cols, o.f[0], o.f[1], o.f[2], o.i[0], o.bias, s);
+        break;
+      }
+      case TLN_OP_SLICE_DEFORM: {
+        tln_slice_call c[kMaxGroup];
+        bool ls = p0->pend_slice.d_logsm != nullptr, mixed = false;
+        for (int k = 0; k < cnt; ++k) {
+          c[k] = q[b + k]->pend_slice;
+          mixed = mixed || ((c[k].d_logsm != nullptr) != ls);
+        }
+        tln_program* t0 = pp[0];
+        if (t0->timing && !t0->tset[2]) {
+          TLN_HIP(hipEventRecord(t0->tev[4], s));
+          t0->tset[2] = true;
+        }
+        const int cb = p0->slots[o.s0.slot].cols, ncls = p0->slots[o.s1.slot].cols;
+        if (!mixed) {
+          rc = tln_slice_deform_multi(c, cnt, cb, ncls, o.p[0], o.p[1], o.p[2], o.bias, s);
+        } else {
+          for (int k = 0; k < cnt && !rc; ++k) rc = tln_slice_deform_multi(c + k, 1, cb, ncls, o.p[0], o.p[1], o.p[2], o.bias, s);
+        }
+        if (!rc && t0->timing) TLN_HIP(hipEventRecord(t0->tev[5], s));
+        break;
+      }
+      case TLN_OP_COPY: {
+        // copies of one width in one launch; other widths (never, in one model) one by one
+        int done = b;
+        while (done < e) {
+          CopyJobs jobs;
+          const int cols = q[done]->pend_copy.cols;
+          int64_t rmax = 0;
+          int mm = 0;
+          while (done + mm < e && q[done + mm]->pend_copy.cols == cols && mm < 8) {
+            const auto& pc = q[done + mm]->pend_copy;
+            jobs.j[mm].src = pc.src;
+            jobs.j[mm].dst = pc.dst;
+            jobs.j[mm].ld_src = pc.ld_src;
+            jobs.j[mm].ld_dst = pc.ld_dst;
+            jobs.j[mm].rows = pc.rows;
+            jobs.j[mm].zero_row0 = pc.zero_row0;
+            if (pc.rows > rmax) rmax = pc.rows;
+            ++mm;
+          }
+          for (int i = mm; i < 8; ++i) jobs.j[i] = jobs.j[0];
+          hipLaunchKernelGGL(k_copy_rows_multi, dim3((unsigned)tln_cdiv(rmax * (cols / 4), 256), (unsigned)mm), dim3(256), 0, s,
+                             jobs, cols);
+          TLN_LAUNCH_CHECK();
+          done += mm;
+        }
+        break;
+      }
+      default:
+        tln_set_error("group mode: op kind %d has no batched form", p0->pend_kind);
+        rc = TLN_E_INVALID;
+    }
+    b = e;
+  }
+  for (int k = 0; k < n; ++k) {
+    pp[k]->has_pending = false;
+    pp[k]->pend_kind = 0;
   }
   return rc;
 }
@@ -1047,10 +1290,15 @@ extern "C" int tln_program_run_group(tln_program_t* const* pp, int n, int early,
   }
   if (rc) return rc;
   rc = walk_group(pp, n, early, d_out, out_rows, out_cols, s, 0, pp[0]->split, true);
+  {
+    // the exact coarse counts of every sequence (one wait) and the coarse tables of all of them in one batch of launches
+    tln_lattice_t* lats[kMaxGroup];
+    for (int k = 0; k < n; ++k) lats[k] = pp[k]->lat;
+    int rc2 = tln_lattice_prepare_levels_finish_multi(lats, n, s);
+    if (rc == TLN_OK) rc = rc2;
+  }
   for (int k = 0; k < n; ++k) {
     tln_program* p = pp[k];
-    int rc2 = tln_lattice_prepare_levels_finish(p->lat, s);
-    if (rc == TLN_OK) rc = rc2;
     if (rc == TLN_OK) {
       for (int i = 1; i <= p->n_coarse; ++i) {
         p->V[i] = tln_lattice_nr_vertices(p->levels[i]);

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """K1 (distribute) alone: the frames of G lock-stepped sequences through one batch of launches
 (tln_distribute_begin_multi) against G single calls, per frame of a 4-frame sequence of 120k-point scans.
-  python tools/k1_bench.py [G=8] [reps=10]        env TLN_BK_ROWS / TLN_BK_PPB: bucket geometry overrides
+  python tools/k1_bench.py [G=8] [reps=10] [batched|single|both]        env TLN_BK_ROWS / TLN_BK_PPB: bucket geometry overrides
 Prints microseconds per frame (amortised over the group) and the algorithmic-bytes rate (128 N bytes per frame)."""
 import os
 import sys
@@ -17,6 +17,7 @@ from temporal_latticenet_amd.workload import turned  # noqa: E402
 def main():
     G = int(sys.argv[1]) if len(sys.argv) > 1 else 8
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+    mode = sys.argv[3] if len(sys.argv) > 3 else "both"       # batched | single | both
     N, T = 120000, 4
     drive = [(torch.from_numpy(p).cuda(), torch.from_numpy(v).cuda()) for p, v in make_sequence(N, T)]
     seqs = [turned(drive, j) for j in range(G)]
@@ -51,6 +52,8 @@ def main():
                                           idx[k].data_ptr(), wts[k].data_ptr(), stream_ptr()), "distribute")
 
     for name, fn in (("batched", batch), ("single ", single)):
+        if mode != "both" and mode != name.strip():
+            continue
         for t in range(T):
             fn(t)
         torch.cuda.synchronize()

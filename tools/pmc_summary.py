@@ -41,7 +41,7 @@ def main():
     g = [r for r in rows if r[0].startswith("k_gather_gemm")]
     n = sum(r[1] for r in g)
     total = sum(r[4] * r[1] for r in g)
-    summary = {"kernel": "k_gather_gemm", "launches": n, "hbm_bytes_per_launch": total / n,
+    summary = {"kernel": "k_gather_gemm", "launches": n, "hbm_bytes_per_launch": total / n if n else None,
                "correction": "2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950: FETCH_SIZE halves wide reads)"}
     # the scatter / gather stages: HBM-side bytes per FRAME (sum over the stage's kernels / frames profiled).  K1 =
     # the partitioned kernels (k_bk_*) or, with TLN_K1_LEGACY=1, the per-row-atomic ones.
