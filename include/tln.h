@@ -531,6 +531,9 @@ int tln_program_run_pair(tln_program_t* a, tln_program_t* b, int early, float* d
 /* the same for a group of n = 1..8 programs (tln_gather_gemm_multi) */
 int tln_program_run_group(tln_program_t* const* programs, int n, int early, float* const* d_out,
                           const int64_t* out_rows, int out_cols, void* stream);
+/* test / measurement switch for group mode: bit k of off_mask set = ops of kind k (TLN_OP_*) are launched per program
+ * instead of as one batch for the group; bit 0 = the K1 / coarse-level / table batches.  0 = everything batched. */
+int tln_program_group_config(int off_mask);
 /* device pointers of the current frame's K1 outputs ([4N, 3+val_dim+1], [4N], [4N]); valid until the next frame */
 int tln_program_frame_rows(tln_program_t* p, const float** d_distributed, const int32_t** d_indices,
                            const float** d_weights, int64_t* rows, int* cols);

@@ -329,12 +329,15 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
     for (int r = 0; r < 16; ++r) {
       const int64_t m = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * half;
       // (hardware exp2 / reciprocal: 1-2 ulp, far inside the 1e-4 the outputs are held to; tanh(x) = 1 - 2 / (1 + e^2x))
+      // every multiply-add spelled out as ONE fused operation: left to the compiler's contraction, the single-cell and the
+      // batched instantiation of this body (k_gather_gemm_v2_gru / _gru_multi) fused different ones and differed in the
+      // last bit — a lock-step group must compute exactly what its sequences compute alone
       const float rr = __frcp_rn(1.0f + __expf(-(acc[0][0][r] + br)));
       const float zz = __frcp_rn(1.0f + __expf(-(acc[0][1][r] + bz)));
-      const float na = (acc[0][2][r] + bni) + rr * (acc[0][3][r] + bnh);
-      const float nn = 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * na));
+      const float na = fmaf(rr, acc[0][3][r] + bnh, acc[0][2][r] + bni);
+      const float nn = fmaf(-2.0f, __frcp_rn(1.0f + __expf(2.0f * na)), 1.0f);
       const float hp = m < hrows ? hv[r] : 0.0f;
-      if (m < g.M) g.out[m * g.ld_out + ch] = (1.0f - zz) * nn + zz * hp;
+      if (m < g.M) g.out[m * g.ld_out + ch] = fmaf(zz, hp, __fmul_rn(1.0f - zz, nn));
     }
     return;
   }

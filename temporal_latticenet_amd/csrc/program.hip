@@ -48,6 +48,16 @@ __global__ void __launch_bounds__(256) k_copy_rows_multi(const CopyJobs jobs, in
   *reinterpret_cast<float4*>(J.dst + r * J.ld_dst + c) = v;
 }
 
+// group mode: bit k set = ops of kind k (TLN_OP_*) are NOT batched over the group but launched per program, as before
+// round 3 (test / measurement switch; env TLN_GROUP_BATCH_OFF at load, tln_program_group_config at run time).  Bit 0:
+// the K1 / coarse-level batches of tln_program_begin_frame_group and the table batch of tln_program_run_group.
+static int g_group_off = getenv("TLN_GROUP_BATCH_OFF") ? atoi(getenv("TLN_GROUP_BATCH_OFF")) : 0;
+extern "C" int tln_program_group_config(int off_mask) {
+  g_group_off = off_mask;
+  return TLN_OK;
+}
+static inline bool group_batches(int kind) { return ((g_group_off >> kind) & 1) == 0; }
+
 namespace {
 
 constexpr size_t kAlign = 256;
@@ -410,7 +420,7 @@ int walk(tln_program* p, bool dry, int early, float* d_out, int64_t out_rows, in
       case TLN_OP_GN_PARTIALS: {
         if (dry) break;
         const tln_slot& ss = p->slots[o.s0.slot];
-        if (p->defer) {
+        if (p->defer && group_batches(TLN_OP_GN_PARTIALS)) {
           p->pend_gn = tln_gn_partials_call{fptr(o.s0.slot), p->rt[o.s0.slot].rows, p->rt[o.stats_out].ptr};
           p->has_pending = true;
           p->pend_kind = TLN_OP_GN_PARTIALS;
@@ -430,7 +440,7 @@ int walk(tln_program* p, bool dry, int early, float* d_out, int64_t out_rows, in
         const float* w[4] = {o.p[0], o.p[1], o.p[2], o.p[3]};
         const float* b[4] = {o.p[4], o.p[5], o.p[6], o.p[7]};
         int dims[6] = {o.i[1], o.i[2], o.i[3], o.i[4], o.i[5], 0};
-        if (p->defer) {
+        if (p->defer && group_batches(TLN_OP_POOL)) {
           p->pend_pool_out = fptr(o.out);
           p->has_pending = true;
           p->pend_kind = TLN_OP_POOL;
@@ -452,7 +462,7 @@ int walk(tln_program* p, bool dry, int early, float* d_out, int64_t out_rows, in
         const int Cn = p->slots[o.out].cols;
         want_scratch(0, (size_t)p->rt[o.out].rows_b * 6 * Cn * sizeof(float));
         if (dry) break;
-        if (p->defer && !p->capture) {
+        if (p->defer && !p->capture && group_batches(TLN_OP_GRU)) {
           p->pend_gru = tln_gru_call{fptr(o.s0.slot), fptr(o.s1.slot), Vr, p->rt[o.s1.slot].rows, fptr(o.out),
                                      reinterpret_cast<float*>(scratch[0]), Vr * 6 * Cn};
           p->has_pending = true;
@@ -492,7 +502,7 @@ int walk(tln_program* p, bool dry, int early, float* d_out, int64_t out_rows, in
         TLN_REQUIRE(p->levels[o.s0.level], "op %d: level %d does not exist", oi, o.s0.level);
         rc = tln_neighbour_table(p->levels[o.s0.level], &tp, s);
         if (rc) return rc;
-        if (p->defer) {
+        if (p->defer && group_batches(TLN_OP_AFLOW)) {
           p->pend_aflow = tln_aflow_call{fptr(o.s0.slot), fptr(o.s1.slot), Vr, p->rt[o.s1.slot].rows, tp, fptr(o.out),
                                          reinterpret_cast<float*>(scratch[0]), reinterpret_cast<int32_t*>(scratch[1])};
           p->has_pending = true;
@@ -533,7 +543,7 @@ int walk(tln_program* p, bool dry, int early, float* d_out, int64_t out_rows, in
       }
       case TLN_OP_SLICE_DEFORM: {
         if (dry) break;
-        if (p->defer) {
+        if (p->defer && group_batches(TLN_OP_SLICE_DEFORM)) {
           const int ncls = p->slots[o.s1.slot].cols;
           p->pend_slice = tln_slice_call{fptr(o.s0.slot), fptr(o.s1.slot), p->rt[o.s1.slot].rows, p->d_idx, p->d_w, p->N,
                                          fptr(o.out), ncls <= 64 ? p->aux_out : nullptr};
@@ -597,7 +607,7 @@ int walk(tln_program* p, bool dry, int early, float* d_out, int64_t out_rows, in
           float* dp = fptr(o.out) + o.out_col;
           const bool vec = ss.cols % 4 == 0 && so.cols % 4 == 0 && o.out_col % 4 == 0 &&
                            (reinterpret_cast<uintptr_t>(sp) & 15) == 0 && (reinterpret_cast<uintptr_t>(dp) & 15) == 0;
-          if (vec && p->defer) {
+          if (vec && p->defer && group_batches(TLN_OP_COPY)) {
             p->pend_copy.src = sp;
             p->pend_copy.ld_src = ss.cols;
             p->pend_copy.dst = dp;
@@ -839,6 +849,18 @@ extern "C" int tln_program_begin_frame_group(tln_program_t* const* pp, tln_latti
                                              int64_t* v_out, void* stream_) {
   TLN_REQUIRE(pp && ll && d_positions && n && v_out && count >= 1 && count <= 8 && val_dim >= 0, "bad frame group");
   hipStream_t s = (hipStream_t)stream_;
+  if (!group_batches(0)) {   // every sequence by itself: all first halves, then all second halves
+    for (int k = 0; k < count; ++k) {
+      int rc = tln_program_begin_frame_start(pp[k], ll[k], d_positions[k], d_values ? d_values[k] : nullptr, n[k], val_dim,
+                                             reset_hashmap, subtract_mean, s);
+      if (rc) return rc;
+    }
+    for (int k = 0; k < count; ++k) {
+      int rc = tln_program_begin_frame_finish(pp[k], v_out + (size_t)k * TLN_MAX_LEVELS, s);
+      if (rc) return rc;
+    }
+    return TLN_OK;
+  }
   tln_distribute_call calls[8];
   for (int k = 0; k < count; ++k) {
     TLN_REQUIRE(pp[k] && ll[k] && d_positions[k] && n[k] > 0, "bad frame arguments (sequence %d)", k);
@@ -1294,7 +1316,10 @@ extern "C" int tln_program_run_group(tln_program_t* const* pp, int n, int early,
     // the exact coarse counts of every sequence (one wait) and the coarse tables of all of them in one batch of launches
     tln_lattice_t* lats[kMaxGroup];
     for (int k = 0; k < n; ++k) lats[k] = pp[k]->lat;
-    int rc2 = tln_lattice_prepare_levels_finish_multi(lats, n, s);
+    int rc2 = TLN_OK;
+    if (group_batches(0)) rc2 = tln_lattice_prepare_levels_finish_multi(lats, n, s);
+    else
+      for (int k = 0; k < n && !rc2; ++k) rc2 = tln_lattice_prepare_levels_finish(lats[k], s);
     if (rc == TLN_OK) rc = rc2;
   }
   for (int k = 0; k < n; ++k) {
