@@ -1508,6 +1508,32 @@ extern "C" int tln_program_replay_gemms_group(tln_program_t* const* pp, int n, i
     TLN_HIP(hipEventElapsedTime(&ms, e0, e1));
     *ms_total = ms;
   }
+  if (!rc && getenv("TLN_GEMM_DUMP")) {  // per-product table for tools/: 10 back-to-back shared launches of each product
+    for (size_t i = 0; i < nc; ++i) {
+      tln_gemm_call calls[8];
+      double fl = 0.0;
+      int64_t msum = 0, mmax = 0;
+      for (int k = 0; k < n; ++k) {
+        const GemmCall& c = pp[k]->calls[i];
+        calls[k] = tln_gemm_call{c.M, c.N, &c.a[0], c.two ? &c.a[1] : nullptr, c.w, c.w_is_nk, c.bias, c.res, c.ld_res,
+                                 c.relu, c.out, c.ld_out, c.stats};
+        const double K = (double)c.a[0].taps * c.a[0].cin + (c.two ? (double)c.a[1].taps * c.a[1].cin : 0.0);
+        fl += 2.0 * (double)c.M * K * c.N;
+        msum += c.M;
+        if (c.M > mmax) mmax = c.M;
+      }
+      TLN_HIP(hipEventRecord(e0, s));
+      for (int r = 0; r < 10; ++r) tln_gather_gemm_multi(calls, n, s);
+      TLN_HIP(hipEventRecord(e1, s));
+      TLN_HIP(hipEventSynchronize(e1));
+      float ms = 0.f;
+      TLN_HIP(hipEventElapsedTime(&ms, e0, e1));
+      const GemmCall& c = pp[0]->calls[i];
+      fprintf(stderr, "group gemm %3zu Msum=%7ld Mmax=%6ld N=%4d taps=%d cin=%4d two=%d gn=%d res=%d nk=%d  %8.2f us  %6.1f TF\n", i,
+              (long)msum, (long)mmax, c.N, c.a[0].taps, c.a[0].cin, (int)c.two, c.a[0].d_gn_partials ? 1 : 0, c.res ? 1 : 0,
+              c.w_is_nk, ms * 100.0, fl / (ms * 100.0e-6) * 1e-12);
+    }
+  }
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   if (rc) return rc;
