@@ -44,11 +44,14 @@ template <int WM, int WN, int TM, int TN, bool W_NK, bool PRO, bool GRU = false,
 __device__ __forceinline__ void v2_body(const GemmArgs& g) {
   constexpr int NT = 64 * WM * WN;
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
-  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
+  // (B: a thread count that does not divide the 16-byte pieces of the weight tile — the 96-row tile's 384 threads on a
+  // 128-column tile — rounds the pieces per thread up; the surplus pieces copy the zero buffer into slack behind the tile)
+  constexpr int A_PIECES = BM * 8 / NT, B_PIECES = (BN * 8 + NT - 1) / NT;
+  constexpr bool B_PAD = (BN * 8) % NT != 0;
+  constexpr int A_BYTES = BM * 128, B_BYTES = B_PIECES * NT * 16;
   constexpr int STAGE = A_BYTES + B_BYTES;
-  constexpr int A_PIECES = BM * 8 / NT, B_PIECES = BN * 8 / NT;
   constexpr int PIECES = A_PIECES + B_PIECES;
-  static_assert((BM * 8) % NT == 0 && (BN * 8) % NT == 0, "whole pieces per thread");
+  static_assert((BM * 8) % NT == 0, "whole A pieces per thread");
   static_assert(PIECES < 32, "vmcnt immediate");
 
   extern __shared__ __attribute__((aligned(16))) char smem2[];
@@ -159,13 +162,13 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
       if (!W_NK) {
         const int k = e / (BN / 4), nq = e - k * (BN / 4);
         const int n = n0 + 4 * nq;
-        ok = n < g.N;
-        data = Wp + (int64_t)(kbase + k) * g.ldw + (ok ? n : 0);
+        ok = n < g.N && (!B_PAD || e < BN * 8);
+        data = Wp + (int64_t)(kbase + (B_PAD ? (k & 31) : k)) * g.ldw + (ok ? n : 0);
       } else {
         const int r = e >> 3, q = e & 7;
         int n = n0 + r;
         if (GRU) n = ((r % 96) >> 5) * s.cin + 64 * (int)blockIdx.y + 32 * (r / 96) + (r & 31);
-        ok = n < g.N;
+        ok = n < g.N && (!B_PAD || e < BN * 8);
         data = Wp + (int64_t)(ok ? n : 0) * g.ldw + kbase + 4 * (q ^ ((r >> 1) & 7));
       }
       const float* src = ok ? data : zero;
@@ -451,10 +454,17 @@ static int v2_two_stage() {
   return v;
 }
 
+template <int WM, int WN, int TM, int TN, int STAGES>
+static size_t v2_lds_bytes(int cin) {
+  constexpr int NT = 64 * WM * WN, BM = 32 * TM * WM, BN = 32 * TN * WN;
+  constexpr int B_PIECES = (BN * 8 + NT - 1) / NT;
+  return (size_t)STAGES * (BM * 128 + B_PIECES * NT * 16) + (size_t)BM * TLN_TAPS * 4 + (size_t)2 * cin * 4 + (size_t)(BM + 32) * 4;
+}
+
 template <int WM, int WN, int TM, int TN, bool W_NK, bool PRO, int STAGES = V2_STAGES>
 static int launch_v2(GemmArgs& g, hipStream_t s) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
-  const size_t lds = (size_t)STAGES * (BM + BN) * 128 + (size_t)BM * TLN_TAPS * 4 + (size_t)2 * g.s[0].cin * 4 + (size_t)(BM + 32) * 4;
+  const size_t lds = v2_lds_bytes<WM, WN, TM, TN, STAGES>(g.s[0].cin);
   TLN_REQUIRE(lds <= 160 * 1024, "gemm v2: LDS %zu B", lds);
   auto kern = k_gather_gemm_v2<WM, WN, TM, TN, W_NK, PRO, STAGES>;
   static thread_local TlnLdsAttr attr;   // (one per template instantiation)
@@ -517,10 +527,23 @@ bool tln_gemm_v2_multi_ok(const GemmArgs* g, int n, bool w_is_nk, const bool* ve
   return total >= (multi_min > 0 ? multi_min : g_v2_min_m);
 }
 
+static int v2_cu_count() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      cus = prop.multiProcessorCount;
+    else
+      cus = 256;
+  }
+  return cus;
+}
+
 template <int WM, int WN, int TM, int TN, bool W_NK, bool PRO, int STAGES = V2_STAGES>
 static int launch_v2_multi(GemmArgs* g, int n, hipStream_t s) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
-  const size_t lds = (size_t)STAGES * (BM + BN) * 128 + (size_t)BM * TLN_TAPS * 4 + (size_t)2 * g[0].s[0].cin * 4 + (size_t)(BM + 32) * 4;
+  const size_t lds = v2_lds_bytes<WM, WN, TM, TN, STAGES>(g[0].s[0].cin);
   TLN_REQUIRE(lds <= 160 * 1024, "gemm v2: LDS %zu B", lds);
   auto kern = k_gather_gemm_v2_multi<WM, WN, TM, TN, W_NK, PRO, STAGES>;
   static thread_local TlnLdsAttr attr;   // (one per template instantiation)
@@ -543,6 +566,26 @@ static int dispatch_v2_multi(GemmArgs* g, int n, hipStream_t s) {
   const int nn = g[0].N;
   if (nn % 192 == 0) return launch_v2_multi<4, 2, 1, 3, W_NK, PRO>(g, n, s);
   if (nn % 128 == 0) {
+    // Tile height against the quantisation of the launch: two workgroups of this tile share a CU, and a CU's time is
+    // (workgroups it gets) x (rows per workgroup).  The lock-stepped level-1 products have 52k-72k rows together — 407 to
+    // 565 tiles of 128 rows on 256 CUs, i.e. "2 or 3 per CU" — so where the 128-row count lands just above a multiple
+    // of the CU count, 96-row tiles (six waves) finish the launch in 3 x 96 rows per CU instead of 3 x 128.
+    if constexpr (!W_NK && PRO) {
+      // MEASURED (round 3, 4 streams x 8): never 1314, by this model 1284, always 1212 clouds/s — a six-wave workgroup
+      // costs far more than 3/4 of an eight-wave one (three waves per SIMD instead of four while two workgroups share the
+      // CU), so the tile stays off unless asked for (TLN_V2_BM96: 0 never = default, 1 always, -1 model)
+      static const int env = getenv("TLN_V2_BM96") ? atoi(getenv("TLN_V2_BM96")) : 0;
+      int64_t w128 = 0, w96 = 0;
+      for (int i = 0; i < n; ++i) {
+        w128 += tln_cdiv(g[i].M, 128);
+        w96 += tln_cdiv(g[i].M, 96);
+      }
+      const int64_t cb = nn / 128;
+      const double t128 = (double)tln_cdiv(w128 * cb, v2_cu_count()) * 1.0;
+      const double t96 = (double)tln_cdiv(w96 * cb, v2_cu_count()) * 0.78;   // 0.75 of the rows + the fixed cost per workgroup
+      if ((v2_two_stage() & 1) && (env == 1 || (env != 0 && t96 < t128)))
+        return launch_v2_multi<3, 2, 1, 2, W_NK, PRO, 2>(g, n, s);
+    }
     return (v2_two_stage() & 1) ? launch_v2_multi<4, 2, 1, 2, W_NK, PRO, 2>(g, n, s) : launch_v2_multi<4, 2, 1, 2, W_NK, PRO>(g, n, s);
   }
   if (nn == 64)
