@@ -480,11 +480,13 @@ int tln_program_begin_frame_start(tln_program_t* p, tln_lattice_t* l, const floa
 int tln_program_begin_frame_finish(tln_program_t* p, int64_t* v_out, void* stream);
 /* the frames of `count` (1..8) lock-stepped sequences begun together: one batch of K1 launches for all of them
  * (tln_distribute_begin_multi), one wait for the vertex counters; v_out is [count][TLN_MAX_LEVELS].  With stage timing
- * on, programs[0] holds the events around the batched stages (tln_program_timing_read: duration of the batch). */
+ * on, programs[0] holds the events around the batched stages (tln_program_timing_read: duration of the batch).
+ * need_indices = 0: the frames will return early (tln_program_run_group with early != 0): the per-row vertex indices,
+ * which only the slice ops read, are not written. */
 int tln_program_begin_frame_group(tln_program_t* const* programs, tln_lattice_t* const* lattices,
                                   const float* const* d_positions, const float* const* d_values, const int64_t* n,
-                                  int count, int val_dim, int reset_hashmap, int subtract_mean, int64_t* v_out,
-                                  void* stream);
+                                  int count, int val_dim, int reset_hashmap, int subtract_mean, int need_indices,
+                                  int64_t* v_out, void* stream);
 /* the rest of the frame.  early != 0: stop at the program's STOP_IF_EARLY op and copy that slot to d_out;
  * else the TLN_SLOT_OUT slot is d_out.  d_out must hold out_rows x out_cols floats (checked). */
 int tln_program_run(tln_program_t* p, int early, float* d_out, int64_t out_rows, int out_cols, void* stream);

@@ -87,7 +87,7 @@ _PROTOS = {
     "tln_lattice_prepare_levels_finish_multi": (_i, [_vp, _i, _vp]),
     "tln_pointnet_pool_multi": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp]),
     "tln_program_group_config": (_i, [_i]),
-    "tln_program_begin_frame_group": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "tln_program_begin_frame_group": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "tln_lattice_nr_vertices": (_i64, [_vp]),
     "tln_lattice_capacity": (_i64, [_vp]),
     "tln_lattice_level": (_i, [_vp]),

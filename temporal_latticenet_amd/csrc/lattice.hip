@@ -1668,7 +1668,7 @@ struct BkJob {
   uint64_t slot_mask;
   int64_t n, rows, rpb;
   float s0, s1, s2;
-  int val_dim, ppb, B, nblk, shift, nr_words, vold, capacity, stamp;
+  int val_dim, ppb, B, nblk, shift, nr_words, vold, capacity, stamp, stage;
 };
 struct BkJobs {
   BkJob j[TLN_BK_MAXJOBS];
@@ -1742,8 +1742,12 @@ __global__ void __launch_bounds__(1024) k_bk_split(const BkJobs jobs) {
   if (tid == 0) off[(size_t)B * nblk + blockIdx.x] = total;
   __syncthreads();
   // the 16-byte records: weight, row, key.  The position / value of a row are re-read by k_bk_place from the frame's
-  // own arrays (1.9 MB, cache resident) — carrying them along made the record 32 bytes, written once and pulled twice
+  // own arrays (1.9 MB, cache resident) — carrying them along made the record 32 bytes, written once and pulled twice.
+  // They go to the block's region grouped by bucket THROUGH LDS (J.stage): scattered 16-byte stores to ~1000 runs per
+  // block reached memory as partial lines (2.3 x the bytes, PMC WRITE_SIZE); the staged image leaves as whole lines.
   uint4* region = J.rec + (size_t)blockIdx.x * (4 * (size_t)ppb);
+  uint4* stage = reinterpret_cast<uint4*>(bk_hist + ((B + 3) & ~3));
+  uint4* dst = J.stage ? stage : region;
   for (int64_t p = p0 + tid; p < p1; p += T) {
     const float x = pos[3 * p], y = pos[3 * p + 1], z = pos[3 * p + 2];
     int rem0[4], rank[4];
@@ -1755,8 +1759,13 @@ __global__ void __launch_bounds__(1024) k_bk_split(const BkJobs jobs) {
       vertex_key(rem0, rank, r, k0, k1, k2);
       const uint64_t K = tln_key_in_range(k0, k1, k2) ? tln_pack_key(k0, k1, k2) : TLN_KEY_EMPTY;
       const uint32_t at = atomicAdd(&bk_hist[bk_bucket(K, slot_mask, shift)], 1u);
-      region[at] = make_uint4(__float_as_uint(bary[r]), (uint32_t)(4 * p + r), (uint32_t)K, (uint32_t)(K >> 32));
+      dst[at] = make_uint4(__float_as_uint(bary[r]), (uint32_t)(4 * p + r), (uint32_t)K, (uint32_t)(K >> 32));
     }
+  }
+  if (J.stage) {
+    __syncthreads();
+    const int nrec = (int)(4 * (p1 - p0));
+    for (int i = tid; i < nrec; i += T) region[i] = stage[i];
   }
 }
 
@@ -2101,7 +2110,7 @@ __global__ void __launch_bounds__(TLN_BK_THREADS) __attribute__((amdgpu_waves_pe
     else dest = bin0 + P + atomicAdd(&s_tail, 1u);
     bin_rec[dest].a = a;   // (both halves of the 32-byte record: one memory transaction, not one per array)
     bin_rec[dest].m = make_uint4(bb.x, bb.y, (uint32_t)vv, 0u);
-    indices[bb.y] = vv;
+    if (indices) indices[bb.y] = vv;   // (NULL: nobody slices this frame — a scattered 4-byte store per row saved)
   };
 #pragma unroll
   for (int k = 0; k < BK_KEEP; ++k)
@@ -2244,6 +2253,7 @@ static int bk_fill_job(tln_lattice* l, const float* d_positions, const float* d_
   J.vold = (int)l->nr_vertices;
   J.capacity = (int)l->capacity;
   J.stamp = l->bins_stamp;
+  J.stage = 0;   // decided for the whole launch (bk_launch)
   return TLN_OK;
 }
 
@@ -2255,8 +2265,20 @@ static int bk_launch(BkJobs& jobs, int n, int split_t, hipEvent_t ev, hipStream_
     if (jobs.j[i].nblk > maxblk) maxblk = jobs.j[i].nblk;
     if (jobs.j[i].B > maxB) maxB = jobs.j[i].B;
   }
+  // the split blocks stage their records in LDS when the largest block's image fits beside the histogram
+  int maxppb = 0;
+  for (int i = 0; i < n; ++i)
+    if (jobs.j[i].ppb > maxppb) maxppb = jobs.j[i].ppb;
+  static const bool stage_off = getenv("TLN_BK_STAGE_OFF") != nullptr;
+  size_t split_lds = (size_t)((maxB + 3) & ~3) * sizeof(uint32_t);
+  const size_t staged = split_lds + (size_t)4 * maxppb * sizeof(uint4);
+  const bool stage = !stage_off && staged <= 144 * 1024;
+  if (stage) split_lds = staged;
+  for (int i = 0; i < n; ++i) jobs.j[i].stage = stage ? 1 : 0;
   for (int i = n; i < TLN_BK_MAXJOBS; ++i) jobs.j[i] = jobs.j[0];   // (never indexed: the grids have n rows)
-  hipLaunchKernelGGL(k_bk_split, dim3((unsigned)maxblk, (unsigned)n), dim3(split_t), (size_t)maxB * sizeof(uint32_t), s, jobs);
+  static thread_local TlnLdsAttr split_attr;
+  TLN_HIP(tln_set_max_lds(split_attr, reinterpret_cast<const void*>(k_bk_split), (int)split_lds));
+  hipLaunchKernelGGL(k_bk_split, dim3((unsigned)maxblk, (unsigned)n), dim3(split_t), split_lds, s, jobs);
   hipLaunchKernelGGL(k_bk_insert, dim3((unsigned)maxB, (unsigned)n), dim3(TLN_BK_THREADS), 0, s, jobs);
   hipLaunchKernelGGL(k_bk_prefix, dim3(1, (unsigned)n), dim3(TLN_BK_THREADS), 0, s, jobs);
   TLN_LAUNCH_CHECK();
@@ -2286,10 +2308,12 @@ static void distribute_remember(tln_lattice* l, const float* d_positions, int64_
 extern "C" int tln_distribute_begin(tln_lattice_t* l, const float* d_positions, const float* d_values, int64_t n,
                                     int val_dim, int subtract_mean, float* d_distributed, int32_t* d_indices,
                                     float* d_weights, void* stream_) {
-  TLN_REQUIRE(l && d_positions && d_indices && d_weights, "null argument");
+  TLN_REQUIRE(l && d_positions && d_weights, "null argument");
   TLN_REQUIRE(l->level == 0, "distribute works on the finest level");
   TLN_REQUIRE(n > 0 && 4 * n < (1ll << 31), "nr of points %lld out of range", (long long)n);
   TLN_REQUIRE(val_dim >= 0 && val_dim <= 1024 && (val_dim == 0 || d_values), "bad val_dim %d", val_dim);
+  // d_indices may be NULL (a frame nobody slices) where the partitioned kernels run and no [4N, .] rows are asked for
+  TLN_REQUIRE(d_indices || (bk_eligible(l, n, val_dim) && !d_distributed), "d_indices is required here");
   hipStream_t s = (hipStream_t)stream_;
   int rc = distribute_prepare(l, n, s);
   if (rc) return rc;
@@ -2335,7 +2359,8 @@ extern "C" int tln_distribute_begin_multi(const tln_distribute_call* c, int n, v
   hipStream_t s = (hipStream_t)stream_;
   bool batch = n >= 2 && n <= TLN_BK_MAXJOBS;
   for (int i = 0; i < n; ++i) {
-    TLN_REQUIRE(c[i].l && c[i].d_positions && c[i].d_indices && c[i].d_weights, "null argument");
+    TLN_REQUIRE(c[i].l && c[i].d_positions && c[i].d_weights, "null argument");
+    TLN_REQUIRE(c[i].d_indices || (bk_eligible(c[i].l, c[i].n, c[i].val_dim) && !c[i].d_distributed), "d_indices is required here");
     TLN_REQUIRE(c[i].l->level == 0, "distribute works on the finest level");
     TLN_REQUIRE(c[i].n > 0 && 4 * c[i].n < (1ll << 31), "nr of points %lld out of range", (long long)c[i].n);
     TLN_REQUIRE(c[i].val_dim >= 0 && c[i].val_dim <= 1024 && (c[i].val_dim == 0 || c[i].d_values), "bad val_dim %d", c[i].val_dim);

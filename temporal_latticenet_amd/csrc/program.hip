@@ -175,6 +175,7 @@ struct tln_program {
   DevBuf k1;  // distributed | indices | weights
   float* d_dist = nullptr;
   int32_t* d_idx = nullptr;
+  bool idx_valid = false;   // d_idx holds this frame's vertex indices (an early-return frame of a group skips them)
   float* d_w = nullptr;
   DevBuf arena;
   Arena alloc;
@@ -519,6 +520,7 @@ int walk(tln_program* p, bool dry, int early, float* d_out, int64_t out_rows, in
       }
       case TLN_OP_SLICE_GATHER: {
         if (dry) break;
+        TLN_REQUIRE(p->idx_valid, "op %d: the frame was begun without its vertex indices", oi);
         if (p->timing && !p->tset[2]) {
           TLN_HIP(hipEventRecord(p->tev[4], s));
           p->tset[2] = true;
@@ -531,6 +533,7 @@ int walk(tln_program* p, bool dry, int early, float* d_out, int64_t out_rows, in
       }
       case TLN_OP_SLICE: {
         if (dry) break;
+        TLN_REQUIRE(p->idx_valid, "op %d: the frame was begun without its vertex indices", oi);
         if (p->timing && !p->tset[2]) {
           TLN_HIP(hipEventRecord(p->tev[4], s));
           p->tset[2] = true;
@@ -543,6 +546,7 @@ int walk(tln_program* p, bool dry, int early, float* d_out, int64_t out_rows, in
       }
       case TLN_OP_SLICE_DEFORM: {
         if (dry) break;
+        TLN_REQUIRE(p->idx_valid, "op %d: the frame was begun without its vertex indices", oi);
         if (p->defer && group_batches(TLN_OP_SLICE_DEFORM)) {
           const int ncls = p->slots[o.s1.slot].cols;
           p->pend_slice = tln_slice_call{fptr(o.s0.slot), fptr(o.s1.slot), p->rt[o.s1.slot].rows, p->d_idx, p->d_w, p->N,
@@ -830,6 +834,7 @@ extern "C" int tln_program_begin_frame_start(tln_program_t* p, tln_lattice_t* l,
     p->tset[0] = p->tset[1] = p->tset[2] = false;
     TLN_HIP(hipEventRecord(p->tev[0], s));
   }
+  p->idx_valid = true;
   rc = tln_distribute_begin(l, d_positions, d_values, n, val_dim, subtract_mean, p->d_dist, p->d_idx, p->d_w, s);
   if (rc) return rc;
   if (p->timing) {   // every kernel of K1 is enqueued by now (the second half only waits for the counters)
@@ -846,7 +851,7 @@ extern "C" int tln_program_begin_frame_start(tln_program_t* p, tln_lattice_t* l,
 extern "C" int tln_program_begin_frame_group(tln_program_t* const* pp, tln_lattice_t* const* ll,
                                              const float* const* d_positions, const float* const* d_values,
                                              const int64_t* n, int count, int val_dim, int reset_hashmap, int subtract_mean,
-                                             int64_t* v_out, void* stream_) {
+                                             int need_indices, int64_t* v_out, void* stream_) {
   TLN_REQUIRE(pp && ll && d_positions && n && v_out && count >= 1 && count <= 8 && val_dim >= 0, "bad frame group");
   hipStream_t s = (hipStream_t)stream_;
   if (!group_batches(0)) {   // every sequence by itself: all first halves, then all second halves
@@ -855,6 +860,7 @@ extern "C" int tln_program_begin_frame_group(tln_program_t* const* pp, tln_latti
                                              reset_hashmap, subtract_mean, s);
       if (rc) return rc;
     }
+    (void)need_indices;
     for (int k = 0; k < count; ++k) {
       int rc = tln_program_begin_frame_finish(pp[k], v_out + (size_t)k * TLN_MAX_LEVELS, s);
       if (rc) return rc;
@@ -875,8 +881,12 @@ extern "C" int tln_program_begin_frame_group(tln_program_t* const* pp, tln_latti
   for (int k = 0; k < count; ++k) {
     pp[k]->tset[0] = pp[k]->tset[1] = pp[k]->tset[2] = false;
     pp[k]->timing_group = count;
+    // the per-row vertex indices are read by the slice ops only: a frame that returns early does not need them (and
+    // k_bk_place saves a scattered 4-byte store per row); the [4N, .] rows, if the program wants them, need them
+    const bool want_idx = need_indices != 0 || pp[k]->d_dist != nullptr;
+    pp[k]->idx_valid = want_idx;
     calls[k] = tln_distribute_call{ll[k], d_positions[k], d_values ? d_values[k] : nullptr, n[k], val_dim, subtract_mean,
-                                   pp[k]->d_dist, pp[k]->d_idx, pp[k]->d_w};
+                                   pp[k]->d_dist, want_idx ? pp[k]->d_idx : nullptr, pp[k]->d_w};
   }
   if (p0->timing) TLN_HIP(hipEventRecord(p0->tev[0], s));
   int rc = tln_distribute_begin_multi(calls, count, s);
@@ -1555,7 +1565,7 @@ extern "C" int tln_program_frame_rows(tln_program_t* p, const float** d_distribu
                                       const float** d_weights, int64_t* rows, int* cols) {
   TLN_REQUIRE(p && p->d_idx, "no frame yet");
   if (d_distributed) *d_distributed = p->d_dist;   // NULL when the frame's pool read the vertex bins instead
-  if (d_indices) *d_indices = p->d_idx;
+  if (d_indices) *d_indices = p->idx_valid ? p->d_idx : nullptr;   // (NULL: the frame did not produce them)
   if (d_weights) *d_weights = p->d_w;
   if (rows) *rows = 4 * p->N;
   if (cols) *cols = p->dist_cols;

@@ -472,8 +472,9 @@ class FrameProgram:
         vp = (C.c_void_p * n)(*[x.data_ptr() for x in vals]) if vals is not None else None
         ns = (C.c_int64 * n)(*[x.shape[0] for x in pos])
         vout = (C.c_int64 * (n * MAX_LEVELS))()
+        all_early = bool(early_return) and all(p.stop_shape is not None for p in progs)
         _lib.check(lib.tln_program_begin_frame_group(hs, lh, pp, vp, ns, n, val_dim, 1 if reset_hashmap else 0,
-                                                     1 if progs[0].subtract_mean else 0, vout, s),
+                                                     1 if progs[0].subtract_mean else 0, 0 if all_early else 1, vout, s),
                    "tln_program_begin_frame_group")
         begun = []
         for k, (p, ls) in enumerate(zip(progs, lattices)):
