@@ -94,6 +94,11 @@ int tln_lattice_drop_bins(tln_lattice_t* l);
  * by one workgroup each, LDS atomics only; the default), 1 = one global atomic per row (also env TLN_K1_LEGACY=1; always
  * taken for val_dim > 1).  Same results bit for bit; a test / measurement switch. */
 int tln_distribute_config(int legacy);
+/* rows per bucket the partitioned kernels aim at (0 = default 512).  A bucket (one workgroup, a 1024-entry LDS table)
+ * that meets more distinct keys than its table holds makes the library redo the frame with the per-row-atomic kernels
+ * (same results); tln_lattice_bucket_fallbacks counts those frames.  Test / measurement hook. */
+int tln_distribute_bucket_rows(int rows);
+int64_t tln_lattice_bucket_fallbacks(const tln_lattice_t* l);
 
 /* build the vertex-sorted row list (CSR) from caller-supplied indices (R rows, -1 folded into the tail bucket) */
 int tln_build_csr(tln_lattice_t* l, const int32_t* d_indices, int64_t rows, void* stream);

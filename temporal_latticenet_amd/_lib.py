@@ -95,6 +95,8 @@ _PROTOS = {
     "tln_lattice_drop_bins": (_i, [_vp]),
     "tln_distribute_config": (_i, [_i]),
     "tln_pool_config": (_i, [_i]),
+    "tln_distribute_bucket_rows": (_i, [_i]),
+    "tln_lattice_bucket_fallbacks": (_i64, [_vp]),
     "tln_lattice_keys": (_i, [_vp, _vp, _i64, _vp]),
     "tln_lattice_insert_keys": (_i, [_vp, _vp, _i64, _vp, _vp]),
     "tln_distribute": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp]),

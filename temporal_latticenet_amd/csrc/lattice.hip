@@ -29,7 +29,9 @@ extern "C" int tln_version(void) { return 1; }
 // ---------------------------------------------------------------------------------------
 enum { CTR_NV = 0, CTR_NEW = 1, CTR_OVERFLOW = 2, CTR_PROBE_FAIL = 3, CTR_VOLD = 4, CTR_OCCUPIED = 5,
        CTR_CURSOR = 6 /* rows placed in vertex bins */, CTR_TAIL = 7 /* rows without a vertex */,
-       CTR_COUNT = 8 };
+       CTR_BUCKET_FULL = 8 /* partitioned K1: keys that did not fit a bucket's LDS table (the frame is redone by the
+                              per-row-atomic kernels) */,
+       CTR_COUNT = 9 };
 // Probing stays inside the aligned group of TLN_SLOT_GROUP slots the key hashes into (wraps there).  The table is
 // sized for a load of at most 1/2, so a group never fills; what the grouping buys: the buckets of the partitioned K1
 // (top bits of the home slot) own disjoint slot ranges, so a bucket's workgroup inserts its keys with plain stores.
@@ -91,7 +93,10 @@ struct tln_lattice {
   hipEvent_t ctr_event = nullptr;
   hipEvent_t ctr_wait = nullptr;   // a batched first half: the event of the batch's first lattice (borrowed)
   bool dist_pending = false;
+  int64_t bucket_fallbacks = 0;   // frames redone by the per-row-atomic kernels after a bucket's LDS table overflowed
   const float* dist_pos = nullptr;
+  const float* dist_val = nullptr;
+  float* dist_w = nullptr;
   float* dist_out = nullptr;
   const int32_t* dist_idx = nullptr;
   int64_t dist_rows = 0;
@@ -1541,7 +1546,7 @@ __global__ void __launch_bounds__(256) k_bins_scatter(TableRef t, const int32_t*
     v = t.slots[slot].val;
     if (rank == 0) slot_cnt[slot] = 0;   // exactly one row per touched slot: the counts are zero again for the next frame
   }
-  indices[row] = v;
+  if (indices) indices[row] = v;
   const int64_t p = row >> 2;
   const float x = pos[3 * p], y = pos[3 * p + 1], z = pos[3 * p + 2];
   int dest;
@@ -1848,7 +1853,7 @@ __global__ void __launch_bounds__(TLN_BK_THREADS) k_bk_insert(const BkJobs jobs)
     const uint64_t K = ((uint64_t)bb.w << 32) | bb.z;
     if (K == TLN_KEY_EMPTY) return;
     const int he = bk_lds_insert(hk, K);
-    if (he < 0) atomicAdd(&t.ctr[CTR_PROBE_FAIL], 1);   // more distinct keys in one bucket than its table holds
+    if (he < 0) atomicAdd(&t.ctr[CTR_BUCKET_FULL], 1);   // more distinct keys in one bucket than its table holds
     else atomicMin(&htouch[he], bb.y);
   };
 #pragma unroll
@@ -1944,9 +1949,13 @@ __global__ void __launch_bounds__(TLN_BK_THREADS) k_bk_prefix(const BkJobs jobs)
   }
   if (threadIdx.x == 0) {
     int32_t* ctr = J.ctr;
-    const long long vnew = (long long)J.vold + carry;
+    // a bucket's LDS table overflowed (k_bk_insert): nothing of this frame is numbered — k_bk_place returns at once,
+    // the host redoes the frame with the per-row-atomic kernels (the keys already entered stay, un-numbered, with
+    // their first-touch rows: exactly what those kernels expect to find)
+    const bool full = ctr[CTR_BUCKET_FULL] != 0;
+    const long long vnew = (long long)J.vold + (full ? 0u : carry);
     ctr[CTR_VOLD] = J.vold;
-    ctr[CTR_NEW] = (int)carry;
+    ctr[CTR_NEW] = full ? 0 : (int)carry;
     ctr[CTR_NV] = (int)(vnew < J.capacity ? vnew : J.capacity);
     ctr[CTR_OCCUPIED] += (int)carry;
     // the host's copy (pinned, mapped): written from here instead of a copy kernel between this launch and k_bk_place
@@ -1957,6 +1966,7 @@ __global__ void __launch_bounds__(TLN_BK_THREADS) k_bk_prefix(const BkJobs jobs)
 __global__ void __launch_bounds__(TLN_BK_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) k_bk_place(const BkJobs jobs) {
   const BkJob& J = jobs.j[blockIdx.y];
   if ((int)blockIdx.x >= J.B) return;
+  if (J.ctr[CTR_BUCKET_FULL] != 0) return;             // (uniform) the frame is redone by the per-row-atomic kernels
   __shared__ unsigned long long hk[TLN_BK_HT];
   __shared__ uint32_t hcnt[TLN_BK_HT];                 // rows per entry, then the entry's write cursor
   extern __shared__ unsigned long long bk_dyn[];       // (dynamic: the block needs more than 64 KB of LDS in all)
@@ -2137,6 +2147,8 @@ bool tln_lat_bins(const tln_lattice* l, const float* d_distributed, int64_t rows
   return true;
 }
 
+extern "C" int64_t tln_lattice_bucket_fallbacks(const tln_lattice_t* l) { return l ? l->bucket_fallbacks : -1; }
+
 extern "C" int tln_lattice_drop_bins(tln_lattice_t* l) {
   TLN_REQUIRE(l, "null lattice");
   l->bins_rows = -1;
@@ -2160,6 +2172,13 @@ static bool k1_partitioned() {
 }
 extern "C" int tln_distribute_config(int legacy) {
   g_k1_legacy = legacy ? 1 : 0;
+  return TLN_OK;
+}
+// rows per bucket the partitioned kernels aim at (0 = default 512; a test / measurement hook: large values provoke a
+// bucket whose distinct keys overflow its LDS table, i.e. the fallback to the per-row-atomic kernels)
+static int g_bk_rows = 0;
+extern "C" int tln_distribute_bucket_rows(int rows) {
+  g_bk_rows = rows;
   return TLN_OK;
 }
 
@@ -2195,7 +2214,8 @@ static int bk_fill_job(tln_lattice* l, const float* d_positions, const float* d_
   const int64_t rows = 4 * n;
   static const int env_rows = getenv("TLN_BK_ROWS") ? atoi(getenv("TLN_BK_ROWS")) : 0;   // measurement overrides
   static const int env_ppb = getenv("TLN_BK_PPB") ? atoi(getenv("TLN_BK_PPB")) : 0;
-  const int bucket_rows = env_rows >= 128 && env_rows <= 8192 ? env_rows : TLN_BK_ROWS;
+  const int want_rows = g_bk_rows > 0 ? g_bk_rows : env_rows;
+  const int bucket_rows = want_rows >= 128 && want_rows <= 65536 ? want_rows : TLN_BK_ROWS;
   int B = TLN_BK_MINB;
   while ((int64_t)B * bucket_rows < rows && B < l->bk_maxb) B <<= 1;
   // points per split block: a block's run inside a bucket is ~ppb / 128 records long, and the longer the runs, the
@@ -2301,6 +2321,33 @@ static void distribute_remember(tln_lattice* l, const float* d_positions, int64_
   l->dist_val_dim = val_dim;
   l->dist_subtract = subtract_mean;
   l->bins_weights = d_weights;
+  l->dist_w = const_cast<float*>(d_weights);
+}
+
+// K1 by the per-row-atomic kernels (val_dim > 1, frames beyond the partitioned kernels' range, the legacy switch, and the
+// fallback when a bucket's LDS table overflowed): insertion, numbering, the counters' way to the host, the bins
+static int distribute_legacy_launch(tln_lattice* l, const float* d_positions, const float* d_values, int64_t n, int val_dim,
+                                    int subtract_mean, float* d_distributed, int32_t* d_indices, float* d_weights,
+                                    hipStream_t s) {
+  const int64_t rows = 4 * n;
+  TableRef t = table_ref(l);
+  l->bins_stamped = false;
+  hipLaunchKernelGGL(k_distribute_insert, dim3((unsigned)tln_cdiv(4 * n, 256)), dim3(256), 0, s, d_positions, d_values, n,
+                     val_dim, l->scale[0], l->scale[1], l->scale[2], t, l->row_slot, d_weights, d_distributed,
+                     l->slot_cnt, l->row_rank);
+  TLN_LAUNCH_CHECK();
+  int rc = number_new(l, rows, s);
+  if (rc) return rc;
+  TLN_HIP(hipMemcpyAsync(l->h_ctr, l->d_ctr, CTR_COUNT * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  TLN_HIP(hipEventRecord(l->ctr_event, s));
+  // the bins: the host does not know the new vertex count yet; the kernels read it and stride over the vertices
+  hipLaunchKernelGGL(k_bins_alloc, dim3(256), dim3(256), 0, s, l->d_ctr, l->vslot, l->slot_cnt, l->vcnt, l->vstart);
+  hipLaunchKernelGGL(k_bins_scatter, dim3((unsigned)tln_cdiv(rows, 256)), dim3(256), 0, s, t, l->row_slot, l->row_rank, rows,
+                     d_positions, d_values, val_dim, d_weights, l->slot_cnt, l->vstart, d_indices, l->bin_rec);
+  if (subtract_mean)
+    hipLaunchKernelGGL(k_bins_mean, dim3(8192), dim3(256), 0, s, l->d_ctr, l->vcnt, l->vstart, l->bin_rec, l->mean);
+  TLN_LAUNCH_CHECK();
+  return TLN_OK;
 }
 
 // first half: hash insertion, numbering, the bins; the vertex counters start their way to the host.  d_distributed may be NULL: the [4N, 3+val_dim+1] rows are then not produced
@@ -2317,7 +2364,6 @@ extern "C" int tln_distribute_begin(tln_lattice_t* l, const float* d_positions, 
   hipStream_t s = (hipStream_t)stream_;
   int rc = distribute_prepare(l, n, s);
   if (rc) return rc;
-  const int64_t rows = 4 * n;
   if (!l->ctr_event) TLN_HIP(hipEventCreateWithFlags(&l->ctr_event, hipEventDisableTiming));
   l->ctr_wait = nullptr;
   if (bk_eligible(l, n, val_dim)) {
@@ -2329,25 +2375,11 @@ extern "C" int tln_distribute_begin(tln_lattice_t* l, const float* d_positions, 
     rc = bk_launch(jobs, 1, split_t, l->ctr_event, s);
     if (rc) return rc;
   } else {
-    TableRef t = table_ref(l);
-    l->bins_stamped = false;
-    hipLaunchKernelGGL(k_distribute_insert, dim3((unsigned)tln_cdiv(4 * n, 256)), dim3(256), 0, s, d_positions, d_values, n,
-                       val_dim, l->scale[0], l->scale[1], l->scale[2], t, l->row_slot, d_weights, d_distributed,
-                       l->slot_cnt, l->row_rank);
-    TLN_LAUNCH_CHECK();
-    rc = number_new(l, rows, s);
+    rc = distribute_legacy_launch(l, d_positions, d_values, n, val_dim, subtract_mean, d_distributed, d_indices, d_weights, s);
     if (rc) return rc;
-    TLN_HIP(hipMemcpyAsync(l->h_ctr, l->d_ctr, CTR_COUNT * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    TLN_HIP(hipEventRecord(l->ctr_event, s));
-    // the bins: the host does not know the new vertex count yet; the kernels read it and stride over the vertices
-    hipLaunchKernelGGL(k_bins_alloc, dim3(256), dim3(256), 0, s, l->d_ctr, l->vslot, l->slot_cnt, l->vcnt, l->vstart);
-    hipLaunchKernelGGL(k_bins_scatter, dim3((unsigned)tln_cdiv(rows, 256)), dim3(256), 0, s, t, l->row_slot, l->row_rank, rows,
-                       d_positions, d_values, val_dim, d_weights, l->slot_cnt, l->vstart, d_indices, l->bin_rec);
-    if (subtract_mean)
-      hipLaunchKernelGGL(k_bins_mean, dim3(8192), dim3(256), 0, s, l->d_ctr, l->vcnt, l->vstart, l->bin_rec, l->mean);
-    TLN_LAUNCH_CHECK();
   }
   distribute_remember(l, d_positions, n, val_dim, subtract_mean, d_distributed, d_indices, d_weights);
+  l->dist_val = d_values;
   return TLN_OK;
 }
 
@@ -2398,6 +2430,7 @@ extern "C" int tln_distribute_begin_multi(const tln_distribute_call* c, int n, v
     c[i].l->ctr_wait = i ? l0->ctr_event : nullptr;
     distribute_remember(c[i].l, c[i].d_positions, c[i].n, c[i].val_dim, c[i].subtract_mean, c[i].d_distributed,
                         c[i].d_indices, c[i].d_weights);
+    c[i].l->dist_val = c[i].d_values;
   }
   return TLN_OK;
 }
@@ -2410,6 +2443,19 @@ extern "C" int tln_distribute_finish(tln_lattice_t* l, void* stream_) {
   l->dist_pending = false;
   TLN_HIP(hipEventSynchronize(l->ctr_wait ? l->ctr_wait : l->ctr_event));
   l->ctr_wait = nullptr;
+  if (l->h_ctr[CTR_BUCKET_FULL] != 0) {
+    // a bucket of the partitioned kernels met more distinct keys than its LDS table holds (skewed hashing; never on a
+    // LiDAR frame at the default geometry): nothing was numbered, the keys entered so far sit un-numbered in the table with
+    // their first-touch rows — the per-row-atomic kernels redo the frame from there, with the same result
+    if (!l->ctr_event) TLN_HIP(hipEventCreateWithFlags(&l->ctr_event, hipEventDisableTiming));
+    TLN_HIP(hipMemsetAsync(l->d_ctr + CTR_BUCKET_FULL, 0, sizeof(int32_t), s));
+    int32_t* idx = const_cast<int32_t*>(l->dist_idx);
+    int rc = distribute_legacy_launch(l, l->dist_pos, l->dist_val, l->dist_rows / 4, l->dist_val_dim, l->dist_subtract,
+                                      l->dist_out, idx, l->dist_w, s);
+    if (rc) return rc;
+    TLN_HIP(hipEventSynchronize(l->ctr_event));
+    ++l->bucket_fallbacks;
+  }
   publish_counts(l);
   if (l->h_ctr[CTR_PROBE_FAIL] != 0) {
     tln_set_error("hash probing failed for %d rows (table too full)", l->h_ctr[CTR_PROBE_FAIL]);

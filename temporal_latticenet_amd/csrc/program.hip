@@ -1094,6 +1094,9 @@ extern "C" int tln_program_run_begin(tln_program_t* p, int early, float* d_out, 
 
 extern "C" int tln_program_run_until(tln_program_t* p, int op_end, void* stream_) {
   TLN_REQUIRE(p && p->seg_open && op_end >= 0, "tln_program_run_until without tln_program_run_begin");
+  // a cut behind the cursor means its state would be set AFTER the ops that read it have run (on a buffer that
+  // tln_program_state_expect only sized): refuse instead of returning wrong logits
+  TLN_REQUIRE(op_end >= p->seg_cursor, "tln_program_run_until(%d): ops up to %d have already run", op_end, p->seg_cursor);
   return seg_walk_to(p, op_end, (hipStream_t)stream_);
 }
 

@@ -19,7 +19,7 @@ import torch
 import torch.distributed as dist
 
 __all__ = ["init_from_env", "shard_items", "max_over_ranks", "all_gather_rows", "send_tensor", "recv_tensor",
-           "FrameShardPlan"]
+           "HandoffError", "reset_handoff_counters", "FrameShardPlan", "FrameShardRunner"]
 
 
 def init_from_env(backend=None, device_index=None):
@@ -35,6 +35,7 @@ def init_from_env(backend=None, device_index=None):
         if backend == "nccl" and device_index is not None:
             kw["device_id"] = torch.device("cuda", device_index)
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+        reset_handoff_counters()
     return rank, world
 
 
@@ -68,20 +69,64 @@ def all_gather_rows(rows, group=None):
     return [o[:c] for o, c in zip(out, counts)]
 
 
-def send_tensor(t, dst, tag=0, group=None):
-    """shape header + payload (hidden states grow from frame to frame, so the receiver cannot know V_s)"""
-    hdr = torch.tensor([t.dim()] + list(t.shape) + [0] * (4 - t.dim()), dtype=torch.int64, device=t.device)
-    dist.send(hdr, dst, group=group, tag=tag)
-    dist.send(t.contiguous(), dst, group=group, tag=tag)
+class HandoffError(RuntimeError):
+    """a point-to-point hand-off went wrong: the message that arrived is not the one the receiver was waiting for (the
+    two sides walked their fusion slots differently), or nothing arrived in time"""
 
 
-def recv_tensor(src, device, dtype=torch.float32, tag=0, group=None):
-    hdr = torch.zeros(5, dtype=torch.int64, device=device)
-    dist.recv(hdr, src, group=group, tag=tag)
+_MAGIC = 0x544C4E48            # "TLNH"
+_HDR = 8                       # magic, message number on this (src -> dst) channel, slot id, ndim, 4 extents
+_sent, _received = {}, {}      # (group id, peer) -> messages so far on that channel
+HANDOFF_TIMEOUT_S = float(os.environ.get("TLN_HANDOFF_TIMEOUT_S", "120"))
+
+
+def reset_handoff_counters():
+    _sent.clear()
+    _received.clear()
+
+
+def _wait(work, what, timeout_s):
+    import datetime
+    try:
+        ok = work.wait(datetime.timedelta(seconds=timeout_s)) if timeout_s and timeout_s > 0 else work.wait()
+    except RuntimeError as e:                                   # gloo / nccl raise on timeout
+        raise HandoffError("%s: %s" % (what, e)) from e
+    if ok is False:
+        raise HandoffError("%s: timed out after %.0f s" % (what, timeout_s))
+
+
+def send_tensor(t, dst, tag=0, group=None, timeout_s=None):
+    """header + payload.  The header carries the shape (hidden states grow from frame to frame, so the receiver cannot
+    know V_s), a per-channel MESSAGE NUMBER and the SLOT id the sender believes it is serving: the RCCL backend ignores
+    tags, messages between two ranks are matched by order alone, so a receiver that walked its fusion slots differently
+    would silently take the wrong state — it now sees a header it did not expect and raises HandoffError."""
+    key = (id(group), dst)
+    seq = _sent.get(key, 0)
+    _sent[key] = seq + 1
+    hdr = torch.tensor([_MAGIC, seq, int(tag), t.dim()] + list(t.shape) + [0] * (4 - t.dim()), dtype=torch.int64,
+                       device=t.device)
+    tmo = HANDOFF_TIMEOUT_S if timeout_s is None else timeout_s
+    _wait(dist.isend(hdr, dst, group=group, tag=tag), "send of header %d (slot %d) to rank %d" % (seq, tag, dst), tmo)
+    if t.numel():
+        _wait(dist.isend(t.contiguous(), dst, group=group, tag=tag),
+              "send of payload %d (slot %d) to rank %d" % (seq, tag, dst), tmo)
+
+
+def recv_tensor(src, device, dtype=torch.float32, tag=0, group=None, timeout_s=None):
+    key = (id(group), src)
+    seq = _received.get(key, 0)
+    _received[key] = seq + 1
+    tmo = HANDOFF_TIMEOUT_S if timeout_s is None else timeout_s
+    hdr = torch.zeros(_HDR, dtype=torch.int64, device=device)
+    _wait(dist.irecv(hdr, src, group=group, tag=tag), "receive of header %d (slot %d) from rank %d" % (seq, tag, src), tmo)
     h = hdr.tolist()
-    shape = h[1:1 + h[0]]
+    if h[0] != _MAGIC or h[1] != seq or h[2] != int(tag) or not 0 <= h[3] <= 4:
+        raise HandoffError("hand-off out of step: expected message %d for slot %d from rank %d, got magic %#x message %d "
+                           "slot %d ndim %d" % (seq, tag, src, h[0], h[1], h[2], h[3]))
+    shape = h[4:4 + h[3]]
     t = torch.empty(shape, dtype=dtype, device=device)
-    dist.recv(t, src, group=group, tag=tag)
+    if t.numel():
+        _wait(dist.irecv(t, src, group=group, tag=tag), "receive of payload %d (slot %d) from rank %d" % (seq, tag, src), tmo)
     return t
 
 

@@ -566,6 +566,14 @@ class FrameProgram:
         ls._bins_key = None
         ls._last_indices = None
         plan = sorted((self.state_ops(sid) + (sid,)) for sid in range(self.n_states))     # by first-read op
+        # a state takes part in the hand-off iff it is both read (on the receiving side) and written (on the sending
+        # side) by the op list: both sides walk the SAME list of states, so that the order-matched messages pair up
+        plan = [(fr, lw, lvl, sid) for fr, lw, lvl, sid in plan if fr >= 0 and lw >= 0]
+        # the segments must move forward: read(k) <= write(k) < read(k+1) ... — a fusion module that interleaved the ops
+        # of two states would otherwise have its state set after the ops that read it
+        cuts = [x for fr, lw, lvl, sid in plan for x in (fr, lw + 1)]
+        if any(b < a for a, b in zip(cuts, cuts[1:])):
+            raise _lib.TlnError("frame-sharded run: the hidden states' op ranges interleave (%s)" % (plan,))
         if recv_state is not None:
             for fr, lw, lvl, sid in plan:
                 if fr >= 0:

@@ -145,6 +145,10 @@ class Lattice:
         """c of scale_i = c / (sigma_i sqrt((i+1)(i+2))) this lattice (and its coarse levels) was created with"""
         return float(_lib.lib().tln_lattice_scale_constant(self._h))
 
+    def bucket_fallbacks(self):
+        """frames this lattice redid with the per-row-atomic K1 kernels because a bucket's LDS table overflowed"""
+        return int(_lib.lib().tln_lattice_bucket_fallbacks(self._h))
+
     def overflow_rows(self):
         return int(_lib.lib().tln_lattice_overflow_rows(self._h))
 

@@ -98,12 +98,16 @@ class SequenceStreams:
     def _fetch(self, i, grp, t):
         """frame t of the sequences of a lock-step group: device tensors as they are; host tensors (pinned) start their
         way to the device on stream i's COPY stream.  Returns (positions, values, event or None)."""
-        if all(sq[t][0].is_cuda for sq in grp):
+        def on_device(x):
+            return x is None or x.is_cuda          # (values may be None: a cloud without a value channel)
+
+        if all(on_device(sq[t][0]) and on_device(sq[t][1]) for sq in grp):
             return [sq[t][0] for sq in grp], [sq[t][1] for sq in grp], None
         cs = self._copy_streams[i]
         with torch.cuda.stream(cs):
-            ps = [sq[t][0] if sq[t][0].is_cuda else sq[t][0].to("cuda", non_blocking=True) for sq in grp]
-            vs = [sq[t][1] if sq[t][1].is_cuda else sq[t][1].to("cuda", non_blocking=True) for sq in grp]
+            # decided per tensor: only host tensors are copied, device tensors (and None) pass through unchanged
+            ps = [x if on_device(x) else x.to("cuda", non_blocking=True) for x in (sq[t][0] for sq in grp)]
+            vs = [x if on_device(x) else x.to("cuda", non_blocking=True) for x in (sq[t][1] for sq in grp)]
             ev = torch.cuda.Event()
             ev.record(cs)
         return ps, vs, ev
@@ -113,7 +117,8 @@ class SequenceStreams:
         if ev is not None:
             self.streams[i].wait_event(ev)
             for x in ps + vs:
-                x.record_stream(self.streams[i])    # allocated on the copy stream, used (and released) on this one
+                if x is not None:
+                    x.record_stream(self.streams[i])    # allocated on the copy stream, used (and released) on this one
         return ps, vs
 
     def _work(self, i, sequences, keep_outputs):

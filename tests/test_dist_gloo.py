@@ -42,7 +42,10 @@ def _entry(rank, fn, port, *args):
     try:
         fn(rank, *args)
     finally:
-        dist.destroy_process_group()
+        try:
+            dist.destroy_process_group()
+        except Exception:          # (a test that let a receive time out leaves a torn-down gloo pair behind)
+            pass
 
 
 # ---------------------------------------------------------------------------------------------
@@ -69,6 +72,46 @@ def _sequence_sharding(rank):
 
 def test_sequence_sharding_and_primitives():
     _spawn(_sequence_sharding)
+
+
+def _handoff_out_of_step(rank):
+    """the point-to-point hand-off is matched by ORDER on RCCL (tags ignored): every message carries its number on the
+    (src -> dst) channel and the fusion slot the sender serves, and the receiver checks both"""
+    # in step: three messages, the third one empty (a state that does not exist yet)
+    if rank == 0:
+        for slot, t in enumerate([torch.ones(3, 4), torch.zeros(2, 2), torch.zeros(0)]):
+            D.send_tensor(t, 1, tag=slot)
+    else:
+        for slot, shape in enumerate([(3, 4), (2, 2), (0,)]):
+            assert tuple(D.recv_tensor(0, "cpu", tag=slot).shape) == shape
+    dist.barrier()
+    # the sender serves slot 5, the receiver waits for slot 6 (same tag on the wire, as RCCL would deliver it)
+    if rank == 0:
+        hdr = torch.tensor([D._MAGIC, D._sent[(id(None), 1)], 5, 1, 2, 0, 0, 0], dtype=torch.int64)
+        D._sent[(id(None), 1)] += 1
+        dist.send(hdr, 1, tag=6)
+    else:
+        with pytest.raises(D.HandoffError, match="out of step"):
+            D.recv_tensor(0, "cpu", tag=6)
+    dist.barrier()
+    # a message number that does not follow (a message was lost or sent twice)
+    if rank == 0:
+        dist.send(torch.tensor([D._MAGIC, 99, 7, 1, 2, 0, 0, 0], dtype=torch.int64), 1, tag=7)
+    else:
+        with pytest.raises(D.HandoffError, match="expected message"):
+            D.recv_tensor(0, "cpu", tag=7)
+    dist.barrier()
+    # nobody sends: the receiver gives up instead of hanging the pipeline (last: gloo tears the pair down on a timeout)
+    if rank == 1:
+        with pytest.raises(D.HandoffError):
+            D.recv_tensor(0, "cpu", tag=8, timeout_s=1.0)
+    else:
+        import time
+        time.sleep(3.0)
+
+
+def test_handoff_messages_are_numbered_and_time_out():
+    _spawn(_handoff_out_of_step)
 
 
 # ---------------------------------------------------------------------------------------------

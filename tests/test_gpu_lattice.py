@@ -325,3 +325,43 @@ def test_batched_distribute_of_eight_lattices_equals_the_single_calls(gpu):
             assert np.array_equal(lats[k].keys().cpu().numpy(), tabs[k].keys)
             _check_csr(lats[k], oi)
             assert lats[k].overflow_rows() == 0
+
+
+def test_a_bucket_that_overflows_its_table_falls_back_to_the_atomic_kernels(gpu):
+    """The partitioned K1 gives every bucket (one workgroup) a 1024-entry LDS table for the distinct keys of a frame.  With
+    the buckets made 64x larger than the default (tln_distribute_bucket_rows) a fine lattice puts thousands of distinct
+    keys into each: the kernels notice (their own counter, not the "table too full" one), number nothing, and the library
+    redoes the frame with the per-row-atomic kernels -- same indices as the oracle, and the sequence goes on append-only.
+    Also through the batched first half, and with the per-row indices switched off for a frame."""
+    from temporal_latticenet_amd import _lib
+    from temporal_latticenet_amd.lattice import Lattice
+    lib = _lib.lib()
+    seq = make_sequence(60000, 3, seed=411)
+    lib.tln_distribute_bucket_rows(32768)
+    try:
+        lat = Lattice.from_params([0.1] * 3, 1 << 19)
+        tab = P.VertexTable(3, 1 << 19)
+        for t, (pos, val) in enumerate(seq[:2]):
+            d, i, w = lat.distribute(torch.from_numpy(pos).to(gpu), torch.from_numpy(val).to(gpu), reset_hashmap=(t == 0))
+            od, oi, ow = O.distribute(tab, pos, val, [0.1] * 3)
+            assert lat.bucket_fallbacks() == t + 1, "the frame was meant to overflow a bucket"
+            assert lat.nr_lattice_vertices() == tab.nr_vertices > 50000
+            assert np.array_equal(i.cpu().numpy(), oi) and np.array_equal(w.cpu().numpy(), ow)
+            np.testing.assert_allclose(d.cpu().numpy(), od, rtol=0, atol=2e-5)
+        lib.tln_distribute_bucket_rows(0)            # the third frame on the default geometry: no fallback, same numbering
+        pos, val = seq[2]
+        d, i, w = lat.distribute(torch.from_numpy(pos).to(gpu), torch.from_numpy(val).to(gpu), reset_hashmap=False)
+        od, oi, ow = O.distribute(tab, pos, val, [0.1] * 3)
+        assert lat.bucket_fallbacks() == 2 and np.array_equal(i.cpu().numpy(), oi)
+        assert np.array_equal(lat.keys().cpu().numpy(), tab.keys)
+        # batched first halves, two lattices, both overflowing
+        lib.tln_distribute_bucket_rows(32768)
+        lats = [Lattice.from_params([0.1] * 3, 1 << 19) for _ in range(2)]
+        outs = Lattice.distribute_batch(lats, [torch.from_numpy(seq[k][0]).to(gpu) for k in range(2)],
+                                        [torch.from_numpy(seq[k][1]).to(gpu) for k in range(2)])
+        for k, (d, i, w) in enumerate(outs):
+            t2 = P.VertexTable(3, 1 << 19)
+            od, oi, ow = O.distribute(t2, seq[k][0], seq[k][1], [0.1] * 3)
+            assert lats[k].bucket_fallbacks() == 1 and np.array_equal(i.cpu().numpy(), oi)
+    finally:
+        lib.tln_distribute_bucket_rows(0)
