@@ -65,6 +65,12 @@ def parse():
                          "913 clouds/s at 4 streams x 1, 1160 at 4 x 3, 1220 at 4 x 6 and 4 x 8")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) on the GPU node; gloo for rehearsals")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: all ranks use cuda:0")
+    ap.add_argument("--frames-extra", choices=["gloo", "nccl", "off"], default="gloo",
+                    help="N > 1, --mode sequences: also time the frame-sharded pipeline and report it as `frames_mode` "
+                         "beside the sequence-sharded `value`.  gloo (default): over a side group with host-staged "
+                         "hand-offs — the path every rehearsal has exercised, so a problem in it cannot cost the run its "
+                         "line; nccl: over RCCL / xGMI as --mode frames does (what the north star asks; not yet run on "
+                         "hardware); off: skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-points", type=int, default=120000, help="points per frame of the CPU sample")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="lower bound of CPU work in the sample")
@@ -209,6 +215,71 @@ def main():
             barrier()
             el_h = D.max_over_ranks(time.perf_counter() - t0, device=None if via_host else "cuda")
             value_h2d = args.gpus * S * per * n_h * args.frames / el_h
+
+        # ---- N > 1, default mode: the line's `value` is the sequence-sharded rate (the contract's weak scaling: every
+        # rank its own sequences, no collective); the north star's OTHER way to use the ranks — the frames of one sequence
+        # sharded over them, key all-gather + hidden-state hand-off (dist.FrameShardRunner) — is timed in the same
+        # invocation by all ranks and reported beside it as `frames_mode` (latency of one sequence, steady state)
+        frames_extra = None
+        if not frames_mode and world > 1 and args.frames_extra != "off" and \
+                (args.frames % world == 0 or world % args.frames == 0):
+            def time_frames_extra():
+                plan2 = D.FrameShardPlan(args.frames, rank, world)
+                x_backend = args.frames_extra if args.dist_backend == "nccl" else args.dist_backend
+                x_host = x_backend != "nccl"
+                if x_backend == "gloo" and args.dist_backend != "gloo":
+                    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")      # rendezvous is on 127.0.0.1
+                group2 = None
+                for gi in range(plan2.nr_groups):                           # (collective: every rank creates every group)
+                    gr = dist.new_group(list(range(gi * plan2.group_size, (gi + 1) * plan2.group_size)), backend=x_backend)
+                    if gi == plan2.group:
+                        group2 = gr
+                fr2 = frames if plan2.group == 0 and rank == 0 else \
+                    [(torch.from_numpy(p).cuda(), torch.from_numpy(v).cuda())
+                     for p, v in make_sequence(args.points, args.frames, seed=1234 + plan2.group)]
+                runner2 = D.FrameShardRunner(model, lambda: make_lattice(contents), plan2, group=group2, via_host=x_host)
+                mine2 = {f: fr2[f] for f in plan2.frames}
+                dev = None if via_host else "cuda"                          # (the MAX over ranks on the job's own group)
+
+                def steps2(n):
+                    keys = runner2.exchange_keys([mine2] * n)
+                    for i in range(n):
+                        runner2.run_sequence(mine2, keys[i])
+
+                def latency2():
+                    barrier()
+                    t_ = time.perf_counter()
+                    steps2(1)
+                    barrier()
+                    return D.max_over_ranks(time.perf_counter() - t_, device=dev)
+
+                try:
+                    n_f = max(2, args.steps // 4)
+                    steps2(max(1, args.warmup // 2))
+                    lat2 = min(latency2() for _ in range(3))
+                    barrier()
+                    t0_ = time.perf_counter()
+                    steps2(n_f)
+                    barrier()
+                    el2 = D.max_over_ranks(time.perf_counter() - t0_, device=dev)
+                finally:
+                    runner2.close()
+                return {"latency_ms_per_sequence": round(lat2 * 1e3, 3),
+                        "steady_state_clouds_per_s": round(plan2.nr_groups * n_f * args.frames / el2, 3), "steps": n_f,
+                        "ranks_per_sequence": plan2.group_size, "groups": plan2.nr_groups,
+                        "transport": "RCCL (device tensors over xGMI)" if not x_host else
+                                     "gloo side group: vertex keys and hidden states staged through host memory "
+                                     "(--frames-extra nccl: RCCL)",
+                        "note": "the frames of every sequence sharded over %d ranks (rank g owns frame-slot g: all-gather of "
+                                "the per-frame vertex keys, point-to-point hand-off of the fusion modules' hidden states), "
+                                "%d group(s); latency: one %d-frame sequence alone through the pipeline (best of 3); "
+                                "steady state: sequences back to back.  `value` above is the sequence-sharded rate of the "
+                                "same ranks" % (plan2.group_size, plan2.nr_groups, args.frames)}
+
+            try:
+                frames_extra = time_frames_extra()
+            except Exception as e:                                          # never at the price of the line
+                frames_extra = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
 
         # ---- what the timed region computed, checked: one more step of the same configuration with the outputs kept;
         # one sequence per stream (at different positions of its lock-step group) against the same sequence run ALONE
@@ -457,6 +528,8 @@ def main():
             "value_h2d": None if value_h2d is None else round(value_h2d, 3),
             "roofline": roof, "roofline_scatter": scatter, "cpu_baseline": cpu, "checked": checked,
         }
+        if not frames_mode and frames_extra is not None:
+            line["frames_mode"] = frames_extra
         if frames_mode:
             # the recurrence bounds what one sequence gains from more GPUs (latency); a stream of
             # sequences keeps every rank busy with a different one (steady state = `value`)

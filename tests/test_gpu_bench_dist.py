@@ -62,6 +62,10 @@ def test_bench_sequence_sharding_two_ranks(gpu):
     assert abs(d["value"] - 2 * 2 * 2 * 2 * 4 / (d["ms_per_step"] * 2e-3)) < 1e-3 * d["value"]
     assert "2 lock-stepped" in d["config"]["parallelism"]
     assert "no data-path collective" in d["config"]["parallelism"]
+    # ... and the same invocation also times the north star's frame sharding over the two ranks (4 frames: blocks of two)
+    fm = d["frames_mode"]
+    assert fm["ranks_per_sequence"] == 2 and fm["groups"] == 1
+    assert fm["latency_ms_per_sequence"] > 0 and fm["steady_state_clouds_per_s"] > 0
 
 
 @pytest.mark.parametrize("world", [2, 4])
