@@ -205,7 +205,8 @@ int tln_gather_gemm_ex(int64_t M, int N, const tln_gemm_src* s0, const tln_gemm_
                        const float* d_w, int w_is_nk, const float* d_bias, const float* d_residual,
                        int64_t ld_res, int relu, float* d_out, int64_t ld_out, void* d_stats, void* stream);
 
-/* tuning hook: force the block tile (TM,TN in {1,2}; 0 = heuristic) */
+/* tuning hook: force the block tile of the tiled kernel (tn in {1,2}: 64 / 128 columns; 0 = heuristic; tm is ignored
+ * since round 3: the 128-row tiles were removed, large M belongs to the gemm_v2 kernel) */
 void tln_gemm_force_tiles(int tm, int tn);
 /* Two independent products in one launch: for a host that steps two sequences in lock-step on one stream (the
  * frame program's pair mode, tln_program_run_pair).  Each call is what tln_gather_gemm_ex would take.  When both

@@ -14,6 +14,7 @@ SOURCES = {
     # file -> extra flags.  lattice.hip must not contract a*b+c: its integer outputs are bit-exact vs the oracle
     "lattice.hip": ["-ffp-contract=off"],
     "pool.hip": [],
+    "legacy.hip": [],     # kernels behind test / measurement switches only (see its header)
     "gemm.hip": [],
     # gemm_v2.hip: a product launched alone and the same product inside a shared launch are two instantiations of one
     # body and must give the same bits: no contraction left to the compiler's discretion (explicit fmaf where wanted)
@@ -43,7 +44,7 @@ def _stale(target, deps):
 
 def build(force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_args.h"), os.path.join(INCLUDE, "tln.h"),
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_args.h"), os.path.join(CSRC, "pool_common.h"), os.path.join(INCLUDE, "tln.h"),
                os.path.abspath(__file__)]
     hipcc = _hipcc()
     jobs = []

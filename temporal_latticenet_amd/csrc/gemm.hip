@@ -951,11 +951,10 @@ static int dispatch(GemmArgs& g, const Plan& p, hipStream_t s) {
     if (p.groups == 2) return launch_gemm<1, 1, 1, BK, 2, W_NK, true>(g, p.splits, s);
     return launch_gemm<1, 1, 1, BK, 1, W_NK, true>(g, p.splits, s);
   }
-  if (p.tm == 2 && p.tn == 2) return launch_gemm<2, 2, 2, BK, 1, W_NK, true>(g, p.splits, s);
-  if (p.tm == 2) return launch_gemm<2, 2, 1, BK, 1, W_NK, true>(g, p.splits, s);
+  // (round 3: the 128-row tiles <2,2,1>, <2,2,2> and the K-groups of the 64-row tile — 16 instantiations only the force
+  // hooks reached, measured slower than what the heuristic picks at every size of round 1 — are gone; level-0 sized
+  // products belong to gemm_v2.hip now)
   if (p.tn == 2) return launch_gemm<2, 1, 2, BK, 1, W_NK, true>(g, p.splits, s);
-  if (p.groups >= 4) return launch_gemm<2, 1, 1, BK, 4, W_NK, true>(g, p.splits, s);
-  if (p.groups == 2) return launch_gemm<2, 1, 1, BK, 2, W_NK, true>(g, p.splits, s);
   return launch_gemm<2, 1, 1, BK, 1, W_NK, true>(g, p.splits, s);
 }
 
@@ -1032,15 +1031,12 @@ static Plan make_plan(int64_t M, int N, int nchunks) {
     const int per = (nchunks + splits - 1) / splits;
     p.groups = splits == 1 ? (per >= 8 ? 4 : (per >= 4 ? 2 : 1)) : (per >= 4 ? 2 : 1);
   }
-  if (g_force_tm) p.tm = g_force_tm;
   if (g_force_tn) p.tn = g_force_tn;
   if (g_force_wm) p.wm = g_force_wm;
   if (g_force_groups) p.groups = g_force_groups;
   if (g_force_splits) p.splits = g_force_splits;
-  if (p.tm == 2 || p.tn == 2) {
-    p.wm = 2;
-    p.groups = 1;
-  }
+  if (p.tn == 2) p.wm = 2;
+  if (p.wm == 2) p.groups = 1;
   if (p.splits > nchunks) p.splits = nchunks > 0 ? nchunks : 1;
   return p;
 }

@@ -74,7 +74,7 @@ def test_lattice_conv(gpu, cin, cout):
     assert torch.equal(rows.cpu(), O.im2row(lv, P.neighbour_table(tab)))
 
 
-@pytest.mark.parametrize("tm,tn", [(1, 1), (2, 1), (1, 2), (2, 2)])
+@pytest.mark.parametrize("tm,tn", [(1, 1), (1, 2)])
 def test_gemm_all_tiles_with_prologue_epilogue(gpu, tm, tn):
     from temporal_latticenet_amd import _lib, ops
     lat, tab, _, _ = _lattice(gpu, 20000, 0.5)
@@ -97,7 +97,7 @@ def test_gemm_all_tiles_with_prologue_epilogue(gpu, tm, tn):
     np.testing.assert_allclose(out.cpu().numpy(), want.numpy(), rtol=1e-4, atol=5e-5)
 
 
-@pytest.mark.parametrize("splits,wm,groups", [(1, 1, 1), (2, 1, 2), (4, 1, 1), (8, 2, 1), (3, 2, 4), (2, 1, 4)])
+@pytest.mark.parametrize("splits,wm,groups", [(1, 1, 1), (2, 1, 2), (4, 1, 1), (8, 2, 1), (3, 2, 1), (2, 1, 4)])
 def test_gemm_split_k_is_exact_and_reproducible(gpu, splits, wm, groups):
     """split-K over the grid (slab + last-arriver reduction in fixed slice order), 32- and 64-row tiles, K-groups,
     and the fused GroupNorm partial sums of the epilogue"""
