@@ -247,6 +247,24 @@ void tln_gemm_v2_config(int off, int64_t min_m);
  * index/GroupNorm prologue, after the K loop, after the reductions, end) to d_buf (5 x u64); NULL switches it off */
 void tln_gemm_debug_stamps(void* d_buf);
 
+/* ---- backward of the gather-GEMM (training: train_ln.py:212-233 calls loss.backward() through these products) ------
+ * dW [taps*cin, N] (the [K, N] layout of lm:291; a Linear's [N, K] gradient is its transpose) =
+ * sum_m gather(src, table)[m, :]^T dout[m, :].  MFMA tiles over (tap, 32 channels, 32-64 columns), M cut into slices
+ * whose partial tiles are added in slice order: deterministic, no atomics.  cin a multiple of 32; taps 1 (d_table NULL:
+ * row m itself) or TLN_TAPS.  d_ws: tln_gather_gemm_dw_ws_floats(M, cin, taps, N) floats.
+ * dA needs no entry point of its own: for a level's own neighbour table (paired taps) and for 1x1 products it is a
+ * forward gather-GEMM with rearranged weights (temporal_latticenet_amd/autograd.py). */
+int64_t tln_gather_gemm_dw_ws_floats(int64_t M, int cin, int taps, int N);
+int tln_gather_gemm_dw(const float* d_src, int64_t src_rows, int cin, const int32_t* d_table, int taps,
+                       const float* d_dout, int64_t M, int N, float* d_dw, float* d_ws, int64_t ws_floats, void* stream);
+/* backward of the slice blends as segment sums over the lattice's vertex-sorted row list (tln_build_csr over the same
+ * rows): d_out [V, C] = sum over the rows of v of (w_row + delta_row) * dvals[row >> 2 (per_row: row)][:C]; and
+ * d_dw [rows] = dot(lv[idx_row], dout[row >> 2]).  Deterministic (no float atomics). */
+int tln_slice_blend_bwd_lv(tln_lattice_t* l, const float* d_dvals, int64_t ld, int C, int per_row, const float* d_weights,
+                           const float* d_delta, int64_t rows, float* d_out, void* stream);
+int tln_slice_blend_bwd_w(const float* d_lv, int64_t V, int C, const int32_t* d_indices, const float* d_dout,
+                          int64_t rows, float* d_dw, void* stream);
+
 /* materialised im2row (API parity with Im2RowLattice / Im2RowIndicesLattice, lm:301-304) */
 int tln_im2row(const float* d_src, int64_t src_rows, int cin, const int32_t* d_table, int64_t M,
                float* d_out /* [M, 9*cin] */, void* stream);

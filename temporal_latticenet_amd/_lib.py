@@ -85,6 +85,10 @@ _PROTOS = {
     "tln_gru_cell_multi": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "tln_lattice_prepare_levels_begin_multi": (_i, [_vp, _i, _i, _vp, _vp]),
     "tln_lattice_prepare_levels_finish_multi": (_i, [_vp, _i, _vp]),
+    "tln_gather_gemm_dw_ws_floats": (_i64, [_i64, _i, _i, _i]),
+    "tln_gather_gemm_dw": (_i, [_vp, _i64, _i, _vp, _i, _vp, _i64, _i, _vp, _vp, _i64, _vp]),
+    "tln_slice_blend_bwd_lv": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp, _i64, _vp, _vp]),
+    "tln_slice_blend_bwd_w": (_i, [_vp, _i64, _i, _vp, _vp, _i64, _vp, _vp]),
     "tln_pointnet_pool_multi": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp]),
     "tln_program_group_config": (_i, [_i]),
     "tln_program_begin_frame_group": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),

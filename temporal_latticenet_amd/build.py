@@ -14,6 +14,7 @@ SOURCES = {
     # file -> extra flags.  lattice.hip must not contract a*b+c: its integer outputs are bit-exact vs the oracle
     "lattice.hip": ["-ffp-contract=off"],
     "pool.hip": [],
+    "backward.hip": [],   # training path: dW of the gather-GEMM, the slice blends' backward
     "legacy.hip": [],     # kernels behind test / measurement switches only (see its header)
     "gemm.hip": [],
     # gemm_v2.hip: a product launched alone and the same product inside a shared launch are two instantiations of one

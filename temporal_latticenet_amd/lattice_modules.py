@@ -169,12 +169,12 @@ class _TapConv(torch.nn.Module):
             bound = 1.0 / math.sqrt(self.nr_filters)
             self.bias = torch.nn.Parameter(torch.empty(self.nr_filters, device="cuda").uniform_(-bound, bound))
 
-    def _product(self, rows, lv, table_ptr, prologue, residual, table_tensor=None):
+    def _product(self, rows, lv, table_ptr, prologue, residual, table_tensor=None, symmetric=False):
         if self.weight is None:
             self._make(lv.shape[1])
         if AG.grad_mode():                       # training path: autograd wrapper around the same kernel
             assert prologue is None
-            return AG.gather_gemm(rows, lv, table_tensor(), self.weight, self.bias, residual)
+            return AG.gather_gemm(rows, lv, table_tensor(), self.weight, self.bias, residual, symmetric=symmetric)
         gn = None
         if prologue is not None and prologue[0] == "gn":      # GroupNorm+ReLU of `lv` inside the same host call
             gn, prologue = (lv, prologue[1].ensure(lv), True), None
@@ -193,7 +193,7 @@ class ConvLatticeModule(_TapConv):
 
     def forward(self, lv, ls, prologue=None, residual=None):
         out = self._product(ls.nr_lattice_vertices(), lv, ls.neighbour_table_ptr(), prologue, residual,
-                            ls.neighbour_table)
+                            ls.neighbour_table, symmetric=True)
         ls.set_values(out)
         return out, ls
 
@@ -401,10 +401,10 @@ class SliceFastCUDALatticeModule(torch.nn.Module):
                 for m in self.stepdown:
                     b, _ = m(b, ls)
                 b, _ = self.bottleneck(b, ls)
-                g = AG.slice_gather(b, indices, weights)
+                g = AG.slice_gather(b, indices, weights, lattice=ls)
                 hdn = torch.relu(torch.nn.functional.linear(g, self.linear_pre_deltaW.weight))
                 delta = torch.nn.functional.linear(hdn, self.linear_deltaW.weight, self.linear_deltaW.bias)
-            feat = AG.slice_blend(lv, indices, weights, delta)
+            feat = AG.slice_blend(lv, indices, weights, delta, lattice=ls)
             ls.set_values(lv)
             return torch.nn.functional.linear(feat, self.linear_clasify.weight, self.linear_clasify.bias)
         b = None

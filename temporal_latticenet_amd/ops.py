@@ -273,6 +273,41 @@ def slice_blend(lv, indices, weights, delta=None, bias=None):
     return out
 
 
+def gather_gemm_dw(src, table_ptr, taps, dout, M):
+    """dW [taps*cin, N] of out = im2row(src, table) @ W (tln_gather_gemm_dw: MFMA tiles, slices of M added in a fixed
+    order); cin a multiple of 32"""
+    src, dout = _f32c(src), _f32c(dout)
+    cin, n = src.shape[1], dout.shape[1]
+    lib = _lib.lib()
+    ws = torch.empty((int(lib.tln_gather_gemm_dw_ws_floats(M, cin, taps, n)),), dtype=torch.float32, device="cuda")
+    dw = torch.empty((taps * cin, n), dtype=torch.float32, device="cuda")
+    _lib.check(lib.tln_gather_gemm_dw(_ptr(src), src.shape[0], cin, table_ptr if taps > 1 else None, taps, _ptr(dout), M, n,
+                                      _ptr(dw), _ptr(ws), ws.numel(), stream_ptr()), "tln_gather_gemm_dw")
+    return dw
+
+
+def slice_blend_bwd_lv(lattice: Lattice, dvals, C, weights, delta, indices, per_row=False):
+    """[V, C] = per-vertex sum of (w + delta)_row * dvals[row >> 2 (per_row: row)][:C] over the vertex-sorted row list"""
+    lattice.ensure_csr(indices)
+    dvals = _f32c(dvals)
+    out = torch.empty((lattice.nr_lattice_vertices(), C), dtype=torch.float32, device="cuda")
+    rows = indices.shape[0]
+    _lib.check(_lib.lib().tln_slice_blend_bwd_lv(lattice._h, _ptr(dvals), dvals.shape[-1], C, 1 if per_row else 0,
+                                                 _ptr(_f32c(weights)), _ptr(_f32c(delta)), rows, _ptr(out), stream_ptr()),
+               "tln_slice_blend_bwd_lv")
+    return out
+
+
+def slice_blend_bwd_w(lv, indices, dout):
+    """[4N] = dot(lv[idx_row], dout[row >> 2])"""
+    lv, dout = _f32c(lv), _f32c(dout)
+    rows = indices.shape[0]
+    dw = torch.empty((rows,), dtype=torch.float32, device="cuda")
+    _lib.check(_lib.lib().tln_slice_blend_bwd_w(_ptr(lv), lv.shape[0], lv.shape[1], _ptr(indices.contiguous()), _ptr(dout),
+                                                rows, _ptr(dw), stream_ptr()), "tln_slice_blend_bwd_w")
+    return dw
+
+
 def slice_deform(b, scores, indices, weights, w_pre, w_dw, b_dw, bias=None):
     """the DeformSlice head per point in one kernel (tln_slice_deform): logits [n, C]"""
     b, scores = _f32c(b), _f32c(scores)

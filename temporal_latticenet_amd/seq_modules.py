@@ -267,7 +267,7 @@ class CustomKernelConvLatticeIm2RowModule(torch.nn.Module):
             V, Cn = lattice_values.shape
             table = lattice_structure.neighbour_table()
             hp = AG.pad_rows(hidden_state, V, -999999.0)
-            nbrs = AG.im2row(hp, table).reshape(V, 9, Cn)
+            nbrs = AG.im2row(hp, table, symmetric=True).reshape(V, 9, Cn)      # the level's own table: taps pair up
             valid = (table != -1).float()
             d = torch.cdist(nbrs, lattice_values.unsqueeze(1), p=2.0).squeeze(2) * valid
             if not self.use_center:

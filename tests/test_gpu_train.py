@@ -53,7 +53,7 @@ def test_parameter_gradients_match_oracle_autograd(gpu, rnn):
     oloss = torch.nn.functional.nll_loss(torch.log_softmax(sv, 1), target)
     oloss.backward()
     assert abs(float(loss.detach()) - float(oloss.detach())) < 1e-4
-    checked = 0
+    checked, worst = 0, 0.0
     for k, g in got.items():
         og = oracle.sd[k].grad
         if og is None:
@@ -62,9 +62,11 @@ def test_parameter_gradients_match_oracle_autograd(gpu, rnn):
         scale = max(float(og.abs().max()), 1e-6)
         err_max = float((g - og).abs().max()) / scale
         err_l2 = float((g - og).norm()) / max(float(og.norm()), 1e-9)
-        assert err_l2 < 5e-3 and err_max < 3e-2, "%s: gradient error l2 %.3e max %.3e" % (k, err_l2, err_max)
+        assert err_l2 < 1e-3 and err_max < 1e-2, "%s: gradient error l2 %.3e max %.3e" % (k, err_l2, err_max)
+        worst = max(worst, err_l2)
         checked += 1
     assert checked > 40
+    print("[gradients] %s: %d parameters, worst relative l2 error %.3e" % (",".join(rnn), checked, worst))
     # every parameter the oracle gives a gradient to also got one on the GPU
     for k, v in oracle.sd.items():
         if v.is_floating_point() and v.grad is not None and float(v.grad.abs().max()) > 0:
@@ -90,3 +92,64 @@ def test_training_step_reduces_the_loss(gpu):
         model.reset_sequence()
         losses.append(float(loss))
     assert losses[-1] < losses[0], losses
+
+
+def test_backward_kernels_are_deterministic_and_agree_with_the_torch_formulation(gpu):
+    """csrc/backward.hip: dW by MFMA tiles with a fixed slice order, dA as a gather-GEMM through the paired taps, the
+    slice blends' backward as segment sums — (i) two backward passes give the SAME BITS for every parameter (the torch
+    formulation scatters with index_add_: float atomics), (ii) the gradients agree with that formulation (materialised
+    im2row + index_add_, autograd.torch_backward) to float rounding."""
+    from temporal_latticenet_amd import autograd as AG
+    contents = make_config(frames=2, sigma=0.8)
+    seq = make_sequence(6000, 2, seed=63)
+    model = build_model(contents).train()
+    with torch.no_grad():
+        _forward(model, contents, seq, gpu, False)
+    model.reset_sequence()
+    randomize_parameters(model, seed=6)
+    target = torch.randint(0, 26, (6000,), generator=torch.Generator().manual_seed(1)).to(gpu)
+
+    def grads():
+        model.zero_grad(set_to_none=True)
+        logsm, _ = _forward(model, contents, seq, gpu, True)
+        torch.nn.functional.nll_loss(logsm, target).backward()
+        model.reset_sequence()
+        return {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+
+    a, b = grads(), grads()
+    assert a.keys() == b.keys() and len(a) > 40
+    for k in a:
+        assert torch.equal(a[k], b[k]), "%s: two backward passes differ" % k
+    AG.torch_backward(True)
+    try:
+        ref = grads()
+    finally:
+        AG.torch_backward(False)
+    for k in a:
+        scale = max(float(ref[k].abs().max()), 1e-9)
+        assert float((a[k] - ref[k]).abs().max()) <= 2e-4 * scale + 1e-7, k
+
+
+@pytest.mark.parametrize("cin,cout,taps", [(64, 64, 9), (192, 192, 9), (128, 64, 9), (192, 576, 1), (96, 8, 1), (192, 26, 1)])
+def test_gather_gemm_dw_kernel(gpu, cin, cout, taps):
+    """tln_gather_gemm_dw against im2row(src)^T @ dout in float64, on a ragged ~9k-vertex lattice"""
+    from oracle import ops as O
+    from oracle import permuto as P
+    from temporal_latticenet_amd import ops
+    from temporal_latticenet_amd.lattice import Lattice
+    pos, val = make_sequence(20000, 1, seed=21)[0]
+    lat = Lattice.from_params([0.5] * 3, 1 << 17)
+    lat.distribute(torch.from_numpy(pos).to(gpu), torch.from_numpy(val).to(gpu))
+    V = lat.nr_lattice_vertices()
+    tab = lat.neighbour_table().cpu().numpy()
+    g = torch.Generator().manual_seed(cin + cout)
+    src = torch.randn(V, cin, generator=g)
+    dout = torch.randn(V, cout, generator=g)
+    dw = ops.gather_gemm_dw(src.to(gpu), lat.neighbour_table_ptr() if taps == 9 else None, taps, dout.to(gpu), V)
+    again = ops.gather_gemm_dw(src.to(gpu), lat.neighbour_table_ptr() if taps == 9 else None, taps, dout.to(gpu), V)
+    assert torch.equal(dw, again)
+    a = (O.im2row(src, tab) if taps == 9 else src).double()
+    want = a.t() @ dout.double()
+    scale = float(want.abs().max())
+    assert tuple(dw.shape) == (taps * cin, cout)
+    assert float((dw.cpu().double() - want).abs().max()) <= 2e-5 * scale
