@@ -24,8 +24,11 @@ class OracleLNN:
     def __init__(self, sd, nr_classes, rnn_modules, sequence_learning=True, pointnet_layers=(16, 32, 64),
                  nr_downsamples=2, nr_blocks_down_stage=(2, 2, 2), nr_blocks_bottleneck=3,
                  nr_blocks_up_stage=(1, 2, 2), sigmas=(0.6, 0.6, 0.6), capacity=100000, experiment="none",
-                 nr_levels_down_with_normal_resnet=3, nr_levels_up_with_normal_resnet=3, scale_constant=None):
-        self.sd = {k: v.detach().cpu().float() if v.is_floating_point() else v.detach().cpu() for k, v in sd.items()}
+                 nr_levels_down_with_normal_resnet=3, nr_levels_up_with_normal_resnet=3, scale_constant=None,
+                 dtype=torch.float32):
+        # dtype = torch.float64: the reference for GRADIENT checks (tests/test_gpu_train.py) — a float32 CPU autograd pass
+        # through ~60 layers carries rounding noise of the size of the errors to be measured
+        self.sd = {k: v.detach().cpu().to(dtype) if v.is_floating_point() else v.detach().cpu() for k, v in sd.items()}
         self.nr_classes = nr_classes
         self.rnn = [m if m in ("linear", "maxpool", "cga", "aflow", "lstm", "gru") else "none" for m in rnn_modules]
         self.seq = sequence_learning

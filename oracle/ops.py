@@ -124,9 +124,34 @@ def linear_fma(x, w, b, relu):
 
 def pointnet_pool(distributed, indices, nr_vertices, weights, biases, min_points=4, exact=True):
     """exact=True: the MLP in the pinned fma order (linear_fma) — what the HIP kernel is compared with bit for bit;
-    exact=False: torch's F.linear (the eager CPU timing baseline of bench.py)."""
+    exact=False: torch's F.linear (the eager CPU timing baseline of bench.py);
+    exact="grad": for gradient checks — the arg-max rows are SELECTED with the pinned fma order (so they are the rows
+    the HIP pool selects), the values that autograd differentiates are F.linear's of those very rows."""
     distributed = torch.as_tensor(distributed)
     indices = torch.as_tensor(indices)
+    if exact == "grad":
+        with torch.no_grad():
+            sel_w = [w.detach() for w in weights]
+            sel_b = [None if b is None else b.detach() for b in biases]
+            hard = pointnet_pool(distributed, indices, nr_vertices, sel_w, sel_b, min_points, exact=True)
+            xs = distributed[:, :distributed.shape[1] - 1]
+            for i, (w, b) in enumerate(zip(sel_w, sel_b)):
+                xs = torch.from_numpy(linear_fma(xs.numpy(), w.numpy(), None if b is None else b.numpy(),
+                                                 i != len(sel_w) - 1))
+            il = indices.long().clone()
+            il[il < 0] = 0
+            _, argmax = scatter_max(xs, il, nr_vertices)
+        x = distributed[:, :distributed.shape[1] - 1].to(weights[0].dtype)
+        for i, (w, b) in enumerate(zip(weights, biases)):
+            x = F.linear(x, w, b)
+            if i != len(weights) - 1:
+                x = torch.relu(x)
+        rows, c = x.shape
+        live = (argmax < rows) & (hard[:, :c] != 0)                  # empty / masked vertices carry no gradient
+        soft = x[argmax.clamp(max=rows - 1), torch.arange(c)[None, :]]
+        out = hard.clone().to(x.dtype)
+        out[:, :c] = torch.where(live, soft, out[:, :c])
+        return out
     barycentric_weights = distributed[:, -1]                                   # lm:448
     x = distributed[:, :distributed.shape[1] - 1]                              # lm:452
     for i, (w, b) in enumerate(zip(weights, biases)):                          # lm:460-473

@@ -19,7 +19,7 @@ def randomize_parameters(model, seed=0):
                 continue
 
 
-def oracle_from_model(model, contents, nr_classes=26):
+def oracle_from_model(model, contents, nr_classes=26, dtype=None):
     from oracle.model import OracleLNN
     m = contents["model"]
     lg = contents["lattice_gpu"]
@@ -27,7 +27,7 @@ def oracle_from_model(model, contents, nr_classes=26):
     return OracleLNN(model.state_dict(), nr_classes, m["rnn_modules"], m["sequence_learning"], m["pointnet_layers"],
                      m["nr_downsamples"], m["nr_blocks_down_stage"], m["nr_blocks_bottleneck"],
                      m["nr_blocks_up_stage"], [sigma] * 3, int(lg["hash_table_capacity"]), m["experiment"],
-                     scale_constant=_scale_constant(lg.get("scale_constant")))
+                     scale_constant=_scale_constant(lg.get("scale_constant")), **({} if dtype is None else {"dtype": dtype}))
 
 
 def _scale_constant(v):
