@@ -250,7 +250,7 @@ void tln_gemm_debug_stamps(void* d_buf);
 /* ---- backward of the gather-GEMM (training: train_ln.py:212-233 calls loss.backward() through these products) ------
  * dW [taps*cin, N] (the [K, N] layout of lm:291; a Linear's [N, K] gradient is its transpose) =
  * sum_m gather(src, table)[m, :]^T dout[m, :].  MFMA tiles over (tap, 32 channels, 32-64 columns), M cut into slices
- * whose partial tiles are added in slice order: deterministic, no atomics.  cin a multiple of 32; taps 1 (d_table NULL:
+ * whose partial tiles are added in slice order: deterministic, no atomics.  taps 1 (d_table NULL:
  * row m itself) or TLN_TAPS.  d_ws: tln_gather_gemm_dw_ws_floats(M, cin, taps, N) floats.
  * dA needs no entry point of its own: for a level's own neighbour table (paired taps) and for 1x1 products it is a
  * forward gather-GEMM with rearranged weights (temporal_latticenet_amd/autograd.py). */

@@ -53,9 +53,10 @@ class GatherGemmFn(torch.autograd.Function):
     """out[M,N] = act( im2row(src, table) @ W + bias + residual ); table [M,9] int32 or None (identity rows)"""
 
     @staticmethod
-    def forward(ctx, M, src, table, weight, bias, residual, w_is_nk, relu, symmetric=False):
+    def forward(ctx, M, src, table, weight, bias, residual, w_is_nk, relu, symmetric=False, src_lattice=None):
         src = src.contiguous()
         ctx.symmetric = bool(symmetric)
+        ctx.src_lattice = src_lattice
         taps = 9 if table is not None else 1
         with torch.no_grad():
             out = ops.gather_gemm(M, weight, ops.gemm_src(src, _tptr(table), taps), w_is_nk=w_is_nk, bias=bias,
@@ -100,6 +101,18 @@ class GatherGemmFn(torch.autograd.Function):
                 # paired taps: dsrc[j] = sum_k dout[table[j, k^1]] @ W_k^T  -> weight blocks swapped pairwise, transposed
                 wp = weight.view(9, c, n)[_PAIR].transpose(1, 2).reshape(9 * n, c).contiguous()
                 dsrc = ops.gather_gemm(M, wp, ops.gemm_src(dout, _tptr(table), 9))
+            elif table is not None and hip and ctx.src_lattice is not None and not ctx.w_is_nk and \
+                    ctx.src_lattice.nr_lattice_vertices() >= src.shape[0]:
+                # a cross-level table (coarsen / finefy: no paired taps): drows = dout @ W^T on the forward kernel, then
+                # every source row sums the entries that point at it in a FIXED order — the flat table sorted stably by
+                # source row (the source level's tln_build_csr), one wave per source row (tln_slice_blend_bwd_lv)
+                drows = ops.gather_gemm(M, weight, ops.gemm_src(dout, None, 1), w_is_nk=True)      # [M, 9c]
+                flat = table.reshape(-1).contiguous()
+                ones = torch.ones((flat.shape[0],), dtype=torch.float32, device=dout.device)
+                # (the level may have grown since this frame's forward — backward runs after the whole sequence —: the
+                # numbering is append-only, the rows this frame knew come first)
+                dsrc = ops.slice_blend_bwd_lv(ctx.src_lattice, drows.view(-1, c), c, ones, None, flat,
+                                              per_row=True)[: src.shape[0]].contiguous()
             else:
                 w_kn = weight.t() if ctx.w_is_nk else weight                         # [K, N]
                 drows = dout @ w_kn.t()                                              # [M, K]
@@ -115,13 +128,15 @@ class GatherGemmFn(torch.autograd.Function):
                         dsrc.index_add_(0, idx[ok], drows[ok, t * c:(t + 1) * c])
         dbias = dout.sum(0) if ctx.has_bias else None
         dres = dout if ctx.has_res else None
-        return None, dsrc, None, dW.contiguous(), dbias, dres, None, None, None
+        return None, dsrc, None, dW.contiguous(), dbias, dres, None, None, None, None
 
 
-def gather_gemm(M, src, table, weight, bias=None, residual=None, w_is_nk=False, relu=False, symmetric=False):
+def gather_gemm(M, src, table, weight, bias=None, residual=None, w_is_nk=False, relu=False, symmetric=False,
+                src_lattice=None):
     """symmetric: `table` is the neighbour table of the level `src` lives on (ConvLatticeModule): its taps pair up, which
-    turns dA into a gather-GEMM; the cross-level tables of coarsen / finefy do not"""
-    return GatherGemmFn.apply(M, src, table, weight, bias, residual, w_is_nk, relu, symmetric)
+    turns dA into a gather-GEMM; the cross-level tables of coarsen / finefy do not — for those `src_lattice` (the level `src`
+    lives on) lends its row sorter, so that their dA is a fixed-order segment sum instead of an index_add_"""
+    return GatherGemmFn.apply(M, src, table, weight, bias, residual, w_is_nk, relu, symmetric, src_lattice)
 
 
 class Im2RowFn(torch.autograd.Function):
@@ -184,16 +199,38 @@ class PoolFn(torch.autograd.Function):
         rows = argrow[mask].long()
         cols = mask.nonzero()[:, 1]
         g = d[mask]
-        with torch.enable_grad():
-            ps = [p.detach().requires_grad_(True) for p in params]
-            x = distributed[rows, : ps[0].shape[1]]
-            for i in range(nl):
-                x = F.linear(x, ps[i], ps[nl + i])
-                if i < nl - 1:
-                    x = torch.relu(x)
-            sel = x.gather(1, cols[:, None]).squeeze(1)
-            grads = torch.autograd.grad(sel, ps, g)
-        return (None, None, None, None) + tuple(grads)
+        ws, bs = [p.detach() for p in params[:nl]], [p.detach() for p in params[nl:]]
+        if _TORCH_BACKWARD:
+            with torch.enable_grad():
+                ps = [p.detach().requires_grad_(True) for p in params]
+                x = distributed[rows, : ps[0].shape[1]]
+                for i in range(nl):
+                    x = F.linear(x, ps[i], ps[nl + i])
+                    if i < nl - 1:
+                        x = torch.relu(x)
+                sel = x.gather(1, cols[:, None]).squeeze(1)
+                grads = torch.autograd.grad(sel, ps, g)
+            return (None, None, None, None) + tuple(grads)
+        # the MLP again on the arg-max rows (one per (vertex, channel)), then its backward layer by layer on the
+        # deterministic product kernels: dW_i = h_{i-1}^T dz_i (tln_gather_gemm_dw), dh_{i-1} = dz_i W_i (the forward
+        # kernel) — torch's own GEMM may cut the long dimension (R ~ 64 V rows) into atomically added slices
+        R = rows.shape[0]
+        if R == 0:
+            return (None, None, None, None) + tuple(torch.zeros_like(p) for p in params)
+        hs = [distributed[rows, : ws[0].shape[1]].contiguous()]
+        for i in range(nl):
+            y = F.linear(hs[-1], ws[i], bs[i])
+            hs.append(torch.relu(y) if i < nl - 1 else y)
+        dz = torch.zeros((R, cout), dtype=torch.float32, device=g.device)
+        dz[torch.arange(R, device=g.device), cols] = g                      # one entry per row: no collisions
+        dws, dbs = [None] * nl, [None] * nl
+        for i in range(nl - 1, -1, -1):
+            dws[i] = ops.gather_gemm_dw(hs[i], None, 1, dz, R).t().contiguous()      # [cout_i, cin_i]
+            dbs[i] = dz.sum(0)
+            if i > 0:
+                dh = ops.gather_gemm(R, ws[i], ops.gemm_src(dz, None, 1), w_is_nk=False)   # dz @ W_i  ([K=cout_i, N=cin_i])
+                dz = dh * (hs[i] > 0)
+        return (None, None, None, None) + tuple(dws) + tuple(dbs)
 
 
 def pointnet_pool(lattice, distributed, indices, weights, biases, min_points):

@@ -31,7 +31,7 @@ template <int TN>
 __global__ void __launch_bounds__(256) k_gather_gemm_dw(const DwArgs a) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int l31 = lane & 31, half = lane >> 5;
-  const int cblocks = a.cin >> 5;
+  const int cblocks = (a.cin + 31) >> 5;
   const int tap = blockIdx.x / cblocks, c0 = (blockIdx.x - tap * cblocks) << 5;
   const int n0 = (blockIdx.y * 4 + wv) * 32 * TN;
   if (n0 >= a.N) return;
@@ -56,7 +56,7 @@ __global__ void __launch_bounds__(256) k_gather_gemm_dw(const DwArgs a) {
       int64_t idx = -1;
       if (live) idx = table ? (int64_t)table[m * a.taps + tap] : m;
       const bool has = idx >= 0 && idx < a.src_rows;
-      av[u] = has ? src[idx * a.cin + c0 + l31] : 0.0f;
+      av[u] = (has && c0 + l31 < a.cin) ? src[idx * a.cin + c0 + l31] : 0.0f;
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int n = n0 + 32 * j + l31;
@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(256) k_gather_gemm_dw(const DwArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int c = c0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      out[((size_t)tap * a.cin + c) * a.N + n] = acc[j][r];
+      if (c < a.cin) out[((size_t)tap * a.cin + c) * a.N + n] = acc[j][r];
     }
   }
 }
@@ -94,7 +94,7 @@ __global__ void __launch_bounds__(256) k_dw_reduce(const float* __restrict__ ws,
 
 static void dw_geometry(int64_t M, int cin, int taps, int N, int* tn, int* splits, int64_t* rows_per_split) {
   *tn = (N % 64 == 0) ? 2 : 1;
-  const int64_t waves = (int64_t)taps * (cin / 32) * tln_cdiv(N, 32 * *tn);
+  const int64_t waves = (int64_t)taps * tln_cdiv(cin, 32) * tln_cdiv(N, 32 * *tn);
   int64_t s = tln_cdiv(4096, waves);           // ~4 waves per SIMD over the chip
   const int64_t max_s = tln_cdiv(M, 256);      // a slice has at least 256 rows
   if (s > max_s) s = max_s;
@@ -118,7 +118,7 @@ extern "C" int tln_gather_gemm_dw(const float* d_src, int64_t src_rows, int cin,
                                   const float* d_dout, int64_t M, int N, float* d_dw, float* d_ws, int64_t ws_floats,
                                   void* stream_) {
   TLN_REQUIRE(d_src && d_dout && d_dw && d_ws, "null argument");
-  TLN_REQUIRE(M > 0 && N > 0 && cin > 0 && cin % 32 == 0 && (taps == 1 || taps == TLN_TAPS), "bad dW shape");
+  TLN_REQUIRE(M > 0 && N > 0 && cin > 0 && (taps == 1 || taps == TLN_TAPS), "bad dW shape");
   TLN_REQUIRE(taps == 1 || d_table, "a 9-tap product needs its table");
   int tn, splits;
   int64_t rps;
@@ -127,7 +127,7 @@ extern "C" int tln_gather_gemm_dw(const float* d_src, int64_t src_rows, int cin,
   TLN_REQUIRE(ws_floats >= (int64_t)splits * elems, "dW workspace too small");
   hipStream_t s = (hipStream_t)stream_;
   DwArgs a{d_src, taps == 1 ? nullptr : d_table, d_dout, d_ws, src_rows, M, rps, cin, N, taps, splits};
-  dim3 grid((unsigned)(taps * (cin / 32)), (unsigned)tln_cdiv(N, 128 * tn), (unsigned)splits);
+  dim3 grid((unsigned)(taps * tln_cdiv(cin, 32)), (unsigned)tln_cdiv(N, 128 * tn), (unsigned)splits);
   if (tn == 2) hipLaunchKernelGGL(k_gather_gemm_dw<2>, grid, dim3(256), 0, s, a);
   else hipLaunchKernelGGL(k_gather_gemm_dw<1>, grid, dim3(256), 0, s, a);
   hipLaunchKernelGGL(k_dw_reduce, dim3((unsigned)tln_cdiv(elems, 256)), dim3(256), 0, s, d_ws, splits, elems, d_dw);

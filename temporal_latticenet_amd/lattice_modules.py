@@ -169,12 +169,13 @@ class _TapConv(torch.nn.Module):
             bound = 1.0 / math.sqrt(self.nr_filters)
             self.bias = torch.nn.Parameter(torch.empty(self.nr_filters, device="cuda").uniform_(-bound, bound))
 
-    def _product(self, rows, lv, table_ptr, prologue, residual, table_tensor=None, symmetric=False):
+    def _product(self, rows, lv, table_ptr, prologue, residual, table_tensor=None, symmetric=False, src_lattice=None):
         if self.weight is None:
             self._make(lv.shape[1])
         if AG.grad_mode():                       # training path: autograd wrapper around the same kernel
             assert prologue is None
-            return AG.gather_gemm(rows, lv, table_tensor(), self.weight, self.bias, residual, symmetric=symmetric)
+            return AG.gather_gemm(rows, lv, table_tensor(), self.weight, self.bias, residual, symmetric=symmetric,
+                                  src_lattice=src_lattice)
         gn = None
         if prologue is not None and prologue[0] == "gn":      # GroupNorm+ReLU of `lv` inside the same host call
             gn, prologue = (lv, prologue[1].ensure(lv), True), None
@@ -205,7 +206,7 @@ class CoarsenLatticeModule(_TapConv):
     def forward(self, lv, ls, prologue=None):
         coarse = ls.coarsen()
         out = self._product(coarse.nr_lattice_vertices(), lv, coarse.coarse_to_fine_table_ptr(), prologue, None,
-                            coarse.coarse_to_fine_table)
+                            coarse.coarse_to_fine_table, src_lattice=ls)
         coarse.set_values(out)
         return out, coarse
 
@@ -217,7 +218,7 @@ class FinefyLatticeModule(_TapConv):
     def forward(self, lv_coarse, ls_coarse, ls_fine, prologue=None):
         nf = ls_fine.nr_lattice_vertices()
         out = self._product(nf, lv_coarse, ls_coarse.fine_to_coarse_table_ptr(), prologue, None,
-                            lambda: ls_coarse.fine_to_coarse_table(nf))
+                            lambda: ls_coarse.fine_to_coarse_table(nf), src_lattice=ls_coarse)
         ls_fine.set_values(out)
         return out, ls_fine
 

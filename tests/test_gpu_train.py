@@ -71,10 +71,12 @@ def test_parameter_gradients_match_oracle_autograd(gpu, rnn):
         # both share (GroupNorm, the GRU / AFlow arithmetic).  The kernels themselves are pinned against the torch
         # formulation at 2e-4 and against float64 products at 2e-5 in the two tests below.
         tol = 5e-3 if k.startswith("point_net_seq.layers.") else 2.5e-3
+        if og.numel() == 1:
+            tol = 1e-2          # AFlow's alpha / beta: ONE number summed over every vertex and tap with cancellation
         if err_l2 > 5e-4:
             print("[gradients] %-60s l2 %.3e max %.3e" % (k, err_l2, err_max))
         bad += [(k, err_l2, err_max)] if not (err_l2 < tol and err_max < 10 * tol) else []
-        worst = max(worst, err_l2 if tol == 1e-3 else 0.0)
+        worst = max(worst, err_l2)
         checked += 1
     assert not bad, bad
     assert checked > 40
@@ -130,8 +132,8 @@ def test_backward_kernels_are_deterministic_and_agree_with_the_torch_formulation
 
     a, b = grads(), grads()
     assert a.keys() == b.keys() and len(a) > 40
-    for k in a:
-        assert torch.equal(a[k], b[k]), "%s: two backward passes differ" % k
+    differ = [k for k in a if not torch.equal(a[k], b[k])]
+    assert not differ, "two backward passes differ in %d of %d parameters: %s" % (len(differ), len(a), differ)
     AG.torch_backward(True)
     try:
         ref = grads()
