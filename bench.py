@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--frames", type=int, default=4)
     ap.add_argument("--sigma", type=float, default=0.6)
     ap.add_argument("--rnn", type=str, default="gru,gru,aflow,gru")
+    ap.add_argument("--scale-constant", type=str, default=None,
+                    help="lattice scale constant (cfg lattice_gpu.scale_constant): adams (default) | unit | a number")
     ap.add_argument("--mode", choices=["sequences", "frames"], default="sequences")
     ap.add_argument("--streams", type=int, default=4,
                     help="independent sequences in flight per GPU (one HIP stream + host thread + model replica each); "
@@ -125,7 +127,8 @@ def main():
     from temporal_latticenet_amd.synthetic import make_sequence
 
     rnn = tuple(args.rnn.split(","))
-    contents = make_config(rnn_modules=rnn, frames=args.frames, sigma=args.sigma, capacity=1 << 18)
+    contents = make_config(rnn_modules=rnn, frames=args.frames, sigma=args.sigma, capacity=1 << 18,
+                           scale_constant=args.scale_constant)
     quiet = contextlib.redirect_stdout(io.StringIO())   # the model prints its layer list like the reference does
     with quiet:
         torch.manual_seed(1234)
@@ -524,7 +527,11 @@ def main():
                     "hint, cfg:71: ~10k vertices per 120k-point scan at sigma = 1; inputs resident in HBM)",
             "config": {"workload": "%d-frame sequence, %d pts/frame, sigma=%s, rnn_modules=[%s], 26 classes, "
                                    "full U-Net lattice encoder/decoder, inference" % (args.frames, args.points, args.sigma, args.rnn),
-                       "parallelism": par, "vertices_per_frame_V0_V1_V2": vcounts},
+                       "parallelism": par, "vertices_per_frame_V0_V1_V2": vcounts,
+                       "lattice_scale_constant": "%.6f (%s)" % (lattice.scale_constant(),
+                                                              "Adams 2010's (d+1)*sqrt(2/3), the default"
+                                                              if args.scale_constant in (None, "adams") else
+                                                              "lattice_gpu.scale_constant = %s" % args.scale_constant)},
             "value_h2d": None if value_h2d is None else round(value_h2d, 3),
             "roofline": roof, "roofline_scatter": scatter, "cpu_baseline": cpu, "checked": checked,
         }
@@ -603,7 +610,9 @@ def cpu_baseline(model, contents, args, checked=None, kept0=None):
     torch.set_num_threads(cores)
     oracle = OracleLNN(model.state_dict(), 26, m["rnn_modules"], m["sequence_learning"], m["pointnet_layers"],
                        m["nr_downsamples"], m["nr_blocks_down_stage"], m["nr_blocks_bottleneck"],
-                       m["nr_blocks_up_stage"], [args.sigma] * 3, 1 << 18, m["experiment"])
+                       m["nr_blocks_up_stage"], [args.sigma] * 3, 1 << 18, m["experiment"],
+                       scale_constant=(None if args.scale_constant in (None, "adams") else
+                                       (1.0 if args.scale_constant == "unit" else float(args.scale_constant))))
     oracle.exact_pool = False                # the timed baseline is plain PyTorch-CPU eager (F.linear)
     seq = make_sequence(args.cpu_points, args.frames, seed=1234)
     done, t0 = 0, time.perf_counter()
