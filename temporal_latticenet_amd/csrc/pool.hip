@@ -334,6 +334,327 @@ __global__ void __launch_bounds__(256) k_pool_bins(const PoolJobs jobs, int min_
   flush(cur, js, cnt - 1, best, bj, brow);
 }
 
+// ---------------------------------------------------------------------------------------
+// The 4-16-32-64 pool with its two wide layers on the matrix cores AND the per-vertex max taken where the accumulator
+// leaves the values (round 3).  v_mfma_f32_32x32x2_f32 accumulates like a chain of fp32 fmas in ascending k
+// (tools/micro/mfma_chain.hip), so C = bias followed by K/2 MFMAs reproduces the pinned summation order
+// bit for bit.  legacy.hip's first matrix-core version wrote every 32 x 64 result tile to LDS and walked it row by row
+// with lane = channel — ~2000 vector instructions per 64 rows, as many cycles as the MFMAs — and was no faster than the
+// all-VALU kernel.  Here:
+//   layer 1 (4 -> 16)   lane = row, VALU (64 fmas)
+//   layer 2 (16 -> 32)  D[o][row], A = W2, B = h1 of a 32-row tile (one v_permlane32_swap per k pair serves both tiles)
+//   layer 3 (32 -> 64)  D[row][o], A = h2 from layer 2's accumulator, B = W3: a lane ends up with 16 rows
+//                       {8g + 4h + m} of ONE channel (h = lane / 32)
+//   relayout            8 v_permlane32_swap per tile and column half: the lower lanes now hold rows 0-15 of the tile, the
+//                       upper lanes rows 16-31, in order: a 64-row chunk is four BLOCKS of 16 consecutive rows
+//   max / arg-max       every lane walks its block's 16 values in registers (a run of equal vertices starts where the
+//                       wave-uniform start mask says; ties go to the smallest row id): runs inside a block are flushed on
+//                       the spot, a run that crosses a block boundary hands (value, row) to the other half of the wave
+//                       (three hand-offs per chunk) — ~13 vector instructions per row for TWO channels.
+// Flush = what k_pool_bins does: a vertex whose rows all lie inside the chunk is written straight to the output, the
+// others (and vertex 0) go through the packed 64-bit atomicMax and k_pool_bins_finalize.
+// ---------------------------------------------------------------------------------------
+typedef float f16p __attribute__((ext_vector_type(16)));
+typedef unsigned u2p __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void pswap32(float x, float y, float& lo, float& hi) {
+  // lo = {x[0:31], y[0:31]},  hi = {x[32:63], y[32:63]}
+  const u2p r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+  lo = __uint_as_float(r.x);
+  hi = __uint_as_float(r.y);
+}
+
+template <int CIN>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) k_pool_bins_mx(
+    const PoolJobs jobs, int min_points, const float* __restrict__ w1, const float* __restrict__ b1,
+    const float* __restrict__ w2, const float* __restrict__ b2, const float* __restrict__ w3, const float* __restrict__ b3) {
+  const PoolJob& J = jobs.j[blockIdx.y];
+  const TlnBins& bn = J.bn;
+  const int64_t rows = J.rows;
+  unsigned long long* __restrict__ packed = J.packed;
+  float* __restrict__ out = J.out;
+  int32_t* __restrict__ argrow = J.argrow;
+  constexpr int H1 = 16, H2 = 32, COUT = 64;
+  __shared__ int tv_s[4][64], trow_s[4][64];     // vertex (-2: no row) and row id of the chunk's rows, per wave
+  __shared__ float tw_s[4][64];                  // their barycentric weights (the arg-max row's is part of the output)
+  const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int half = lane >> 5, l32 = lane & 31;
+  int* tv = tv_s[wid];
+  int* trow = trow_s[wid];
+  float* tw = tw_s[wid];
+
+  // operands that stay in registers for every chunk of this wave
+  float a2[H1 / 2];
+#pragma unroll
+  for (int j = 0; j < H1 / 2; ++j) a2[j] = w2[l32 * H1 + 2 * j + half];
+  float bw3[2][H2 / 2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int j = 0; j < H2 / 2; ++j) bw3[nt][j] = w3[(l32 + 32 * nt) * H2 + 2 * j + half];
+  float bias2[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) bias2[i] = b2[8 * (i / 4) + 4 * half + (i % 4)];
+  const float bias3[2] = {b3[l32], b3[l32 + 32]};
+  const int nv = bn.ctr[0];
+  const float w0 = bn.weights[0];   // lm:514: an arg-max row id > V reads the barycentric weight of row 0
+  const int64_t chunks = (rows + 63) >> 6;
+
+  struct RowIn {
+    float4 q;
+    int v, row;
+    float w;
+  };
+  struct VtxIn {
+    float mx, my, mz;
+    int st, c;
+  };
+  auto load_rows = [&](int64_t ch, RowIn& r) {
+    const int64_t at = ch * 64 + lane;
+    r.v = -2;                       // no row here (past the frame's rows)
+    r.row = 0;
+    r.w = 0.0f;
+    r.q = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ch < chunks && at < rows) {
+      r.q = bn.rec[at].a;
+      const uint4 meta = bn.rec[at].m;
+      r.v = (int)meta.z;            // -1: a row without a vertex
+      r.row = (int)meta.y;
+      r.w = __uint_as_float(meta.x);
+    }
+  };
+  auto load_vtx = [&](const RowIn& r, VtxIn& g) {
+    g.mx = g.my = g.mz = 0.0f;
+    g.st = -1;
+    g.c = 0;
+    if (r.v >= 0) {
+      if (bn.subtract) {
+        g.mx = bn.mean[3 * r.v];
+        g.my = bn.mean[3 * r.v + 1];
+        g.mz = bn.mean[3 * r.v + 2];
+      }
+      g.st = bn.vstart[r.v];
+      g.c = bn.vcnt[r.v];
+    }
+  };
+
+  const float NEG = -__builtin_inff();
+  const int64_t stride = (int64_t)gridDim.x * 4;
+  int64_t chunk = (int64_t)blockIdx.x * 4 + wid;
+  RowIn rin, rnext;
+  VtxIn vin, vnext;
+  load_rows(chunk, rin);
+  load_vtx(rin, vin);
+  for (; chunk < chunks; chunk += stride) {
+    const int64_t j0 = chunk * 64;
+    const int cnt = (int)((rows - j0) < 64 ? (rows - j0) : 64);
+    load_rows(chunk + stride, rnext);
+    // ---- lane = row: mean subtraction, layer 1
+    float h1[H1];
+#pragma unroll
+    for (int k = 0; k < H1; ++k) h1[k] = 0.0f;
+    int my_v = -2;                  // rows without a vertex fold into vertex 0 with their raw position (lm:480)
+    bool r_whole = false, r_masked = false;
+    if (rin.v != -2) {
+      my_v = 0;
+      float4 q = rin.q;
+      if (rin.v >= 0) {
+        my_v = rin.v;
+        q.x -= vin.mx;
+        q.y -= vin.my;
+        q.z -= vin.mz;
+        r_whole = rin.v != 0 && (int64_t)vin.st >= j0 && (int64_t)vin.st + vin.c <= j0 + cnt;
+        r_masked = vin.c < min_points;
+      }
+      const float xin[4] = {q.x, q.y, q.z, q.w};
+      float x[CIN];
+#pragma unroll
+      for (int k = 0; k < CIN; ++k) x[k] = xin[k];
+      dense<CIN, H1, true>(w1, b1, x, h1);
+    }
+    tv[lane] = my_v;
+    trow[lane] = rin.row;
+    tw[lane] = rin.w;
+    // wave-uniform masks over the 64 rows: first row of every run of equal vertices (rows past the end: one dead run)
+    const int v_prev = __shfl_up(my_v, 1, 64);
+    const unsigned long long startmask = __ballot(lane == 0 || my_v != v_prev);
+    const unsigned long long wholemask = __ballot(r_whole);
+    const unsigned long long maskedmask = __ballot(r_masked);
+    // ---- layer 2 on both 32-row tiles
+    f16p acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      acc0[i] = bias2[i];
+      acc1[i] = bias2[i];
+    }
+#pragma unroll
+    for (int j = 0; j < H1 / 2; ++j) {
+      float t0, t1;
+      pswap32(h1[2 * j], h1[2 * j + 1], t0, t1);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[j], t0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[j], t1, acc1, 0, 0, 0);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): tv / trow of this chunk are in LDS
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // a finished run (its last row at chunk position `pos`): straight to the output if the vertex lies inside the chunk
+    auto flush_run = [&](int pos, const float (&val)[2], const int (&row)[2], const int (&at)[2]) {
+      const int v = tv[pos];
+      if (v == -2) return;          // the dead run behind the frame's last row
+      const bool whole = (wholemask >> pos) & 1ull;
+      const bool masked = (maskedmask >> pos) & 1ull;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const int c = l32 + 32 * nt;
+        if (whole) {
+          const float bary = row[nt] > nv ? w0 : tw[at[nt]];   // lm:514 (the arg-max row's weight: from LDS, by position)
+          out[(int64_t)v * (2 * COUT) + c] = masked ? 0.0f : val[nt];
+          out[(int64_t)v * (2 * COUT) + COUT + c] = masked ? 0.0f : bary;
+          if (argrow) argrow[(int64_t)v * COUT + c] = masked ? -1 : row[nt];
+        } else {
+          const unsigned long long p = ((unsigned long long)tln_f2ord(val[nt]) << 32) |
+                                       (unsigned long long)(0xFFFFFFFFu - (uint32_t)row[nt]);
+          atomicMax(&packed[(int64_t)v * COUT + c], p);
+        }
+      }
+    };
+    auto better = [](float v, int r, float bv, int br) { return v > bv || (v == bv && r < br); };
+
+    // the run open at the end of the previous block, in the lanes of THIS half once handed over
+    float cval[2] = {NEG, NEG};
+    int crow[2] = {0x7fffffff, 0x7fffffff}, cat[2] = {0, 0};
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      // ---- layer 3 for the tile: 2 x 16 MFMAs, then the rows of a channel in order (lower lanes 0-15, upper 16-31)
+      f16p h2 = t ? acc1 : acc0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) h2[i] = fmaxf(h2[i], 0.0f);
+      float aop[H2 / 2];
+#pragma unroll
+      for (int jj = 0; jj < H2 / 2; ++jj) {
+        if ((jj & 3) < 2) {   // the k pairs whose channels sit in the lower half's registers
+          const int i0 = 4 * (jj / 4) + 2 * (jj % 2);
+          pswap32(h2[i0], h2[i0 + 1], aop[jj], aop[jj + 2]);
+        }
+      }
+      float n[2][16];
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        f16p d;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) d[i] = bias3[nt];
+#pragma unroll
+        for (int j = 0; j < H2 / 2; ++j) d = __builtin_amdgcn_mfma_f32_32x32x2f32(aop[j], bw3[nt][j], d, 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          pswap32(d[m], d[8 + m], n[nt][m], n[nt][4 + m]);
+          pswap32(d[4 + m], d[12 + m], n[nt][8 + m], n[nt][12 + m]);
+        }
+      }
+      // ---- the block's walk
+      const int base = 32 * t + 16 * half;
+      const unsigned tile_bits = (unsigned)(startmask >> (32 * t));
+      const unsigned sb = half ? (tile_bits >> 16) : (tile_bits & 0xFFFFu);    // start bits of this lane's 16 rows
+      bool seen = false;
+      float best[2] = {NEG, NEG}, headv[2] = {NEG, NEG};
+      int brow[2] = {0x7fffffff, 0x7fffffff}, headr[2] = {0x7fffffff, 0x7fffffff};
+      int bat[2] = {0, 0}, heada[2] = {0, 0};
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const bool st = (sb >> j) & 1u;
+        const int rj = trow[base + j];
+        if (st) {
+          if (seen) {
+            flush_run(base + j - 1, best, brow, bat);      // a run that began and ended inside this block
+          } else {
+            headv[0] = best[0];
+            headv[1] = best[1];
+            headr[0] = brow[0];
+            headr[1] = brow[1];
+            heada[0] = bat[0];
+            heada[1] = bat[1];
+            seen = true;
+          }
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const float v = n[nt][j];
+          const bool take = st || better(v, rj, best[nt], brow[nt]);
+          best[nt] = take ? v : best[nt];
+          brow[nt] = take ? rj : brow[nt];
+          bat[nt] = take ? base + j : bat[nt];
+        }
+      }
+      // ---- stitch the blocks: lower half (block 2t) first, its open run goes to the upper half (block 2t + 1), and
+      // that one's to the lower half of the next tile.  All conditions but `seen` are wave-uniform.
+#pragma unroll
+      for (int hb = 0; hb < 2; ++hb) {
+        const int b = 2 * t + hb;                                   // block being finished
+        const bool cont_in = b > 0 && !((startmask >> (16 * b)) & 1ull);         // a run continues into it
+        const bool ends = b == 3 || ((startmask >> (16 * (b + 1))) & 1ull);      // its last run ends with it
+        if (b > 0) {   // the carry of block b - 1 sits in the other half's lanes
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) {
+            const float xv = __shfl_xor(cval[nt], 32, 64);
+            const int xr = __shfl_xor(crow[nt], 32, 64);
+            const int xa = __shfl_xor(cat[nt], 32, 64);
+            if (half == hb) {
+              cval[nt] = xv;
+              crow[nt] = xr;
+              cat[nt] = xa;
+            }
+          }
+        }
+        if (half == hb) {
+          float outv[2];
+          int outr[2], outa[2];
+          if (seen) {
+            if (cont_in) {   // the older run ends inside this block: carry + head
+              float hv[2];
+              int hr[2], ha[2];
+#pragma unroll
+              for (int nt = 0; nt < 2; ++nt) {
+                const bool tk = better(headv[nt], headr[nt], cval[nt], crow[nt]);
+                hv[nt] = tk ? headv[nt] : cval[nt];
+                hr[nt] = tk ? headr[nt] : crow[nt];
+                ha[nt] = tk ? heada[nt] : cat[nt];
+              }
+              flush_run(base + (__ffs((int)sb) - 1) - 1, hv, hr, ha);
+            }
+            outv[0] = best[0];
+            outv[1] = best[1];
+            outr[0] = brow[0];
+            outr[1] = brow[1];
+            outa[0] = bat[0];
+            outa[1] = bat[1];
+          } else {           // no run starts in this block: it is all continuation
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+              const bool tk = !cont_in || better(best[nt], brow[nt], cval[nt], crow[nt]);
+              outv[nt] = tk ? best[nt] : cval[nt];
+              outr[nt] = tk ? brow[nt] : crow[nt];
+              outa[nt] = tk ? bat[nt] : cat[nt];
+            }
+          }
+          if (ends) flush_run(base + 15, outv, outr, outa);
+          cval[0] = outv[0];
+          cval[1] = outv[1];
+          crow[0] = outr[0];
+          crow[1] = outr[1];
+          cat[0] = outa[0];
+          cat[1] = outa[1];
+        }
+      }
+    }
+    load_vtx(rnext, vnext);   // the next chunk's rows have arrived by now: what their vertices point to
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // tv / trow are rewritten by the next chunk
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    rin = rnext;
+    vin = vnext;
+  }
+}
+
 // what k_pool_bins left open: vertices without rows (zeros, torch_scatter's empty segment), vertices whose segment
 // crosses a 64-row chunk boundary and vertex 0 (packed accumulators -> value, barycentric weight, mask)
 __global__ void __launch_bounds__(256) k_pool_bins_finalize(const PoolJobs jobs, int cout, int min_points) {
@@ -423,18 +744,20 @@ static int launch_pool(tln_lattice* l, const float* d_dist, int64_t rows, int co
   return TLN_OK;
 }
 
+#define TLN_POOL_DEFAULT_MODE 0
 // which kernel pools the 4-16-32-64 MLP from the bins: the all-VALU k_pool_bins (default) or k_pool_bins_mfma
 // (TLN_POOL_MFMA=1 / tln_pool_config(1)).  Bitwise equal results; the MFMA variant measured no faster.
 static int g_pool_mfma = -1;
-static bool pool_mfma() {
+static int pool_mode() {   // 0: all-VALU k_pool_bins, 1: legacy.hip's matrix-core variant, 2: k_pool_bins_mx
   if (g_pool_mfma < 0) {
     const char* e = getenv("TLN_POOL_MFMA");
-    g_pool_mfma = (e && e[0] == '1') ? 1 : 0;
+    g_pool_mfma = e ? atoi(e) : TLN_POOL_DEFAULT_MODE;
+    if (g_pool_mfma < 0 || g_pool_mfma > 2) g_pool_mfma = TLN_POOL_DEFAULT_MODE;
   }
-  return g_pool_mfma == 1;
+  return g_pool_mfma;
 }
-extern "C" int tln_pool_config(int mfma) {
-  g_pool_mfma = mfma ? 1 : 0;
+extern "C" int tln_pool_config(int mode) {
+  g_pool_mfma = (mode < 0 || mode > 2) ? TLN_POOL_DEFAULT_MODE : mode;
   return TLN_OK;
 }
 
@@ -446,9 +769,25 @@ static int pool_bins_jobs(PoolJobs& jobs, int n, int nr_layers, const float* con
   for (int i = n; i < TLN_POOL_MAXJOBS; ++i) jobs.j[i] = jobs.j[0];   // (never indexed: the grids have n rows)
 #define POOLB_CASE(CI, A, B, CO) rc = launch_pool_bins<CI, A, B, CO>(jobs, n, d_w, d_b, min_points, s)
   *taken = true;
-  const bool wide = n == 1 && nr_layers == 3 && dims[1] == 16 && dims[2] == 32 && dims[3] == 64 && pool_mfma();
+  const bool shape_wide = nr_layers == 3 && dims[1] == 16 && dims[2] == 32 && dims[3] == 64 && (cin == 4 || cin == 3);
+  const bool wide = n == 1 && shape_wide && pool_mode() == 1;
   const PoolJob& j0 = jobs.j[0];
-  if (wide && (cin == 4 || cin == 3))
+  if (shape_wide && pool_mode() == 2) {
+    // matrix cores + the max in accumulator layout: a wave strides over chunks (weights stay in its registers)
+    int64_t rmax = 0;
+    for (int i = 0; i < n; ++i)
+      if (jobs.j[i].rows > rmax) rmax = jobs.j[i].rows;
+    int64_t blocks = tln_cdiv(tln_cdiv(rmax, 64), 4);
+    const int64_t cap = tln_cdiv(512, n) < 64 ? 64 : tln_cdiv(512, n);   // two workgroups per CU over all jobs
+    if (blocks > cap) blocks = cap;
+    if (cin == 4)
+      hipLaunchKernelGGL(k_pool_bins_mx<4>, dim3((unsigned)blocks, (unsigned)n), dim3(256), 0, s, jobs, min_points, d_w[0], d_b[0],
+                         d_w[1], d_b[1], d_w[2], d_b[2]);
+    else
+      hipLaunchKernelGGL(k_pool_bins_mx<3>, dim3((unsigned)blocks, (unsigned)n), dim3(256), 0, s, jobs, min_points, d_w[0], d_b[0],
+                         d_w[1], d_b[1], d_w[2], d_b[2]);
+    TLN_LAUNCH_CHECK();
+  } else if (wide && (cin == 4 || cin == 3))
     rc = tln_pool_bins_mfma_launch(cin, j0.bn, j0.rows, d_w, d_b, min_points, j0.packed, j0.out, j0.argrow, s);
   else if (nr_layers == 3 && cin == 4 && dims[1] == 16 && dims[2] == 32 && dims[3] == 64) POOLB_CASE(4, 16, 32, 64);
   else if (nr_layers == 2 && cin == 4 && dims[1] == 16 && dims[2] == 32) POOLB_CASE(4, 16, 0, 32);

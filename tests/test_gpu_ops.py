@@ -374,7 +374,7 @@ def test_pool_on_the_matrix_cores_is_bitwise_the_fma_chain(gpu, cin):
     Ws = [torch.randn(16, cin, generator=g) * 0.5, torch.randn(32, 16, generator=g) * 0.3, torch.randn(64, 32, generator=g) * 0.3]
     Bs = [torch.randn(16, generator=g) * 0.1, torch.randn(32, generator=g) * 0.1, torch.randn(64, generator=g) * 0.1]
     got = {}
-    for mfma in (1, 0):
+    for mfma in (2, 1, 0):      # 2: k_pool_bins_mx (max in accumulator layout), 1: legacy.hip's LDS-tile variant, 0: all-VALU
         lib.tln_pool_config(mfma)
         try:
             lat = Lattice.from_params([0.7] * 3, 9000)
@@ -387,10 +387,10 @@ def test_pool_on_the_matrix_cores_is_bitwise_the_fma_chain(gpu, cin):
                     od, oi, ow = O.distribute(tab, pos, val, [0.7] * 3)
                     if cin == 4:     # (the oracle's MLP takes every column but the weight; 3 inputs: the two kernels only)
                         want = O.pointnet_pool(od, oi, tab.nr_vertices, Ws, Bs, 4)
-                        assert np.array_equal(outs[-1], want.numpy()), "frame %d" % t
+                        assert np.array_equal(outs[-1], want.numpy()), "frame %d, pool mode %d" % (t, mfma)
             got[mfma] = outs
         finally:
             lib.tln_pool_config(0)
     assert (oi < 0).sum() > 0, "the fixture is meant to overflow on the second frame"
-    for a, b in zip(got[0], got[1]):
-        assert np.array_equal(a, b)
+    for a, b, c in zip(got[0], got[1], got[2]):
+        assert np.array_equal(a, b) and np.array_equal(a, c)
