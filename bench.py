@@ -311,7 +311,7 @@ def main():
         default_workload = (args.points, args.frames, args.sigma, args.rnn) == (120000, 4, 0.6, "gru,gru,aflow,gru")
         if rank == 0:
             reps = 5
-            tot_ms, tot_n, tot_fl, tot_by = 0.0, 0, 0.0, 0.0
+            tot_ms, tot_n, tot_fl, tot_by, tot_ex = 0.0, 0, 0.0, 0.0, 0.0
             st_ms, st_by, st_n = [0.0, 0.0, 0.0], [0.0, 0.0, 0.0], [0, 0, 0]
             lat = make_lattice(contents)
             n_pts = args.points
@@ -340,6 +340,7 @@ def main():
                     if rep == 0:
                         ms, n, fl, by = prog.replay_gemms(reps)
                         tot_ms, tot_n, tot_fl, tot_by = tot_ms + ms, tot_n + n, tot_fl + fl, tot_by + by
+                        tot_ex += type(prog).replay_executed([prog])
                 model.reset_sequence()
                 for k in range(3):
                     if p_n[k] and (st_n[k] == 0 or p_ms[k] < st_ms[k]):
@@ -356,7 +357,7 @@ def main():
                 from temporal_latticenet_amd.models import forward_group
                 gmodels, gseqs = pool.models[:per], per_stream[:per]
                 glats = [make_lattice(contents) for _ in range(per)]
-                g_ms, g_n, g_fl = 0.0, 0, 0.0
+                g_ms, g_n, g_fl, g_ex = 0.0, 0, 0.0, 0.0
                 gs_ms, gs_by, gs_n = [0.0, 0.0, 0.0], [0.0, 0.0, 0.0], [0, 0, 0]
                 with torch.no_grad():
                     # round 0: warm (tables, workspaces of these lattices); round 1: the products captured and replayed;
@@ -377,6 +378,7 @@ def main():
                             if rep == 1:
                                 ms, n, fl, by = FrameProgram.replay_gemms_group([m._program for m in gmodels], reps)
                                 g_ms, g_n, g_fl = g_ms + ms, g_n + n, g_fl + fl
+                                g_ex += FrameProgram.replay_executed([m._program for m in gmodels])
                             if rep >= 2:
                                 v0s = [l.nr_lattice_vertices() for l in cur]
                                 by3 = (sum(128.0 * n_pts for _ in cur), sum(96.0 * n_pts + 512.0 * v for v in v0s),
@@ -395,12 +397,16 @@ def main():
                     m.reset_sequence()
                 if g_n:
                     grp = {"achieved": round(g_fl / (g_ms * 1e-3) / 1e12, 3), "avg_product_us": round(g_ms * 1e3 / g_n, 2),
-                           "products": g_n // reps, "sequences": per}
+                           "products": g_n // reps, "sequences": per,
+                           "executed": round(g_ex * reps / (g_ms * 1e-3) / 1e12, 3), "executed_share": round(g_ex * reps / g_fl, 4)}
             if tot_n:
                 achieved = tot_fl / (tot_ms * 1e-3) / 1e12
                 seqs_per_step = (S * per) if not frames_mode else plan.nr_groups / max(1, args.gpus)
                 step_tf = (tot_fl / reps) * seqs_per_step / (elapsed / args.steps) / 1e12
+                ex_solo = tot_ex * reps / (tot_ms * 1e-3) / 1e12
                 solo = {"achieved": round(achieved, 3), "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+                        "executed": {"achieved": round(ex_solo, 3), "frac": round(ex_solo / FP32_MFMA_PEAK_TFLOPS, 4),
+                                     "share_of_algorithmic": round(tot_ex * reps / tot_fl, 4)},
                         "launches_per_sequence": tot_n // reps, "avg_launch_us": round(tot_ms * 1e3 / tot_n, 2),
                         "mode": "every gather-GEMM product of ONE %d-frame sequence replayed back to back on one stream "
                                 "running alone (the GRU cell's two projections as two plain products: the timed mode "
@@ -408,8 +414,10 @@ def main():
                 # the headline figure is measured on the launches of the timed mode: with lock-step groups (--pairs P) a
                 # stream issues product i of its P sequences through one call (shared gemm_v2 launches on the coarse
                 # levels); without, a stream's launches are those of one sequence
+                head_ex, head_share = ex_solo, tot_ex * reps / tot_fl
                 if grp is not None:
                     head, head_us = grp["achieved"], grp["avg_product_us"]
+                    head_ex, head_share = grp["executed"], grp["executed_share"]
                     mode = ("every gather-GEMM product of one stream's lock-step group (%d sequences) replayed back to "
                             "back as the group issues them (product i of all sequences through one call; the GRU "
                             "cell's two projections as two plain products: the timed mode runs them as one fused "
@@ -425,6 +433,12 @@ def main():
                         "flops_note": "2*M*K*N with the full K = taps*C_in of the reference's im2row product, the zero "
                                       "rows of missing lattice neighbours included; the large-M kernel skips the K "
                                       "chunks of taps no row of a 128-row block has (13-41 % of them, DESIGN.md 5d)",
+                        "executed": {"achieved": round(head_ex, 3), "frac": round(head_ex / FP32_MFMA_PEAK_TFLOPS, 4),
+                                     "share_of_algorithmic": round(head_share, 4),
+                                     "note": "what the matrix cores execute during the same replay: 32x32x32 steps counted "
+                                             "by the kernels themselves in one extra pass (K chunks of absent taps skipped, "
+                                             "tile padding included) x 65536 flops / the replay's time; `achieved` / `frac` "
+                                             "above stay the algorithmic 2*M*K*N of the specification"},
                         "mode": mode, "one_sequence_alone": solo,
                         "whole_step": {"achieved": round(step_tf, 3), "frac": round(step_tf / FP32_MFMA_PEAK_TFLOPS, 4),
                                        "note": "the same flops per sequence x sequences per step / measured step time of "

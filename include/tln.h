@@ -533,6 +533,12 @@ int tln_program_replay_gemms(tln_program_t* p, int reps, double* ms_total, int64
  * tln_gather_gemm_multi call, as the group issued it; launches = products */
 int tln_program_replay_gemms_group(tln_program_t* const* pp, int n, int reps, double* ms_total, int64_t* launches,
                                    double* flops, double* bytes, void* stream);
+/* What the matrix cores EXECUTE for those products (one extra pass of the launches, n = 1..8 programs as above): every
+ * gather-GEMM kernel counts its 32 x 32 x 32 multiply steps into a device counter -- gemm_v2 after skipping the K chunks
+ * of taps no row of a block has, every kernel including the rows / columns its tiles pad.  flops_executed = steps x 65536;
+ * beside the algorithmic 2*M*K*N of tln_program_replay_gemms it says how much of the im2row product's zero work is
+ * left. */
+int tln_program_replay_executed(tln_program_t* const* pp, int n, double* flops_executed, void* stream);
 /* The frame in segments, for the frame-sharded multi-GPU path (temporal_latticenet_amd/dist.py): the rank that owns
  * frame t receives every fusion module's hidden state from the rank of frame t-1 right before the first op that reads
  * it and sends the new one on right after the last op that writes it.  Per frame: tln_program_begin_frame, every state

@@ -166,6 +166,7 @@ _PROTOS = {
                                       C.POINTER(C.c_double), _vp]),
     "tln_program_replay_gemms_group": (_i, [C.POINTER(_vp), _i, _i, C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(C.c_double),
                                       C.POINTER(C.c_double), _vp]),
+    "tln_program_replay_executed": (_i, [C.POINTER(_vp), _i, C.POINTER(C.c_double), _vp]),
     "tln_program_frame_rows": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i64),
                                     C.POINTER(_i)]),
     "tln_program_state_info": (_i, [_vp, _i, C.POINTER(_i64), C.POINTER(_i), C.POINTER(_i)]),

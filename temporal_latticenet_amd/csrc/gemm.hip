@@ -82,6 +82,8 @@ __global__ void __launch_bounds__(128 * WM * G) k_gather_gemm(const GemmArgs g) 
 
   const bool stamp = g.dbg && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0;
   if (stamp) g.dbg[0] = __builtin_amdgcn_s_memtime();
+  // measurement (tln_program_replay_executed): what the matrix cores execute, in units of one 32 x 32 x 32 step
+  if (g.dbg && threadIdx.x == 0) atomicAdd(&g.dbg[8], (unsigned long long)(iters * G) * (WM * TM * TN) * BK / 32);
   // both tables go through LDS: a tap index fetched from global memory inside the K loop makes the compiler merge the
   // LDS and the global alternative into one FLAT load with s_waitcnt vmcnt(0), draining the operand loads in flight
   for (int si = 0; si < g.nsrc; ++si) {
@@ -560,6 +562,7 @@ __device__ __forceinline__ void direct_body(const GemmArgs& g) {
   const int iters = (nchunks + G - 1) / G;  // every wave runs the same count; a chunk index past the list is
                                             // clamped and its A operand zeroed (adds exact zeros)
   const unsigned nc = (unsigned)(ncol ? n : g.N - 1);  // columns past N are computed on column N-1, never stored
+  if (g.dbg && threadIdx.x == 0) atomicAdd(&g.dbg[8], (unsigned long long)(iters * G));   // executed 32 x 32 x 32 steps
 
   // k order inside a chunk: lane half h holds k = 8j + 4h + e (j = 0..3, e = 0..3), identically for A and B.  The two
   // lanes of a row then read ADJACENT 16-byte pieces in every load instruction (32 contiguous bytes per row: 32

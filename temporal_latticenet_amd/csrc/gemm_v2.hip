@@ -126,6 +126,8 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
   const int cpt = s.cin >> 5;                 // chunks per tap
   const int nchunks = Taps[0] * cpt;
   const float* zero = g_v2_zero;
+  // measurement (tln_program_replay_executed): the 32 x 32 x 32 steps this block's matrix cores execute
+  if (!GRU && g.dbg && tid == 0) atomicAdd(&g.dbg[8], (unsigned long long)nchunks * (TM * WM) * (TN * WN));
 
   // issue the LDS-DMAs of chunk t into stage st: every thread PIECES x 16 bytes, lane-linear pieces of 1 KiB per wave
   auto issue = [&](int t_raw, int st) {

@@ -1564,6 +1564,42 @@ extern "C" int tln_program_replay_gemms_group(tln_program_t* const* pp, int n, i
   return TLN_OK;
 }
 
+// What the matrix cores execute for the captured products of one frame of n lock-stepped programs (n = 1: one sequence
+// alone): every gather-GEMM kernel counts its 32 x 32 x 32 steps (gemm_v2 after skipping the K chunks of absent taps, all
+// kernels including the rows and columns a tile pads) into a device counter during ONE extra pass of the launches.
+extern "C" void tln_gemm_debug_stamps(void* d_buf);
+extern "C" int tln_program_replay_executed(tln_program_t* const* pp, int n, double* flops_executed, void* stream_) {
+  TLN_REQUIRE(pp && n >= 1 && n <= 8 && flops_executed, "bad replay arguments");
+  hipStream_t s = (hipStream_t)stream_;
+  *flops_executed = 0.0;
+  const size_t nc = pp[0]->calls.size();
+  for (int k = 0; k < n; ++k) TLN_REQUIRE(pp[k] && pp[k]->calls.size() == nc, "the programs captured different products");
+  if (nc == 0) return TLN_OK;
+  unsigned long long* d_cnt = nullptr;
+  TLN_HIP(hipMalloc(&d_cnt, 16 * sizeof(unsigned long long)));
+  int rc = TLN_OK;
+  if (hipMemsetAsync(d_cnt, 0, 16 * sizeof(unsigned long long), s) != hipSuccess) rc = TLN_E_HIP;
+  tln_gemm_debug_stamps(d_cnt);
+  for (size_t i = 0; i < nc && !rc; ++i) {
+    tln_gemm_call calls[8];
+    for (int k = 0; k < n; ++k) {
+      const GemmCall& c = pp[k]->calls[i];
+      calls[k] = tln_gemm_call{c.M, c.N, &c.a[0], c.two ? &c.a[1] : nullptr, c.w, c.w_is_nk, c.bias, c.res, c.ld_res,
+                               c.relu, c.out, c.ld_out, c.stats};
+    }
+    rc = tln_gather_gemm_multi(calls, n, s);
+  }
+  tln_gemm_debug_stamps(nullptr);
+  unsigned long long h[16] = {0};
+  if (!rc && (hipStreamSynchronize(s) != hipSuccess ||
+              hipMemcpy(h, d_cnt, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess))
+    rc = TLN_E_HIP;
+  (void)hipFree(d_cnt);
+  if (rc) return rc;
+  *flops_executed = (double)h[8] * 65536.0;   // 2 x 32 x 32 x 32
+  return TLN_OK;
+}
+
 extern "C" int tln_program_frame_rows(tln_program_t* p, const float** d_distributed, const int32_t** d_indices,
                                       const float** d_weights, int64_t* rows, int* cols) {
   TLN_REQUIRE(p && p->d_idx, "no frame yet");

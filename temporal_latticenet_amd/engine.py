@@ -536,6 +536,16 @@ class FrameProgram:
                                                              C.byref(by), stream_ptr()), "tln_program_replay_gemms_group")
         return ms.value, n.value, fl.value, by.value
 
+    @staticmethod
+    def replay_executed(programs):
+        """flops the matrix cores execute for the last frame's products of these 1..8 lock-stepped programs (one extra
+        pass of the launches with the kernels' step counters on: tln_program_replay_executed)"""
+        hs = (C.c_void_p * len(programs))(*[p._h for p in programs])
+        fl = C.c_double()
+        _lib.check(_lib.lib().tln_program_replay_executed(hs, len(programs), C.byref(fl), stream_ptr()),
+                   "tln_program_replay_executed")
+        return fl.value
+
     # ---- the frame in segments (frame-sharded multi-GPU, dist.FrameShardRunner) -----------------------------------
     def state_ops(self, sid):
         """(first op that reads stored state `sid`, last op that writes the new one, lattice level of the state)"""

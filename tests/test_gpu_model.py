@@ -197,3 +197,39 @@ def test_experiments_match_oracle(gpu, experiment, rnn):
         scale = max(1.0, float(want.abs().max()))
         err = float((got - want).abs().max())
         assert err <= LOGIT_TOL * scale, "%s frame %d: max abs err %.3e (scale %.2f)" % (experiment, t, err, scale)
+
+
+def test_executed_flops_of_a_frame_are_counted_by_the_kernels(gpu):
+    """bench.py's roofline.executed: the kernels' own step counters over one extra pass of a frame's products.  With the
+    large-M kernel's tap skipping the executed work is below the algorithmic 2*M*K*N (the im2row product's zero rows),
+    without it (every product through the small-M kernels) it is at least the algorithmic figure (tile padding), and the
+    counting pass leaves the results alone."""
+    from temporal_latticenet_amd import _lib
+    from temporal_latticenet_amd.engine import FrameProgram
+    contents = make_config(frames=2, sigma=0.6)
+    seq = make_sequence(60000, 2, seed=5)
+    model = build_model(contents).eval()
+    _run(model, contents, seq, gpu)                 # creates the lazily built parameters
+    _run(model, contents, seq, gpu)                 # compiles the frame program
+    prog = model._program
+    assert prog is not None
+    shares = {}
+    for name, force in (("default", 0), ("small-M kernels only", 1)):
+        _lib.lib().tln_gemm_force_direct(force)
+        try:
+            prog.capture_gemms(True)
+            lat = make_lattice(contents)
+            with torch.no_grad():
+                a, first, lat = model(lat, torch.from_numpy(seq[0][0]).to(gpu), torch.from_numpy(seq[0][1]).to(gpu), False, False)
+                ms, n, fl, by = prog.replay_gemms(1)
+                ex = FrameProgram.replay_executed([prog])
+                again = model._program.replay_gemms(1)
+            prog.capture_gemms(False)
+            model.reset_sequence()
+        finally:
+            _lib.lib().tln_gemm_force_direct(0)
+        assert n > 20 and fl > 0 and again[2] == fl
+        shares[name] = ex / fl
+    print("executed / algorithmic flops:", shares)
+    assert 0.5 < shares["default"] < 0.98
+    assert 1.0 <= shares["small-M kernels only"] < 1.1
