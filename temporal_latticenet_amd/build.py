@@ -53,7 +53,7 @@ def build(force=False, verbose=True):
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ, src.replace(".hip", ".o"))
         if force or _stale(o, [s] + headers):
-            jobs.append((src, [hipcc] + COMMON + extra + ["-c", s, "-o", o]))
+            jobs.append((src, [hipcc] + COMMON + extra + os.environ.get("TLN_EXTRA_FLAGS", "").split() + ["-c", s, "-o", o]))
 
     def run(job):
         name, cmd = job

@@ -129,35 +129,42 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
   // measurement (tln_program_replay_executed): the 32 x 32 x 32 steps this block's matrix cores execute
   if (!GRU && g.dbg && tid == 0) atomicAdd(&g.dbg[8], (unsigned long long)nchunks * (TM * WM) * (TN * WN));
 
-  // issue the LDS-DMAs of chunk t into stage st: every thread PIECES x 16 bytes, lane-linear pieces of 1 KiB per wave
-  auto issue = [&](int t_raw, int st) {
-    // past the last chunk the DMAs repeat the last one into a stage nobody reads any more: no branch in the loop body
+  // The LDS-DMAs of one chunk: every thread PIECES x 16 bytes, lane-linear pieces of 1 KiB per wave.  In two halves so
+  // that the K loop can place them where it wants: dma_prepare (the chunk's tap and this thread's source rows, two
+  // dependent LDS reads) and dma_piece (one DMA from the prepared addresses).
+  struct Dma {
+    int tap, c0, kbase;
+    int idx[A_PIECES];
+  };
+  // past the last chunk the DMAs repeat the last one into a stage nobody reads any more: no branch in the loop body
+  auto dma_tap = [&](int t_raw, Dma& d) {
     const int t = t_raw < nchunks ? t_raw : nchunks - 1;
     const int ti = t / cpt;
-    const int tap = Taps[1 + ti];            // the ti-th tap present in this block
-    const int c0 = (t - ti * cpt) << 5;
-    // (GRU: "tap" 1 = the second source h with its own weights, both [3C][C])
-    const int kbase = GRU ? c0 : tap * s.cin + c0;
-    const float* srcp = (GRU && tap) ? g.s[1].src : s.src;
-    const float* Wp = (GRU && tap) ? g.W2 : g.W;
+    d.tap = Taps[1 + ti];                    // the ti-th tap present in this block
+    d.c0 = (t - ti * cpt) << 5;
+  };
+  auto dma_rows = [&](Dma& d) {
+    d.kbase = GRU ? d.c0 : d.tap * s.cin + d.c0;   // (GRU: "tap" 1 = the second source h with its own weights, both [3C][C])
+#pragma unroll
+    for (int p = 0; p < A_PIECES; ++p) d.idx[p] = Is[((p * NT + tid) >> 3) * taps + d.tap];
+  };
+  auto dma_piece = [&](const Dma& d, int st, int piece) {   // piece: compile-time after unrolling
     char* As = ring + st * STAGE;
     char* Bs = As + A_BYTES;
-    int idx[A_PIECES];
-#pragma unroll
-    for (int p = 0; p < A_PIECES; ++p) idx[p] = Is[((p * NT + tid) >> 3) * taps + tap];
-#pragma unroll
-    for (int p = 0; p < A_PIECES; ++p) {
+    if (piece < A_PIECES) {
+      const int p = piece;
+      const float* srcp = (GRU && d.tap) ? g.s[1].src : s.src;
       const int e = p * NT + tid;
       const int r = e >> 3, q = e & 7;
       // both addresses are computed, one is selected: a branch around the multiply would split the loop body
-      const int ic = idx[p] > 0 ? idx[p] : 0;
-      const float* data = srcp + (int64_t)ic * s.ld + c0 + 4 * (q ^ ((r >> 1) & 7));
-      const float* src = idx[p] >= 0 ? data : zero;
+      const int ic = d.idx[p] > 0 ? d.idx[p] : 0;
+      const float* data = srcp + (int64_t)ic * s.ld + d.c0 + 4 * (q ^ ((r >> 1) & 7));
+      const float* src = d.idx[p] >= 0 ? data : zero;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(As + (p * NT + wv * 64) * 16), 16, 0, 0);
-    }
-#pragma unroll
-    for (int p = 0; p < B_PIECES; ++p) {
+    } else {
+      const int p = piece - A_PIECES;
+      const float* Wp = (GRU && d.tap) ? g.W2 : g.W;
       const int e = p * NT + tid;
       const float* data;
       bool ok;
@@ -165,18 +172,25 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
         const int k = e / (BN / 4), nq = e - k * (BN / 4);
         const int n = n0 + 4 * nq;
         ok = n < g.N && (!B_PAD || e < BN * 8);
-        data = Wp + (int64_t)(kbase + (B_PAD ? (k & 31) : k)) * g.ldw + (ok ? n : 0);
+        data = Wp + (int64_t)(d.kbase + (B_PAD ? (k & 31) : k)) * g.ldw + (ok ? n : 0);
       } else {
         const int r = e >> 3, q = e & 7;
         int n = n0 + r;
         if (GRU) n = ((r % 96) >> 5) * s.cin + 64 * (int)blockIdx.y + 32 * (r / 96) + (r & 31);
         ok = n < g.N && (!B_PAD || e < BN * 8);
-        data = Wp + (int64_t)(ok ? n : 0) * g.ldw + kbase + 4 * (q ^ ((r >> 1) & 7));
+        data = Wp + (int64_t)(ok ? n : 0) * g.ldw + d.kbase + 4 * (q ^ ((r >> 1) & 7));
       }
       const float* src = ok ? data : zero;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(Bs + (p * NT + wv * 64) * 16), 16, 0, 0);
     }
+  };
+  auto issue = [&](int t_raw, int st) {       // a whole chunk at once (the ring's first fill)
+    Dma d;
+    dma_tap(t_raw, d);
+    dma_rows(d);
+#pragma unroll
+    for (int piece = 0; piece < PIECES; ++piece) dma_piece(d, st, piece);
   };
 
   constexpr int TNA = GRU ? TN + 1 : TN;   // GRU: tile TN takes the h chunks of the n gate (gh_n apart from gi_n)
@@ -191,33 +205,46 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
   const int arow0 = wm * 32 * TM + l31;       // this lane's A row of tile 0 inside the block
   const int bcol0 = wn * 32 * TN + l31;       // this lane's B column of tile 0 inside the block
 
-  // One chunk = four steps of 8 k (lane half h holds k = 8j + 4h + e, e = 0..3).  The fragments of step j+1 are
-  // requested BEFORE the MFMAs of step j are issued (two register sets), so that with one wave per SIMD the LDS
-  // latency and the prologue arithmetic sit behind 4*TM*TN MFMAs instead of in front of them; the DMAs of chunk t+2
-  // are issued after the first step's MFMAs for the same reason.
+  // One chunk = four steps of 8 k (lane half h holds k = 8j + 4h + e, e = 0..3), one step = four groups of TM*TN MFMAs
+  // (one per e).  The K loop is scheduled BY HAND, group by group, with a scheduling fence behind every group: left to
+  // the compiler (even under sched_group_barrier hints) the body came out as runs of 15 bare MFMAs, a lump of 69 other
+  // instructions around the DMAs and nine full `s_waitcnt lgkmcnt(0)` drains per chunk — the matrix pipe was busy 75 % of
+  // the loop (tools/v2_stamps.py).  The plan per group: its MFMAs first, then — in the shadow of those MFMAs — a quarter
+  // of the NEXT step's fragment loads; the GroupNorm transform of the next step's A values behind the last group of a
+  // step, when their loads are half a step old.  The chunk barrier sits behind the FIRST group of the last step: by then
+  // every read of this chunk's stage has been issued (the last step's fragments were loaded during the step before), so
+  // behind it the DMAs of chunk t + STAGES may overwrite the stage and the first fragments of chunk t + 1 are loaded
+  // under the remaining three groups — no chunk starts with an exposed LDS round trip.
   struct Frag {
     f32x4 a[TM];
     float b[TN][4];
-    f32x4 sc, sh;   // PRO: the GroupNorm scale / shift of the step's four channels — requested with the fragments, a
-                    // step ahead: read where they are used, every step would start with an exposed LDS round trip
+    f32x4 sc, sh;   // PRO: the GroupNorm scale / shift of the step's four channels
   };
-  auto frag_load = [&](int j, int c0, const char* As, const char* Bs, Frag& f) {
-    if (PRO) {
-      f.sc = *reinterpret_cast<const f32x4*>(Gsc + c0 + 8 * j + 4 * half);
-      f.sh = *reinterpret_cast<const f32x4*>(Gsh + c0 + 8 * j + 4 * half);
+  // a quarter of a step's fragment loads: part 0 = A (+ scale / shift), parts 1..3 = the B values
+  auto frag_load_part = [&](int j, int c0, const char* As, const char* Bs, Frag& f, int part) {
+    if (part == 0) {
+      if (PRO) {
+        f.sc = *reinterpret_cast<const f32x4*>(Gsc + c0 + 8 * j + 4 * half);
+        f.sh = *reinterpret_cast<const f32x4*>(Gsh + c0 + 8 * j + 4 * half);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int r = arow0 + 32 * i;
+        f.a[i] = *reinterpret_cast<const f32x4*>(As + r * 128 + (((2 * j + half) ^ ((r >> 1) & 7)) << 4));
+      }
+      return;
     }
+    if (!W_NK) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int r = arow0 + 32 * i;
-      f.a[i] = *reinterpret_cast<const f32x4*>(As + r * 128 + (((2 * j + half) ^ ((r >> 1) & 7)) << 4));
-    }
+      for (int q = 0; q < 4 * TN; ++q) {        // 4 TN single values over the parts 1..3, in the order the MFMAs want them
+        if (1 + (q * 3) / (4 * TN) != part) continue;
+        const int e = q / TN, jn = q - e * TN;
+        f.b[jn][e] = *reinterpret_cast<const float*>(Bs + ((8 * j + 4 * half + e) * BN + bcol0 + 32 * jn) * 4);
+      }
+    } else {
 #pragma unroll
-    for (int jn = 0; jn < TN; ++jn) {
-      if (!W_NK) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          f.b[jn][e] = *reinterpret_cast<const float*>(Bs + ((8 * j + 4 * half + e) * BN + bcol0 + 32 * jn) * 4);
-      } else {
+      for (int jn = 0; jn < TN; ++jn) {
+        if (1 + (jn * 2) / TN != part) continue;   // (parts 1 and 2: the step's first group needs every column tile)
         const int r = bcol0 + 32 * jn;
         const f32x4 v = *reinterpret_cast<const f32x4*>(Bs + r * 128 + (((2 * j + half) ^ ((r >> 1) & 7)) << 4));
         f.b[jn][0] = v[0];
@@ -227,82 +254,127 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
       }
     }
   };
-  auto frag_mma = [&](const float (&hi)[TM], Frag& f, auto hpart) {
-    constexpr bool H = decltype(hpart)::value;   // GRU: this chunk belongs to the second source
+  // GroupNorm affine; ReLU and the zero row of a missing neighbour in ONE median: a clamp to [0, inf) for a row that
+  // exists, to [0, 0] for one that does not
+  auto frag_pro = [&](const float (&hi)[TM], Frag& f) {
     if (PRO) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          // GroupNorm affine; ReLU and the zero row of a missing neighbour in ONE median: a clamp to [0, inf) for a row
-          // that exists, to [0, 0] for one that does not
-          f.a[i][e] = __builtin_amdgcn_fmed3f(fmaf(f.a[i][e], f.sc[e], f.sh[e]), 0.0f, hi[i]);
-        }
+        for (int e = 0; e < 4; ++e) f.a[i][e] = __builtin_amdgcn_fmed3f(fmaf(f.a[i][e], f.sc[e], f.sh[e]), 0.0f, hi[i]);
     }
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int jn = 0; jn < TN; ++jn) {
-          const int slot = (GRU && H && jn == TN - 1) ? TN : jn;   // compile-time after unrolling
-          acc[i][slot] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][e], f.b[jn][e], acc[i][slot], 0, 0, 0);
-        }
   };
-
-  // ---- main loop: ring of three stages, DMAs two chunks ahead, one barrier per chunk
-  if (nchunks > 0) {
-    issue(0, 0);
-    if (STAGES == 3) issue(1, 1);
-  }
-  int st = 0;
-  // PRO: upper end of the clamp behind the affine (frag_mma) for this lane's rows in chunk t: inf for a row that exists
-  // under the chunk's tap, 0 for a missing neighbour.  Two dependent LDS reads (tap list, index list), neither touched
-  // after the prologue: asked for one chunk AHEAD, in the middle of the MFMAs, instead of right behind the barrier
+  auto frag_mma_e = [&](const Frag& f, int e, auto hpart) {
+    constexpr bool H = decltype(hpart)::value;   // GRU: this chunk belongs to the second source
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int jn = 0; jn < TN; ++jn) {
+        const int slot = (GRU && H && jn == TN - 1) ? TN : jn;   // compile-time after unrolling
+        acc[i][slot] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][e], f.b[jn][e], acc[i][slot], 0, 0, 0);
+      }
+  };
+  // PRO: upper end of the clamp behind the affine for this lane's rows in chunk t: inf for a row that exists under the
+  // chunk's tap, 0 for a missing neighbour.  Two dependent LDS reads (tap list, index list)
   auto clamp_of = [&](int t_raw, float (&hi)[TM]) {
     const int t = t_raw < nchunks ? t_raw : nchunks - 1;
     const int tap = Taps[1 + t / cpt];
 #pragma unroll
     for (int i = 0; i < TM; ++i) hi[i] = (PRO && Is[(arow0 + 32 * i) * taps + tap] < 0) ? 0.0f : __builtin_inff();
   };
+#define V2_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+  // ---- the ring's first fill; the first chunk's first fragments
+  Frag f0, f1;
   float hi[TM];
-  if (nchunks > 0) clamp_of(0, hi);
+  if (nchunks > 0) {
+#pragma unroll
+    for (int k = 0; k < STAGES; ++k) issue(k, k);
+    clamp_of(0, hi);
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((STAGES - 1) * PIECES) : "memory");
+#pragma unroll
+    for (int part = 0; part < 4; ++part) frag_load_part(0, 0, ring, ring + A_BYTES, f0, part);
+    frag_pro(hi, f0);
+  }
+#ifdef TLN_V2_STAMPS
+  unsigned long long st_dma = 0, st_bar = 0;
+  const unsigned long long st_begin = __builtin_amdgcn_s_memtime();
+  const unsigned long long st_rbegin = __builtin_amdgcn_s_memrealtime();
+#endif
+  int st = 0;
   auto chunk = [&](int t, auto hpart) {
-    // this thread's DMAs of chunk t have landed (those of chunk t+1 may still fly); after the barrier everybody's
-    // have, and everybody has finished reading the stage that chunk t+2 is about to overwrite
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(STAGES == 3 ? PIECES : 0) : "memory");
     const int ti = t / cpt;
     const int c0 = (t - ti * cpt) << 5;
     const char* As = ring + st * STAGE;
     const char* Bs = As + A_BYTES;
-    Frag f0, f1;
-    frag_load(0, c0, As, Bs, f0);
-    frag_load(1, c0, As, Bs, f1);
-    frag_mma(hi, f0, hpart);
-    if (STAGES == 3) issue(t + 2, st == 0 ? 2 : st - 1);
-    else issue(t + 1, st ^ 1);
-    frag_load(2, c0, As, Bs, f0);
-    frag_mma(hi, f1, hpart);
-    frag_load(3, c0, As, Bs, f1);
-    frag_mma(hi, f0, hpart);
+    const int stn = st == STAGES - 1 ? 0 : st + 1;
+    const int tn = t + 1 < nchunks ? t + 1 : nchunks - 1;
+    const int c0n = (tn - (tn / cpt) * cpt) << 5;
+    const char* Asn = ring + stn * STAGE;
+    const char* Bsn = Asn + A_BYTES;
+    Dma d;
     float hin[TM];
-    if (PRO) clamp_of(t + 1, hin);
-    frag_mma(hi, f1, hpart);
+    int tapn = 0, isn[TM];
+    // steps 0..2: the groups of step j, the loads of step j + 1 behind them
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      Frag& cur = (j & 1) ? f1 : f0;
+      Frag& nxt = (j & 1) ? f0 : f1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        frag_mma_e(cur, e, hpart);
+        if (e == 3) frag_pro(hi, nxt);                         // (its operands came with part 0, three groups ago)
+        frag_load_part(j + 1, c0, As, Bs, nxt, e);
+        if (j == 0 && e == 1) dma_tap(t + STAGES, d);         // (the DMAs' two dependent LDS reads, a step apart)
+        if (j == 1 && e == 1) dma_rows(d);
+        if (j == 0 && e == 2 && PRO) tapn = Taps[1 + tn / cpt];   // (the next chunk's clamp: two dependent reads as well)
+        if (j == 1 && e == 2 && PRO) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) isn[i] = Is[(arow0 + 32 * i) * taps + tapn];
+        }
+        if (j == 2 && e == 2 && PRO) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) hin[i] = isn[i] < 0 ? 0.0f : __builtin_inff();
+        }
+        V2_FENCE();
+      }
+    }
+    // step 3: behind its first group the chunk barrier — this thread's DMAs of chunk t + 1 have landed (those of the
+    // chunks behind it may still fly), after the barrier everybody's have, and every read of this chunk's stage is done
+    frag_mma_e(f1, 0, hpart);
+#ifdef TLN_V2_STAMPS
+    const unsigned long long tb0 = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((STAGES - 2) * PIECES) : "memory");
+    const unsigned long long tb1 = __builtin_amdgcn_s_memtime();
+    asm volatile("s_barrier" ::: "memory");
+    const unsigned long long tb2 = __builtin_amdgcn_s_memtime();
+    st_dma += tb1 - tb0;
+    st_bar += tb2 - tb1;
+    if (g.dbg && lane == 0 && blockIdx.x == 37 && blockIdx.y == 0 && blockIdx.z == 0 && t < 60) {   // one block's timeline
+      g.dbg[32 + (t * 8 + wv) * 2] = tb1;
+      g.dbg[32 + (t * 8 + wv) * 2 + 1] = tb2;
+    }
+#else
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((STAGES - 2) * PIECES) : "memory");
+#endif
+    V2_FENCE();
+#pragma unroll
+    for (int e = 1; e < 4; ++e) {
+      frag_mma_e(f1, e, hpart);
+      // the DMAs of chunk t + STAGES into this chunk's stage, a third behind each group; the first fragments of chunk t + 1
+#pragma unroll
+      for (int piece = 0; piece < PIECES; ++piece)
+        if ((piece * 3) / PIECES == e - 1) dma_piece(d, st, piece);
+      if (e == 3) frag_pro(PRO ? hin : hi, f0);
+      if (e == 1) frag_load_part(0, c0n, Asn, Bsn, f0, 0);
+      frag_load_part(0, c0n, Asn, Bsn, f0, e);
+      V2_FENCE();
+    }
     if (PRO) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) hi[i] = hin[i];
     }
-    // scheduling hint for the whole (branch-free) chunk body: one MFMA, then a little of everything else — an MFMA
-    // occupies the matrix pipe for 16 issue slots, and what a wave issues between two MFMAs is free, what it issues
-    // in a lump between two runs of MFMAs is not (with one wave per SIMD nobody else fills the pipe meanwhile)
-#pragma unroll
-    for (int k = 0; k < 16 * TM * TN; ++k) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
-      __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);   // VALU
-      if ((k & 7) == 7) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read (the LDS-DMAs)
-    }
-    st = st == STAGES - 1 ? 0 : st + 1;
+    st = stn;
   };
   if constexpr (GRU) {
     for (int t = 0; t < cpt; ++t) chunk(t, std::false_type{});          // the channels of x
@@ -310,6 +382,17 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
   } else {
     for (int t = 0; t < nchunks; ++t) chunk(t, std::false_type{});
   }
+#ifdef TLN_V2_STAMPS
+  if (g.dbg && lane == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (blockIdx.x % 37) == 0) {   // a sample of blocks, every wave
+    const unsigned long long st_end = __builtin_amdgcn_s_memtime();
+    atomicAdd(&g.dbg[16], st_end - st_begin);
+    atomicAdd(&g.dbg[17], st_dma);
+    atomicAdd(&g.dbg[18], st_bar);
+    atomicAdd(&g.dbg[19], (unsigned long long)nchunks);
+    atomicAdd(&g.dbg[20], 1ull);
+    atomicAdd(&g.dbg[21], __builtin_amdgcn_s_memrealtime() - st_rbegin);   // 100 MHz
+  }
+#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the repeated DMAs of the last two rounds
 
   // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).  The residual is loaded for a whole
