@@ -42,6 +42,7 @@ __device__ __attribute__((aligned(16))) float g_v2_zero[4] = {0.f, 0.f, 0.f, 0.f
 // STAGES = 3: DMAs two chunks ahead; STAGES = 2 (128 x 128 tile): one chunk ahead, but two workgroups fit a CU's LDS
 template <int WM, int WN, int TM, int TN, bool W_NK, bool PRO, bool GRU = false, int STAGES = V2_STAGES>
 __device__ __forceinline__ void v2_body(const GemmArgs& g) {
+#if __HIP_DEVICE_COMPILE__   // (the buffer-resource type of the LDS-DMAs exists in the device pass only)
   constexpr int NT = 64 * WM * WN;
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
   // (B: a thread count that does not divide the 16-byte pieces of the weight tile — the 96-row tile's 384 threads on a
@@ -59,9 +60,8 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
   int* Is = reinterpret_cast<int*>(smem2 + STAGES * STAGE);            // [BM][taps]
   const SrcDev& s = g.s[0];
   const int taps = s.taps;
-  float* Gsc = reinterpret_cast<float*>(Is + BM * TLN_TAPS);
-  float* Gsh = Gsc + s.cin;
-  int* Rid = reinterpret_cast<int*>(Gsh + s.cin);   // [BM] row of block position r (the product's row order, or m0 + r)
+  float* GS = reinterpret_cast<float*>(Is + BM * TLN_TAPS);   // [cin / 4][8]: GroupNorm scale | shift of four channels
+  int* Rid = reinterpret_cast<int*>(GS + 2 * s.cin);   // [BM] row of block position r (the product's row order, or m0 + r)
   int* Taps = Rid + BM;                             // [0] = number of taps present in this block, [1..] = which
 
   const int tid = threadIdx.x;
@@ -72,6 +72,7 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
   const int n0 = blockIdx.y * BN;
   const bool has_table = s.table != nullptr;
   const int src_rows = (int)s.src_rows;
+  const int ld_bytes = (int)s.ld * 4;
 
   // ---- block prologue: the rows of this block (in the table's row order when there is one: rows with the same set of
   // present taps sit together, lattice.hip), their tap indices (or the row's own index), the GroupNorm scale / shift,
@@ -92,7 +93,10 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
       if (m >= 0) idx = has_table ? s.table[(int64_t)m * taps + tap] : m;
       if (idx >= src_rows) idx = -1;          // rows past the source: zeros (pad value 0, checked on the host)
       if (GRU && tap == 1 && idx >= (int)g.s[1].src_rows) idx = -1;   // "tap" 1 = the row of h
-      Is[i] = idx;
+      // kept as the row's BYTE offset in the source (host: rows * ld * 4 < 2^31), a missing row as INT_MIN: far outside
+      // the buffer's range, whose check then delivers the zero row (tools/micro/buffer_lds_oob.hip) — no select, no
+      // 64-bit address arithmetic in the K loop
+      Is[i] = idx < 0 ? (int)0x80000000 : idx * ld_bytes;
     }
     if (has_table && !GRU) {
 #pragma unroll
@@ -101,10 +105,10 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
     }
   }
   if (lane == 0) Taps[16 + wv] = (int)present;   // [16 .. 16 + waves): what each wave saw
-  if (PRO) {
+  if (PRO) {   // scale and shift of four channels side by side: [c / 4][scale x 4 | shift x 4]
     for (int c = tid; c < s.cin; c += NT) {
-      Gsc[c] = s.scale[c];
-      Gsh[c] = s.shift[c];
+      GS[(c >> 2) * 8 + (c & 3)] = s.scale[c];
+      GS[(c >> 2) * 8 + 4 + (c & 3)] = s.shift[c];
     }
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -125,64 +129,81 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
 
   const int cpt = s.cin >> 5;                 // chunks per tap
   const int nchunks = Taps[0] * cpt;
-  const float* zero = g_v2_zero;
   // measurement (tln_program_replay_executed): the 32 x 32 x 32 steps this block's matrix cores execute
   if (!GRU && g.dbg && tid == 0) atomicAdd(&g.dbg[8], (unsigned long long)nchunks * (TM * WM) * (TN * WN));
 
-  // The LDS-DMAs of one chunk: every thread PIECES x 16 bytes, lane-linear pieces of 1 KiB per wave.  In two halves so
-  // that the K loop can place them where it wants: dma_prepare (the chunk's tap and this thread's source rows, two
-  // dependent LDS reads) and dma_piece (one DMA from the prepared addresses).
+  // The LDS-DMAs of one chunk: every thread PIECES x 16 bytes, lane-linear pieces of 1 KiB per wave, as
+  // `buffer_load_dwordx4 ... lds`: the address of a piece is a buffer (source rows / weights) + ONE 32-bit lane offset +
+  // a scalar offset.  What depends on the lane alone is computed here, once per block; per chunk a thread adds its rows'
+  // byte offsets (from the index list) to its pieces' constants — three vector instructions where the flat-address
+  // version had fifty-five (a vector instruction costs the matrix pipe ~3 cycles: tools/micro/mfma_rate.hip).
+  const unsigned RSRC3 = 0x00020000u;        // raw buffer, 32-bit data format
+  const __amdgpu_buffer_rsrc_t rA0 = __builtin_amdgcn_make_buffer_rsrc((void*)s.src, 0, (int)(s.src_rows * s.ld * 4), RSRC3);
+  const __amdgpu_buffer_rsrc_t rA1 =
+      GRU ? __builtin_amdgcn_make_buffer_rsrc((void*)g.s[1].src, 0, (int)(g.s[1].src_rows * s.ld * 4), RSRC3) : rA0;
+  const int w_bytes = (int)((W_NK ? (int64_t)g.N : (int64_t)(GRU ? s.cin : g.K0)) * g.ldw * 4);
+  const __amdgpu_buffer_rsrc_t rB0 = __builtin_amdgcn_make_buffer_rsrc((void*)g.W, 0, w_bytes, RSRC3);
+  const __amdgpu_buffer_rsrc_t rB1 = GRU ? __builtin_amdgcn_make_buffer_rsrc((void*)g.W2, 0, w_bytes, RSRC3) : rB0;
+  unsigned a_lane[A_PIECES], b_lane[B_PIECES];
+#pragma unroll
+  for (int p = 0; p < A_PIECES; ++p) {
+    const int e = p * NT + tid;
+    const int r = e >> 3, q = e & 7;
+    a_lane[p] = 16u * (unsigned)(q ^ ((r >> 1) & 7));
+  }
+#pragma unroll
+  for (int p = 0; p < B_PIECES; ++p) {
+    const int e = p * NT + tid;
+    bool ok;
+    unsigned off;
+    if (!W_NK) {
+      const int k = e / (BN / 4), nq = e - k * (BN / 4);
+      const int n = n0 + 4 * nq;
+      ok = n < g.N && (!B_PAD || e < BN * 8);
+      off = 4u * ((unsigned)(B_PAD ? (k & 31) : k) * (unsigned)g.ldw + (unsigned)n);
+    } else {
+      const int r = e >> 3, q = e & 7;
+      int n = n0 + r;
+      if (GRU) n = ((r % 96) >> 5) * s.cin + 64 * (int)blockIdx.y + 32 * (r / 96) + (r & 31);
+      ok = n < g.N && (!B_PAD || e < BN * 8);
+      off = 4u * ((unsigned)n * (unsigned)g.ldw + 4u * (unsigned)(q ^ ((r >> 1) & 7)));
+    }
+    b_lane[p] = ok ? off : 0x80000000u;      // (columns past N: zeros from the range check)
+  }
+  const unsigned is_lane = 4u * (unsigned)((tid >> 3) * taps);   // this thread's row of piece 0 in the index list; piece p: + 64 p rows
   struct Dma {
-    int tap, c0, kbase;
-    int idx[A_PIECES];
+    int tap, c0;
+    unsigned voff[A_PIECES];
   };
   // past the last chunk the DMAs repeat the last one into a stage nobody reads any more: no branch in the loop body
   auto dma_tap = [&](int t_raw, Dma& d) {
     const int t = t_raw < nchunks ? t_raw : nchunks - 1;
     const int ti = t / cpt;
-    d.tap = Taps[1 + ti];                    // the ti-th tap present in this block
+    d.tap = Taps[1 + ti];                    // the ti-th tap present in this block (uniform; made a scalar in dma_rows)
     d.c0 = (t - ti * cpt) << 5;
   };
   auto dma_rows = [&](Dma& d) {
-    d.kbase = GRU ? d.c0 : d.tap * s.cin + d.c0;   // (GRU: "tap" 1 = the second source h with its own weights, both [3C][C])
+    d.tap = __builtin_amdgcn_readfirstlane(d.tap);   // (the DMAs want it in scalar registers: buffer choice, scalar offset)
+    const char* isp = reinterpret_cast<const char*>(Is) + is_lane + 4 * d.tap;
 #pragma unroll
-    for (int p = 0; p < A_PIECES; ++p) d.idx[p] = Is[((p * NT + tid) >> 3) * taps + d.tap];
+    for (int p = 0; p < A_PIECES; ++p)
+      d.voff[p] = (unsigned)*reinterpret_cast<const int*>(isp + p * (NT / 8) * taps * 4) + a_lane[p];
   };
-  auto dma_piece = [&](const Dma& d, int st, int piece) {   // piece: compile-time after unrolling
+  auto dma_piece = [&](const Dma& d, int st, int piece) {   // st, piece: compile-time after unrolling
     char* As = ring + st * STAGE;
     char* Bs = As + A_BYTES;
     if (piece < A_PIECES) {
       const int p = piece;
-      const float* srcp = (GRU && d.tap) ? g.s[1].src : s.src;
-      const int e = p * NT + tid;
-      const int r = e >> 3, q = e & 7;
-      // both addresses are computed, one is selected: a branch around the multiply would split the loop body
-      const int ic = d.idx[p] > 0 ? d.idx[p] : 0;
-      const float* data = srcp + (int64_t)ic * s.ld + d.c0 + 4 * (q ^ ((r >> 1) & 7));
-      const float* src = d.idx[p] >= 0 ? data : zero;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(As + (p * NT + wv * 64) * 16), 16, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds((GRU && d.tap) ? rA1 : rA0,
+                                               (__attribute__((address_space(3))) void*)(As + (p * NT + wv * 64) * 16), 16,
+                                               d.voff[p], 4 * d.c0, 0, 0);
     } else {
       const int p = piece - A_PIECES;
-      const float* Wp = (GRU && d.tap) ? g.W2 : g.W;
-      const int e = p * NT + tid;
-      const float* data;
-      bool ok;
-      if (!W_NK) {
-        const int k = e / (BN / 4), nq = e - k * (BN / 4);
-        const int n = n0 + 4 * nq;
-        ok = n < g.N && (!B_PAD || e < BN * 8);
-        data = Wp + (int64_t)(d.kbase + (B_PAD ? (k & 31) : k)) * g.ldw + (ok ? n : 0);
-      } else {
-        const int r = e >> 3, q = e & 7;
-        int n = n0 + r;
-        if (GRU) n = ((r % 96) >> 5) * s.cin + 64 * (int)blockIdx.y + 32 * (r / 96) + (r & 31);
-        ok = n < g.N && (!B_PAD || e < BN * 8);
-        data = Wp + (int64_t)(ok ? n : 0) * g.ldw + d.kbase + 4 * (q ^ ((r >> 1) & 7));
-      }
-      const float* src = ok ? data : zero;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(Bs + (p * NT + wv * 64) * 16), 16, 0, 0);
+      // (GRU: "tap" 1 = the second source h with its own weights, both [3C][C])
+      const int kbase = GRU ? d.c0 : d.tap * s.cin + d.c0;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds((GRU && d.tap) ? rB1 : rB0,
+                                               (__attribute__((address_space(3))) void*)(Bs + (p * NT + wv * 64) * 16), 16,
+                                               b_lane[p], W_NK ? 4 * kbase : 4 * kbase * (int)g.ldw, 0, 0);
     }
   };
   auto issue = [&](int t_raw, int st) {       // a whole chunk at once (the ring's first fill)
@@ -220,18 +241,46 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
     float b[TN][4];
     f32x4 sc, sh;   // PRO: the GroupNorm scale / shift of the step's four channels
   };
-  // a quarter of a step's fragment loads: part 0 = A (+ scale / shift), parts 1..3 = the B values
-  auto frag_load_part = [&](int j, int c0, const char* As, const char* Bs, Frag& f, int part) {
+  // Where this lane's fragments sit, per ring stage: computed once, kept in registers (made opaque, or the compiler would
+  // rather re-derive them with an add in front of every read — 45 of the loop's 120 vector instructions).  With the stage
+  // a compile-time constant of the chunk body (the loop dispatches on it) every LDS read of the loop is base register +
+  // immediate.  A: [row][32 floats], 16-byte slots swizzled with the row; B: [32][BN] or, for [N,K] weights, like A.
+  unsigned a_at[STAGES][TM][4], b_at[STAGES][W_NK ? 4 : 1];
+#pragma unroll
+  for (int st = 0; st < STAGES; ++st) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = arow0 + 32 * i;
+        a_at[st][i][j] = (unsigned)(size_t)(ring + st * STAGE + r * 128 + (((2 * j + half) ^ ((r >> 1) & 7)) << 4));
+        asm volatile("" : "+v"(a_at[st][i][j]));
+      }
+    if (!W_NK) {
+      b_at[st][0] = (unsigned)(size_t)(ring + st * STAGE + A_BYTES + (4 * half * BN + bcol0) * 4);
+      asm volatile("" : "+v"(b_at[st][0]));
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {   // (the swizzle of a column's slot does not depend on the column tile: 32 jn rows further)
+        b_at[st][j] = (unsigned)(size_t)(ring + st * STAGE + A_BYTES + bcol0 * 128 + (((2 * j + half) ^ ((bcol0 >> 1) & 7)) << 4));
+        asm volatile("" : "+v"(b_at[st][j]));
+      }
+    }
+  }
+  const unsigned gs_lane = (unsigned)(size_t)GS + 32u * (unsigned)half;   // channel c0 + 8 j + 4 half: + 8 c0 + 64 j bytes
+  auto lds_f4 = [](unsigned addr) { return *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>((size_t)addr); };
+  // (volatile: two single reads merged into one ds_read2 reach only 1 KB past their base and cost an add — a vector
+  //  instruction, ~3 cycles of matrix pipe — where a ds_read_b32 with its 16-bit offset costs nothing)
+  auto lds_f1 = [](unsigned addr) { return *reinterpret_cast<const volatile __attribute__((address_space(3))) float*>((size_t)addr); };
+  // a quarter of a step's fragment loads: part 0 = A (+ scale / shift), parts 1..3 = the B values.  st, j, part: constants
+  auto frag_load_part = [&](int st, int j, unsigned gs_c0, Frag& f, int part) {
     if (part == 0) {
       if (PRO) {
-        f.sc = *reinterpret_cast<const f32x4*>(Gsc + c0 + 8 * j + 4 * half);
-        f.sh = *reinterpret_cast<const f32x4*>(Gsh + c0 + 8 * j + 4 * half);
+        f.sc = lds_f4(gs_c0 + 64 * j);
+        f.sh = lds_f4(gs_c0 + 64 * j + 16);
       }
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int r = arow0 + 32 * i;
-        f.a[i] = *reinterpret_cast<const f32x4*>(As + r * 128 + (((2 * j + half) ^ ((r >> 1) & 7)) << 4));
-      }
+      for (int i = 0; i < TM; ++i) f.a[i] = lds_f4(a_at[st][i][j]);
       return;
     }
     if (!W_NK) {
@@ -239,14 +288,13 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
       for (int q = 0; q < 4 * TN; ++q) {        // 4 TN single values over the parts 1..3, in the order the MFMAs want them
         if (1 + (q * 3) / (4 * TN) != part) continue;
         const int e = q / TN, jn = q - e * TN;
-        f.b[jn][e] = *reinterpret_cast<const float*>(Bs + ((8 * j + 4 * half + e) * BN + bcol0 + 32 * jn) * 4);
+        f.b[jn][e] = lds_f1(b_at[st][0] + ((8 * j + e) * BN + 32 * jn) * 4);
       }
     } else {
 #pragma unroll
       for (int jn = 0; jn < TN; ++jn) {
         if (1 + (jn * 2) / TN != part) continue;   // (parts 1 and 2: the step's first group needs every column tile)
-        const int r = bcol0 + 32 * jn;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(Bs + r * 128 + (((2 * j + half) ^ ((r >> 1) & 7)) << 4));
+        const f32x4 v = lds_f4(b_at[st][j] + 32 * jn * 128);
         f.b[jn][0] = v[0];
         f.b[jn][1] = v[1];
         f.b[jn][2] = v[2];
@@ -293,7 +341,7 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
     clamp_of(0, hi);
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((STAGES - 1) * PIECES) : "memory");
 #pragma unroll
-    for (int part = 0; part < 4; ++part) frag_load_part(0, 0, ring, ring + A_BYTES, f0, part);
+    for (int part = 0; part < 4; ++part) frag_load_part(0, 0, gs_lane, f0, part);
     frag_pro(hi, f0);
   }
 #ifdef TLN_V2_STAMPS
@@ -301,17 +349,14 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
   const unsigned long long st_begin = __builtin_amdgcn_s_memtime();
   const unsigned long long st_rbegin = __builtin_amdgcn_s_memrealtime();
 #endif
-  int st = 0;
-  auto chunk = [&](int t, auto hpart) {
+  // the body of chunk t in ring stage ST (a compile-time constant: every LDS address below is register + immediate)
+  auto chunk = [&](int t, auto stage, auto hpart) {
+    constexpr int st = decltype(stage)::value;
+    constexpr int stn = st == STAGES - 1 ? 0 : st + 1;
     const int ti = t / cpt;
-    const int c0 = (t - ti * cpt) << 5;
-    const char* As = ring + st * STAGE;
-    const char* Bs = As + A_BYTES;
-    const int stn = st == STAGES - 1 ? 0 : st + 1;
+    const unsigned gs_c0 = gs_lane + 8u * (unsigned)((t - ti * cpt) << 5);
     const int tn = t + 1 < nchunks ? t + 1 : nchunks - 1;
-    const int c0n = (tn - (tn / cpt) * cpt) << 5;
-    const char* Asn = ring + stn * STAGE;
-    const char* Bsn = Asn + A_BYTES;
+    const unsigned gs_c0n = gs_lane + 8u * (unsigned)((tn - (tn / cpt) * cpt) << 5);
     Dma d;
     float hin[TM];
     int tapn = 0, isn[TM];
@@ -324,7 +369,7 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
       for (int e = 0; e < 4; ++e) {
         frag_mma_e(cur, e, hpart);
         if (e == 3) frag_pro(hi, nxt);                         // (its operands came with part 0, three groups ago)
-        frag_load_part(j + 1, c0, As, Bs, nxt, e);
+        frag_load_part(st, j + 1, gs_c0, nxt, e);
         if (j == 0 && e == 1) dma_tap(t + STAGES, d);         // (the DMAs' two dependent LDS reads, a step apart)
         if (j == 1 && e == 1) dma_rows(d);
         if (j == 0 && e == 2 && PRO) tapn = Taps[1 + tn / cpt];   // (the next chunk's clamp: two dependent reads as well)
@@ -366,21 +411,37 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
       for (int piece = 0; piece < PIECES; ++piece)
         if ((piece * 3) / PIECES == e - 1) dma_piece(d, st, piece);
       if (e == 3) frag_pro(PRO ? hin : hi, f0);
-      if (e == 1) frag_load_part(0, c0n, Asn, Bsn, f0, 0);
-      frag_load_part(0, c0n, Asn, Bsn, f0, e);
+      if (e == 1) frag_load_part(stn, 0, gs_c0n, f0, 0);
+      frag_load_part(stn, 0, gs_c0n, f0, e);
       V2_FENCE();
     }
     if (PRO) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) hi[i] = hin[i];
     }
-    st = stn;
   };
+  // (the stage of chunk t is t mod STAGES: the loop dispatches on it with one scalar branch per chunk)
+  auto run_chunk = [&](int t, int st, auto hpart) {
+    if (st == 0) chunk(t, std::integral_constant<int, 0>{}, hpart);
+    else if (st == 1 || STAGES == 2) chunk(t, std::integral_constant<int, 1>{}, hpart);
+    else chunk(t, std::integral_constant<int, STAGES - 1>{}, hpart);
+  };
+  int st = 0;
   if constexpr (GRU) {
-    for (int t = 0; t < cpt; ++t) chunk(t, std::false_type{});          // the channels of x
-    for (int t = cpt; t < nchunks; ++t) chunk(t, std::true_type{});     // the channels of h
+    for (int t = 0; t < cpt; ++t, st = st == STAGES - 1 ? 0 : st + 1) run_chunk(t, st, std::false_type{});        // the channels of x
+    for (int t = cpt; t < nchunks; ++t, st = st == STAGES - 1 ? 0 : st + 1) run_chunk(t, st, std::true_type{});   // the channels of h
   } else {
-    for (int t = 0; t < nchunks; ++t) chunk(t, std::false_type{});
+    // STAGES chunks per trip, straight-line (a dispatch per chunk would meet in one loop head and pay ~50 register moves
+    // per chunk for it), then the one or two that are left
+    int t = 0;
+    for (; t + STAGES <= nchunks; t += STAGES) {
+      chunk(t, std::integral_constant<int, 0>{}, std::false_type{});
+      chunk(t + 1, std::integral_constant<int, 1>{}, std::false_type{});
+      if constexpr (STAGES == 3) chunk(t + 2, std::integral_constant<int, 2>{}, std::false_type{});
+    }
+    if (t < nchunks) chunk(t, std::integral_constant<int, 0>{}, std::false_type{});
+    if (STAGES == 3 && t + 1 < nchunks) chunk(t + 1, std::integral_constant<int, 1>{}, std::false_type{});
+    (void)st;
   }
 #ifdef TLN_V2_STAMPS
   if (g.dbg && lane == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (blockIdx.x % 37) == 0) {   // a sample of blocks, every wave
@@ -467,6 +528,7 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
         if (half == 0 && ncol && mrow0 < g.M) g.stats[(mrow0 >> 5) * g.N + n] = make_double2(s1, s2);
       }
     }
+#endif
 }
 
 template <int WM, int WN, int TM, int TN, bool W_NK, bool PRO, int STAGES = V2_STAGES>
@@ -507,12 +569,21 @@ extern "C" void tln_gemm_v2_config(int off, int64_t min_m) {
   if (min_m > 0) g_v2_min_m = min_m;
 }
 
+// the kernel addresses a source row and a weight row as a 32-bit byte offset into a buffer (the range check of the
+// buffer delivers the zero rows): source and weights below 2 GiB each — 1.0M vertices x 256 channels still fit
+static bool v2_bytes_ok(const GemmArgs& g) {
+  const SrcDev& s = g.s[0];
+  const int64_t lim = (1ll << 31) - 4096;
+  return s.src_rows * s.ld * 4 < lim && ((int64_t)s.taps * s.cin + g.N) * g.ldw * 4 < lim;
+}
+
 bool tln_gemm_v2_ok(const GemmArgs& g, bool w_is_nk, bool vec) {
   if ((g_v2_off & 1) || !vec || g.nsrc != 1 || g.M < g_v2_min_m) return false;
   const SrcDev& s = g.s[0];
   if (s.cin % 32 != 0 || s.cin > 1024 || s.pad != 0.f) return false;
   if (!(s.taps == 1 || s.taps == TLN_TAPS)) return false;
   if (s.src_rows >= (1ll << 31) || g.M >= (1ll << 31)) return false;
+  if (!v2_bytes_ok(g)) return false;
   // prologue: none, or GroupNorm affine + ReLU (scale/shift given, or partial sums with the scale/shift scratch)
   const bool affine = s.scale != nullptr || s.gn_part != nullptr;
   if (affine && (!s.relu || s.scale == nullptr || s.shift == nullptr)) return false;
@@ -588,6 +659,7 @@ static bool v2_shape_ok(const GemmArgs& g, bool vec) {
   if (s.cin % 32 != 0 || s.cin > 1024 || s.pad != 0.f) return false;
   if (!(s.taps == 1 || s.taps == TLN_TAPS)) return false;
   if (s.src_rows >= (1ll << 31) || g.M >= (1ll << 31)) return false;
+  if (!v2_bytes_ok(g)) return false;
   const bool affine = s.scale != nullptr || s.gn_part != nullptr;
   if (affine && (!s.relu || s.scale == nullptr || s.shift == nullptr)) return false;
   if (!affine && s.relu) return false;
@@ -688,7 +760,7 @@ int tln_gemm_v2_launch_multi(GemmArgs* g, int n, bool w_is_nk, hipStream_t s) {
 // h' = GRUCell(x, pad(h)) as one two-source product with the cell in its epilogue (see v2_body)
 bool tln_gemm_v2_gru_ok(int64_t V, int64_t Vh, int C) {
   static const bool off = getenv("TLN_GRU_FUSED_OFF") != nullptr;
-  return !off && !(g_v2_off & 1) && V >= g_v2_min_m && V < (1ll << 31) && Vh >= 1 && Vh <= V && C % 64 == 0 && C <= 1024;
+  return !off && !(g_v2_off & 1) && V >= g_v2_min_m && V * C * 4 < (1ll << 31) - 4096 && Vh >= 1 && Vh <= V && C % 64 == 0 && C <= 1024;
 }
 static void v2_gru_args(GemmArgs& g, const float* d_x, const float* d_h, int64_t Vh, int64_t V, int C, const float* d_w_ih,
                         const float* d_w_hh, const float* d_b_ih, const float* d_b_hh, float* d_out) {
