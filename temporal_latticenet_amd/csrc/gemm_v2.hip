@@ -312,15 +312,11 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
         for (int e = 0; e < 4; ++e) f.a[i][e] = __builtin_amdgcn_fmed3f(fmaf(f.a[i][e], f.sc[e], f.sh[e]), 0.0f, hi[i]);
     }
   };
-  auto frag_mma_e = [&](const Frag& f, int e, auto hpart) {
-    constexpr bool H = decltype(hpart)::value;   // GRU: this chunk belongs to the second source
+  auto frag_mma_e = [&](const Frag& f, int e) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int jn = 0; jn < TN; ++jn) {
-        const int slot = (GRU && H && jn == TN - 1) ? TN : jn;   // compile-time after unrolling
-        acc[i][slot] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][e], f.b[jn][e], acc[i][slot], 0, 0, 0);
-      }
+      for (int jn = 0; jn < TN; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][e], f.b[jn][e], acc[i][jn], 0, 0, 0);
   };
   // PRO: upper end of the clamp behind the affine for this lane's rows in chunk t: inf for a row that exists under the
   // chunk's tap, 0 for a missing neighbour.  Two dependent LDS reads (tap list, index list)
@@ -350,7 +346,19 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
   const unsigned long long st_rbegin = __builtin_amdgcn_s_memrealtime();
 #endif
   // the body of chunk t in ring stage ST (a compile-time constant: every LDS address below is register + immediate)
-  auto chunk = [&](int t, auto stage, auto hpart) {
+  auto chunk = [&](int t, auto stage) {
+    // GRU: the chunks of x come first, then those of h.  The n gate needs gi_n and gh_n apart: at the first chunk of h the
+    // n-gate tile (x's share, complete) moves to the extra tile and starts again from zero for h's share — once per block,
+    // a uniform branch; the K loop itself is the same for both sources
+    if (GRU && t == cpt) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          acc[i][TNA - 1][r] = acc[i][TN - 1][r];
+          acc[i][TN - 1][r] = 0.0f;
+        }
+    }
     constexpr int st = decltype(stage)::value;
     constexpr int stn = st == STAGES - 1 ? 0 : st + 1;
     const int ti = t / cpt;
@@ -367,7 +375,7 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
       Frag& nxt = (j & 1) ? f0 : f1;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        frag_mma_e(cur, e, hpart);
+        frag_mma_e(cur, e);
         if (e == 3) frag_pro(hi, nxt);                         // (its operands came with part 0, three groups ago)
         frag_load_part(st, j + 1, gs_c0, nxt, e);
         if (j == 0 && e == 1) dma_tap(t + STAGES, d);         // (the DMAs' two dependent LDS reads, a step apart)
@@ -386,7 +394,7 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
     }
     // step 3: behind its first group the chunk barrier — this thread's DMAs of chunk t + 1 have landed (those of the
     // chunks behind it may still fly), after the barrier everybody's have, and every read of this chunk's stage is done
-    frag_mma_e(f1, 0, hpart);
+    frag_mma_e(f1, 0);
 #ifdef TLN_V2_STAMPS
     const unsigned long long tb0 = __builtin_amdgcn_s_memtime();
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((STAGES - 2) * PIECES) : "memory");
@@ -405,7 +413,7 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
     V2_FENCE();
 #pragma unroll
     for (int e = 1; e < 4; ++e) {
-      frag_mma_e(f1, e, hpart);
+      frag_mma_e(f1, e);
       // the DMAs of chunk t + STAGES into this chunk's stage, a third behind each group; the first fragments of chunk t + 1
 #pragma unroll
       for (int piece = 0; piece < PIECES; ++piece)
@@ -420,28 +428,17 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
       for (int i = 0; i < TM; ++i) hi[i] = hin[i];
     }
   };
-  // (the stage of chunk t is t mod STAGES: the loop dispatches on it with one scalar branch per chunk)
-  auto run_chunk = [&](int t, int st, auto hpart) {
-    if (st == 0) chunk(t, std::integral_constant<int, 0>{}, hpart);
-    else if (st == 1 || STAGES == 2) chunk(t, std::integral_constant<int, 1>{}, hpart);
-    else chunk(t, std::integral_constant<int, STAGES - 1>{}, hpart);
-  };
-  int st = 0;
-  if constexpr (GRU) {
-    for (int t = 0; t < cpt; ++t, st = st == STAGES - 1 ? 0 : st + 1) run_chunk(t, st, std::false_type{});        // the channels of x
-    for (int t = cpt; t < nchunks; ++t, st = st == STAGES - 1 ? 0 : st + 1) run_chunk(t, st, std::true_type{});   // the channels of h
-  } else {
-    // STAGES chunks per trip, straight-line (a dispatch per chunk would meet in one loop head and pay ~50 register moves
-    // per chunk for it), then the one or two that are left
+  // STAGES chunks per trip, straight-line (a dispatch per chunk would meet in one loop head and pay ~50 register moves
+  // per chunk for it), then the one or two that are left
+  {
     int t = 0;
     for (; t + STAGES <= nchunks; t += STAGES) {
-      chunk(t, std::integral_constant<int, 0>{}, std::false_type{});
-      chunk(t + 1, std::integral_constant<int, 1>{}, std::false_type{});
-      if constexpr (STAGES == 3) chunk(t + 2, std::integral_constant<int, 2>{}, std::false_type{});
+      chunk(t, std::integral_constant<int, 0>{});
+      chunk(t + 1, std::integral_constant<int, 1>{});
+      if constexpr (STAGES == 3) chunk(t + 2, std::integral_constant<int, 2>{});
     }
-    if (t < nchunks) chunk(t, std::integral_constant<int, 0>{}, std::false_type{});
-    if (STAGES == 3 && t + 1 < nchunks) chunk(t + 1, std::integral_constant<int, 1>{}, std::false_type{});
-    (void)st;
+    if (t < nchunks) chunk(t, std::integral_constant<int, 0>{});
+    if (STAGES == 3 && t + 1 < nchunks) chunk(t + 1, std::integral_constant<int, 1>{});
   }
 #ifdef TLN_V2_STAMPS
   if (g.dbg && lane == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (blockIdx.x % 37) == 0) {   // a sample of blocks, every wave
@@ -483,7 +480,7 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
       // last bit — a lock-step group must compute exactly what its sequences compute alone
       const float rr = __frcp_rn(1.0f + __expf(-(acc[0][0][r] + br)));
       const float zz = __frcp_rn(1.0f + __expf(-(acc[0][1][r] + bz)));
-      const float na = fmaf(rr, acc[0][3][r] + bnh, acc[0][2][r] + bni);
+      const float na = fmaf(rr, acc[0][2][r] + bnh, acc[0][3][r] + bni);   // tile 3: gi_n (x's share, parked), tile 2: gh_n
       const float nn = fmaf(-2.0f, __frcp_rn(1.0f + __expf(2.0f * na)), 1.0f);
       const float hp = m < hrows ? hv[r] : 0.0f;
       if (m < g.M) g.out[m * g.ld_out + ch] = fmaf(zz, hp, __fmul_rn(1.0f - zz, nn));
