@@ -844,6 +844,7 @@ static int fill_src(SrcDev& d, const tln_gemm_src* s) {
   d.src = s->d_src;
   d.table = s->d_table;
   d.perm = nullptr;
+  d.order = nullptr;
   d.scale = s->d_scale;
   d.shift = s->d_shift;
   d.src_rows = s->src_rows;

@@ -8,6 +8,7 @@ struct SrcDev {
   const float* src;
   const int32_t* table;
   const int32_t* perm;   // optional row order of the product (source 0: rows with equal sets of present taps together)
+  const int32_t* order;  // optional launch order of the 128-row blocks of `perm` (heaviest first), gemm_v2 only
   const float* scale;
   const float* shift;
   int64_t src_rows, ld;
@@ -55,6 +56,7 @@ struct GemmArgsN {
 
 // lattice.hip: the row order that belongs to a tap table, if it was built for exactly `rows` rows
 const int32_t* tln_table_perm(const int32_t* table, int64_t rows);
+const int32_t* tln_table_tile_order(const int32_t* table, int64_t rows);
 
 // gemm_v2.hip: the large-M kernel (block tile 128 x N, operands staged by LDS-DMA).  tln_gemm_v2_ok decides from the
 // prepared arguments alone, so every route (operator call, frame program, lock-step group) takes the same kernel.

@@ -68,7 +68,8 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
   const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wv / WN, wn = wv % WN;
   const int l31 = lane & 31, half = lane >> 5;
-  const int64_t m0 = (int64_t)blockIdx.x * BM;
+  // (blocks start in index order: with a launch order the heaviest blocks — most taps present — come first)
+  const int64_t m0 = (int64_t)((BM == 128 && s.order) ? s.order[blockIdx.x] : (int)blockIdx.x) * BM;
   const int n0 = blockIdx.y * BN;
   const bool has_table = s.table != nullptr;
   const int src_rows = (int)s.src_rows;
@@ -625,6 +626,7 @@ static int launch_v2(GemmArgs& g, hipStream_t s) {
   dim3 grid((unsigned)tln_cdiv(g.M, BM), (unsigned)tln_cdiv(g.N, BN), 1);
   g.splits = 1;
   g.s[0].perm = v2_perm_of(g);
+  g.s[0].order = g.s[0].perm ? tln_table_tile_order(g.s[0].table, g.M) : nullptr;
   hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, s, g);
   return TLN_OK;
 }
@@ -708,6 +710,7 @@ static int launch_v2_multi(GemmArgs* g, int n, hipStream_t s) {
     gg.a[i] = g[i < n ? i : 0];
     gg.a[i].splits = 1;
     gg.a[i].s[0].perm = v2_perm_of(gg.a[i]);
+    gg.a[i].s[0].order = gg.a[i].s[0].perm ? tln_table_tile_order(gg.a[i].s[0].table, gg.a[i].M) : nullptr;
     if (i < n && g[i].M > mmax) mmax = g[i].M;
   }
   dim3 grid((unsigned)tln_cdiv(mmax, BM), (unsigned)tln_cdiv(g[0].N, BN), (unsigned)n);
