@@ -28,6 +28,7 @@ Prints ONE JSON line (rank 0) with `value` = clouds/sec of the whole job, plus
 """
 import argparse
 import contextlib
+import datetime
 import io
 import json
 import os
@@ -234,7 +235,10 @@ def main():
                     os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")      # rendezvous is on 127.0.0.1
                 group2 = None
                 for gi in range(plan2.nr_groups):                           # (collective: every rank creates every group)
-                    gr = dist.new_group(list(range(gi * plan2.group_size, (gi + 1) * plan2.group_size)), backend=x_backend)
+                    # (gloo: a collective of the side group that does not complete raises after 90 s instead of holding the
+                    #  job's line back for the default half hour; the point-to-point hand-offs have their own time-out)
+                    kw2 = {"timeout": datetime.timedelta(seconds=90)} if x_backend == "gloo" else {}
+                    gr = dist.new_group(list(range(gi * plan2.group_size, (gi + 1) * plan2.group_size)), backend=x_backend, **kw2)
                     if gi == plan2.group:
                         group2 = gr
                 fr2 = frames if plan2.group == 0 and rank == 0 else \

@@ -81,7 +81,10 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
   const int32_t* __restrict__ perm = s.perm;
   for (int r = tid; r < BM; r += NT) {
     const int64_t p = m0 + r;
-    Rid[r] = p < g.M ? (perm ? perm[p] : (int)p) : -1;
+    // (kept as the row's BYTE offset in the output — host: M * ld_out * 4 < 2^31, a residual has the output's row
+    //  stride —, a position past the end as INT_MIN: the epilogue's loads and stores are buffer operations whose range
+    //  check drops them, one add per element instead of a 64-bit multiply-add)
+    Rid[r] = p < g.M ? (perm ? perm[p] : (int)p) * ((int)g.ld_out * 4) : (int)0x80000000;
   }
   unsigned present = 0;                       // taps seen by this wave
   for (int i0 = 0; i0 < BM * taps; i0 += NT) {
@@ -464,17 +467,18 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
     // r, z: one bias for the sum; n: the two halves apart
     const float br = g.bias[ch] + g.bias2[ch], bz = g.bias[C + ch] + g.bias2[C + ch];
     const float bni = g.bias[2 * C + ch], bnh = g.bias2[2 * C + ch];
-    const int64_t mrow0 = m0 + wm * 32;
-    const int64_t hrows = g.s[1].src_rows;
+    // h' and h by buffer operations from the rows' byte offsets (h and h' have C columns: the same offsets): rows of h
+    // past its end read as zeros (the padding of lm:59-60), rows past M are not stored — both by the range check
+    const __amdgpu_buffer_rsrc_t rOut = __builtin_amdgcn_make_buffer_rsrc((void*)g.out, 0, (int)(g.M * g.ld_out * 4), RSRC3);
+    const int prow0 = wm * 32;
+    unsigned voff[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) voff[r] = (unsigned)Rid[prow0 + (r & 3) + 8 * (r >> 2) + 4 * half] + 4u * (unsigned)ch;
     float hv[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {   // every load from a clamped (always valid) address, before the arithmetic
-      const int64_t m = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      hv[r] = g.s[1].src[(m < hrows ? m : 0) * s.ld + ch];
-    }
+    for (int r = 0; r < 16; ++r) hv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rA1, voff[r], 0, 0));
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int64_t m = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * half;
       // (hardware exp2 / reciprocal: 1-2 ulp, far inside the 1e-4 the outputs are held to; tanh(x) = 1 - 2 / (1 + e^2x))
       // every multiply-add spelled out as ONE fused operation: left to the compiler's contraction, the single-cell and the
       // batched instantiation of this body (k_gather_gemm_v2_gru / _gru_multi) fused different ones and differed in the
@@ -483,12 +487,15 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
       const float zz = __frcp_rn(1.0f + __expf(-(acc[0][1][r] + bz)));
       const float na = fmaf(rr, acc[0][2][r] + bnh, acc[0][3][r] + bni);   // tile 3: gi_n (x's share, parked), tile 2: gh_n
       const float nn = fmaf(-2.0f, __frcp_rn(1.0f + __expf(2.0f * na)), 1.0f);
-      const float hp = m < hrows ? hv[r] : 0.0f;
-      if (m < g.M) g.out[m * g.ld_out + ch] = fmaf(zz, hp, __fmul_rn(1.0f - zz, nn));
+      const float hn = fmaf(zz, hv[r], __fmul_rn(1.0f - zz, nn));
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, hn), rOut, voff[r], 0, 0);
     }
     return;
   }
   const bool has_res = g.res != nullptr;
+  const __amdgpu_buffer_rsrc_t rOut = __builtin_amdgcn_make_buffer_rsrc((void*)g.out, 0, (int)(g.M * g.ld_out * 4), RSRC3);
+  const __amdgpu_buffer_rsrc_t rRes = __builtin_amdgcn_make_buffer_rsrc((void*)(has_res ? g.res : g.out), 0, (int)(g.M * g.ld_out * 4), RSRC3);
+  const bool partial_cols = g.N % BN != 0;   // (uniform; only then a lane can sit on a column past N)
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -499,24 +506,40 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
       const float bias = g.bias ? g.bias[nc] : 0.f;
       const int prow0 = wm * 32 * TM + i * 32;           // block position of the tile's first row
       const int64_t mrow0 = m0 + prow0;
-      int rid[16];                                       // the rows behind the 16 positions (-1: past the end)
+      unsigned voff[16];                                 // byte offsets of the 16 outputs (past the end: out of range)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) rid[r] = Rid[prow0 + (r & 3) + 8 * (r >> 2) + 4 * half];
+      for (int r = 0; r < 16; ++r) voff[r] = (unsigned)Rid[prow0 + (r & 3) + 8 * (r >> 2) + 4 * half] + 4u * (unsigned)n;
+      if (partial_cols) {   // (uniform: skipped by every product whose N is a multiple of the block's columns)
+        if (!ncol) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) voff[r] = 0x80000000u;
+        }
+      }
       float rv[16];
       if (has_res) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) rv[r] = g.res[(int64_t)(rid[r] >= 0 ? rid[r] : 0) * g.ld_res + nc];
+        for (int r = 0; r < 16; ++r) rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rRes, voff[r], 0, 0));
+      }
+      // (residual and ReLU under uniform branches around whole loops: inside one loop the compiler computes both
+      //  alternatives and selects per element)
+      float vv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) vv[r] = acc[i][j][r] + bias;
+      if (has_res) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) vv[r] += rv[r];
+      }
+      if (g.relu) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) vv[r] = fmaxf(vv[r], 0.f);
       }
       double s1 = 0.0, s2 = 0.0;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int64_t m = rid[r];
-        const bool ok = ncol && m >= 0;
-        float v = acc[i][j][r] + bias;
-        if (has_res) v += rv[r];
-        if (g.relu) v = fmaxf(v, 0.f);
-        if (ok) g.out[m * g.ld_out + n] = v;
-        const double dv = ok ? (double)v : 0.0;
+        const bool ok = (int)voff[r] >= 0;
+        const float v = vv[r];
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rOut, voff[r], 0, 0);
+        const double dv = (double)(ok ? v : 0.0f);   // (one select on the float, not two on the double)
         s1 += dv;
         s2 += dv * dv;
       }
@@ -572,7 +595,8 @@ extern "C" void tln_gemm_v2_config(int off, int64_t min_m) {
 static bool v2_bytes_ok(const GemmArgs& g) {
   const SrcDev& s = g.s[0];
   const int64_t lim = (1ll << 31) - 4096;
-  return s.src_rows * s.ld * 4 < lim && ((int64_t)s.taps * s.cin + g.N) * g.ldw * 4 < lim;
+  if (g.res && g.ld_res != g.ld_out) return false;     // (the epilogue addresses residual and output by one offset)
+  return s.src_rows * s.ld * 4 < lim && ((int64_t)s.taps * s.cin + g.N) * g.ldw * 4 < lim && g.M * g.ld_out * 4 < lim;
 }
 
 bool tln_gemm_v2_ok(const GemmArgs& g, bool w_is_nk, bool vec) {
