@@ -235,22 +235,30 @@ class FrameShardRunner:
             self._hooks.append(mod.register_forward_pre_hook(self._make_pre(slot)))
             self._hooks.append(mod.register_forward_hook(self._make_post(slot)))
 
+    def _recv_state(self, sid):
+        """hidden state `sid` from the owner of the previous frame (None: it has none yet).  The transport: ranks of a
+        process group here; pipeline.FramePipeline overrides both ends with in-process queues + stream events"""
+        dev = "cpu" if self.via_host else "cuda"
+        h = recv_tensor(self.plan.prev_rank, dev, tag=sid, group=self.group)
+        return h.to("cuda") if h.numel() else None
+
+    def _send_state(self, sid, t):
+        """hidden state `sid` (a device tensor, or None) to the owner of the next frame"""
+        if t is None:
+            t = torch.zeros(0, device="cuda")
+        send_tensor(t.cpu() if self.via_host else t, self.plan.next_rank, tag=sid, group=self.group)
+
     def _make_pre(self, slot):
         def pre(mod, args):
             if self._recv_now and self.plan.prev_rank is not None:
-                dev = "cpu" if self.via_host else args[0].device
-                h = recv_tensor(self.plan.prev_rank, dev, tag=slot, group=self.group)
-                mod.h_lv = h.to(args[0].device) if h.numel() else None
+                mod.h_lv = self._recv_state(slot)
             return None
         return pre
 
     def _make_post(self, slot):
         def post(mod, args, out):
             if self._send_now and self.plan.next_rank is not None:
-                h = mod.h_lv
-                if h is None:
-                    h = torch.zeros(0, device=args[0].device)
-                send_tensor(h.cpu() if self.via_host else h, self.plan.next_rank, tag=slot, group=self.group)
+                self._send_state(slot, mod.h_lv)
             return None
         return post
 
@@ -328,16 +336,8 @@ class FrameShardRunner:
                 lvl = lvl.coarsen()
                 expect.append(lvl.nr_lattice_vertices())
 
-        def recv(sid):
-            dev = "cpu" if self.via_host else "cuda"
-            h = recv_tensor(self.plan.prev_rank, dev, tag=sid, group=self.group)
-            return h.to("cuda") if h.numel() else None
-
-        def send(sid, t):
-            send_tensor(t.cpu() if self.via_host else t, self.plan.next_rank, tag=sid, group=self.group)
-
-        raw, lat = prog.run_frame_sharded(lat, pos, val, f == 0, early, recv if recv_now else None,
-                                          send if send_now else None, expect)
+        raw, lat = prog.run_frame_sharded(lat, pos, val, f == 0, early, self._recv_state if recv_now else None,
+                                          self._send_state if send_now else None, expect)
         model.first_sequence = False
         model._program_active = True
         if early and prog.stop_shape is not None:
