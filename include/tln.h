@@ -241,7 +241,9 @@ void tln_gemm_force_splits(int splits, int wm);
  * 1 = whenever the shape is eligible (channels multiple of 32, aligned), -1 = never */
 void tln_gemm_force_direct(int mode);
 /* tuning hook: the large-M kernel (csrc/gemm_v2.hip: 128-row block tiles, operands staged once per block by LDS-DMA):
- * off != 0 switches it off; min_m > 0 sets the smallest M that takes it (default 12288) */
+ * off: bit 0 switches it off, bit 2 the row orders / tap skipping, bit 3 = 64-row tiles for every shared 128-column
+ * launch with the GroupNorm prologue, bit 4 = never (default: where they save a round of blocks); min_m > 0 sets the
+ * smallest M that takes it (default 12288) */
 void tln_gemm_v2_config(int off, int64_t min_m);
 /* diagnostic hook: block (0,0,0) of every following gather-GEMM writes five s_memtime stamps (start, after the
  * index/GroupNorm prologue, after the K loop, after the reductions, end) to d_buf (5 x u64); NULL switches it off */

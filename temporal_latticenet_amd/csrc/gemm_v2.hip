@@ -766,6 +766,19 @@ static int dispatch_v2_multi(GemmArgs* g, int n, hipStream_t s) {
       const double t96 = (double)tln_cdiv(w96 * cb, v2_cu_count()) * 0.78;   // 0.75 of the rows + the fixed cost per workgroup
       if ((v2_two_stage() & 1) && (env == 1 || (env != 0 && t96 < t128)))
         return launch_v2_multi<3, 2, 1, 2, W_NK, PRO, 2>(g, n, s);
+      // 64-row tiles of four waves (2 x 2, the same 32 x 64 per wave, three workgroups per CU): half the quantum of a
+      // CU's time.  Where the 128-row count lands just above a multiple of the CU count (532 tiles: "3 per CU" for 2.08)
+      // the launch takes 5 half-rounds instead of 3 whole ones.  MEASURED (4 streams x 8): the replay of a group's
+      // products alone 113.4 -> 114.9 TFLOP/s by this model, the timed mode unchanged (1452 either way: the other streams
+      // fill the idle CUs of a last round already).  On by the model (TLN_V2_BM64 / tln_gemm_v2_config bits 8, 16: 1 /
+      // bit 8 always, 0 / bit 16 never)
+      static const int env64 = getenv("TLN_V2_BM64") ? atoi(getenv("TLN_V2_BM64")) : -1;
+      const int mode64 = (g_v2_off & 8) ? 1 : ((g_v2_off & 16) ? 0 : env64);
+      int64_t w64 = 0;
+      for (int i = 0; i < n; ++i) w64 += tln_cdiv(g[i].M, 64);
+      const double t64 = (double)tln_cdiv(w64 * cb, v2_cu_count()) * 0.53;
+      if ((v2_two_stage() & 1) && (mode64 == 1 || (mode64 != 0 && t64 < t128)))
+        return launch_v2_multi<2, 2, 1, 2, W_NK, PRO, 2>(g, n, s);
     }
     return (v2_two_stage() & 1) ? launch_v2_multi<4, 2, 1, 2, W_NK, PRO, 2>(g, n, s) : launch_v2_multi<4, 2, 1, 2, W_NK, PRO>(g, n, s);
   }

@@ -184,6 +184,19 @@ def test_v2_takes_products_whose_rows_only_together_are_large(gpu, lattice, cin,
         outs.append(out)
     _lib.check(lib.tln_gather_gemm_multi(calls, nprod, stream_ptr()), "tln_gather_gemm_multi")
     torch.cuda.synchronize()
+    if cout == 128 and pro and not nk:
+        # the same shared launch on 64-row tiles (the launch geometry's other choice for this shape class): no bit changes
+        first = [o.clone() for o in outs]
+        for o in outs:
+            o.fill_(float("nan"))
+        lib.tln_gemm_v2_config(8, 12288)
+        try:
+            _lib.check(lib.tln_gather_gemm_multi(calls, nprod, stream_ptr()), "tln_gather_gemm_multi")
+            torch.cuda.synchronize()
+        finally:
+            lib.tln_gemm_v2_config(0, 12288)
+        for i in range(nprod):
+            assert torch.equal(outs[i], first[i]), "64-row tiles, product %d" % i
     lib.tln_gemm_v2_config(0, 1)                           # the same products one by one through gemm_v2
     try:
         for i in range(nprod):
