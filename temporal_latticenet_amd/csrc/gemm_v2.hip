@@ -557,15 +557,17 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gather_gemm_v2(const GemmArgs 
   v2_body<WM, WN, TM, TN, W_NK, PRO, false, STAGES>(g);
 }
 
+template <int STAGES>
 __global__ void __launch_bounds__(512) k_gather_gemm_v2_gru(const GemmArgs g) {
-  v2_body<4, 2, 1, 3, true, false, true>(g);
+  v2_body<4, 2, 1, 3, true, false, true, STAGES>(g);
 }
 
 // the GRU cells of lock-stepped sequences in one launch (blockIdx.z = sequence; same weights, own x / h / out)
+template <int STAGES>
 __global__ void __launch_bounds__(512) k_gather_gemm_v2_gru_multi(const GemmArgsN<TLN_GEMM_MULTI_MAX> gg) {
   const GemmArgs& g = gg.a[blockIdx.z];
   if ((int64_t)blockIdx.x * 128 >= g.M) return;   // (the grid is sized for the largest lattice)
-  v2_body<4, 2, 1, 3, true, false, true>(g);
+  v2_body<4, 2, 1, 3, true, false, true, STAGES>(g);
 }
 
 // several products of one shape class in one launch (blockIdx.z = product): the coarse levels of lock-stepped
@@ -623,12 +625,16 @@ static const int32_t* v2_perm_of(const GemmArgs& g) {
   return tln_table_perm(s.table, g.M);
 }
 
-// which tiles run with a ring of TWO stages (bit 0: 128 x 128, bit 1: 128 x 64; TLN_V2_STAGES2, default both): the DMAs
-// run one chunk ahead instead of two, but the workgroup needs 69 / 53 KB of LDS instead of 101 / 77 and two / three of
-// them share a CU — measured +1.6 % clouds/s together (the 128 x 192 tile stays at three stages: 86 KB with two, still
-// one workgroup per CU)
+// which tiles run with a ring of TWO stages (bit 0: 128 x 128, bit 1: 128 x 64, bit 2: 128 x 192, bit 3: the GRU cell;
+// TLN_V2_STAGES2, default all): the DMAs run one chunk ahead instead of two, but the workgroup needs 69 / 53 KB of LDS
+// instead of 101 / 77 and two / three of them share a CU — measured +1.6 % clouds/s together.  The 128 x 192 tile and the
+// GRU cell are alone on their CU either way (86 KB with two stages, 120 with three) as long as only their own launch
+// runs — but with four streams in flight a 120 KB workgroup keeps every other stream's 53 / 69 KB workgroups off its CU
+// and waits for a CU that is empty: with two stages they share (round 3: 1433 -> 1460 clouds/s at 4 x 8, nothing for a
+// sequence alone; since the chunk barrier moved into the chunk's last step the DMAs of a two-stage ring still lead by
+// a whole chunk)
 static int v2_two_stage() {
-  static const int v = getenv("TLN_V2_STAGES2") ? atoi(getenv("TLN_V2_STAGES2")) : 3;
+  static const int v = getenv("TLN_V2_STAGES2") ? atoi(getenv("TLN_V2_STAGES2")) : 15;
   return v;
 }
 
@@ -662,7 +668,8 @@ static int dispatch_v2(GemmArgs& g, hipStream_t s) {
   // faster than four waves of twice the tile on every shape of the workload (TLN_V2_WAVES=4 brings those back)
   static const int waves = getenv("TLN_V2_WAVES") ? atoi(getenv("TLN_V2_WAVES")) : 8;
   if (waves == 8) {
-    if (n % 192 == 0) return launch_v2<4, 2, 1, 3, W_NK, PRO>(g, s);   // 128 x 192, 8 waves of 32 x 96
+    if (n % 192 == 0)   // 128 x 192, 8 waves of 32 x 96
+      return (v2_two_stage() & 4) ? launch_v2<4, 2, 1, 3, W_NK, PRO, 2>(g, s) : launch_v2<4, 2, 1, 3, W_NK, PRO>(g, s);
     if (n % 128 == 0) {   // 128 x 128, 8 waves of 32 x 64
       return (v2_two_stage() & 1) ? launch_v2<4, 2, 1, 2, W_NK, PRO, 2>(g, s) : launch_v2<4, 2, 1, 2, W_NK, PRO>(g, s);
     }
@@ -745,7 +752,8 @@ static int launch_v2_multi(GemmArgs* g, int n, hipStream_t s) {
 template <bool W_NK, bool PRO>
 static int dispatch_v2_multi(GemmArgs* g, int n, hipStream_t s) {
   const int nn = g[0].N;
-  if (nn % 192 == 0) return launch_v2_multi<4, 2, 1, 3, W_NK, PRO>(g, n, s);
+  if (nn % 192 == 0)
+    return (v2_two_stage() & 4) ? launch_v2_multi<4, 2, 1, 3, W_NK, PRO, 2>(g, n, s) : launch_v2_multi<4, 2, 1, 3, W_NK, PRO>(g, n, s);
   if (nn % 128 == 0) {
     // Tile height against the quantisation of the launch: two workgroups of this tile share a CU, and a CU's time is
     // (workgroups it gets) x (rows per workgroup).  The lock-stepped level-1 products have 52k-72k rows together — 407 to
@@ -831,11 +839,18 @@ int tln_gemm_v2_launch_gru(const float* d_x, const float* d_h, int64_t Vh, int64
   GemmArgs g;
   v2_gru_args(g, d_x, d_h, Vh, V, C, d_w_ih, d_w_hh, d_b_ih, d_b_hh, d_out);
   constexpr int BM = 128, BN = 192;
-  const size_t lds = (size_t)V2_STAGES * (BM + BN) * 128 + (size_t)BM * TLN_TAPS * 4 + (size_t)2 * C * 4 + (size_t)(BM + 32) * 4;
-  static thread_local TlnLdsAttr attr;
-  TLN_HIP(tln_set_max_lds(attr, reinterpret_cast<const void*>(k_gather_gemm_v2_gru), (int)lds));
+  const bool two = (v2_two_stage() & 8) != 0;
+  const size_t lds = (size_t)(two ? 2 : 3) * (BM + BN) * 128 + (size_t)BM * TLN_TAPS * 4 + (size_t)2 * C * 4 + (size_t)(BM + 32) * 4;
   dim3 grid((unsigned)tln_cdiv(V, BM), (unsigned)(3 * C / BN), 1);
-  hipLaunchKernelGGL(k_gather_gemm_v2_gru, grid, dim3(512), lds, s, g);
+  if (two) {
+    static thread_local TlnLdsAttr attr2;
+    TLN_HIP(tln_set_max_lds(attr2, reinterpret_cast<const void*>(k_gather_gemm_v2_gru<2>), (int)lds));
+    hipLaunchKernelGGL(k_gather_gemm_v2_gru<2>, grid, dim3(512), lds, s, g);
+  } else {
+    static thread_local TlnLdsAttr attr;
+    TLN_HIP(tln_set_max_lds(attr, reinterpret_cast<const void*>(k_gather_gemm_v2_gru<3>), (int)lds));
+    hipLaunchKernelGGL(k_gather_gemm_v2_gru<3>, grid, dim3(512), lds, s, g);
+  }
   return TLN_OK;
 }
 
@@ -851,11 +866,18 @@ int tln_gemm_v2_launch_gru_multi(int n, const float* const* d_x, const float* co
     if (i < n && V[k] > vmax) vmax = V[k];
   }
   constexpr int BM = 128, BN = 192;
-  const size_t lds = (size_t)V2_STAGES * (BM + BN) * 128 + (size_t)BM * TLN_TAPS * 4 + (size_t)2 * C * 4 + (size_t)(BM + 32) * 4;
-  static thread_local TlnLdsAttr attr;
-  TLN_HIP(tln_set_max_lds(attr, reinterpret_cast<const void*>(k_gather_gemm_v2_gru_multi), (int)lds));
+  const bool two = (v2_two_stage() & 8) != 0;
+  const size_t lds = (size_t)(two ? 2 : 3) * (BM + BN) * 128 + (size_t)BM * TLN_TAPS * 4 + (size_t)2 * C * 4 + (size_t)(BM + 32) * 4;
   dim3 grid((unsigned)tln_cdiv(vmax, BM), (unsigned)(3 * C / BN), (unsigned)n);
-  hipLaunchKernelGGL(k_gather_gemm_v2_gru_multi, grid, dim3(512), lds, s, gg);
+  if (two) {
+    static thread_local TlnLdsAttr attr2;
+    TLN_HIP(tln_set_max_lds(attr2, reinterpret_cast<const void*>(k_gather_gemm_v2_gru_multi<2>), (int)lds));
+    hipLaunchKernelGGL(k_gather_gemm_v2_gru_multi<2>, grid, dim3(512), lds, s, gg);
+  } else {
+    static thread_local TlnLdsAttr attr;
+    TLN_HIP(tln_set_max_lds(attr, reinterpret_cast<const void*>(k_gather_gemm_v2_gru_multi<3>), (int)lds));
+    hipLaunchKernelGGL(k_gather_gemm_v2_gru_multi<3>, grid, dim3(512), lds, s, gg);
+  }
   return TLN_OK;
 }
 
