@@ -246,3 +246,21 @@ def test_row_order_by_present_taps_changes_no_bit(gpu, lattice, v2_forced, cin, 
     assert torch.equal(with_order, plain)
     a, b = with_order._tln_stats.double().sum(0), plain._tln_stats.double().sum(0)
     np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-10, atol=1e-7)
+
+
+def test_products_past_the_buffer_range_take_the_other_kernels(gpu):
+    """The large-M kernel addresses source, weights and output through 32-bit buffer offsets (2 GiB each).  A product
+    whose source is larger than that must not take it: 8.5M rows x 64 channels = 2.18 GB through a 1x1 product against
+    torch on a sample of rows (the kernels with 64-bit addressing compute it)."""
+    from temporal_latticenet_amd import ops
+    M, cin, cout = 8_500_000, 64, 64
+    g = torch.Generator(device=gpu).manual_seed(5)
+    x = torch.randn(M, cin, device=gpu, generator=g)
+    assert x.numel() * 4 > (1 << 31)
+    W = torch.randn(cin, cout, device=gpu, generator=g) / 8.0
+    out = ops.gather_gemm(M, W, ops.gemm_src(x))
+    torch.cuda.synchronize()
+    rows = torch.cat([torch.arange(0, 4096, device=gpu), torch.arange(M - 4096, M, device=gpu),
+                      torch.randint(0, M, (8192,), device=gpu, generator=g)])
+    want = x[rows].double() @ W.double()
+    np.testing.assert_allclose(out[rows].cpu().numpy(), want.float().cpu().numpy(), rtol=1e-4, atol=1e-4)
