@@ -6,27 +6,32 @@
 // (one wave per 32x32 tile) gathers every source row N/32 times and the 64x64-tile kernel N/64 times, each wave
 // through its own vector-memory path: the gather, not the matrix pipe, sets their pace (80 / 62 TFLOP/s on
 // 192 -> 192).  Here a block owns 128 rows x ALL its columns (up to 192 per block):
-//   * A (gathered rows) and B (weights) are staged ONCE per block and K chunk by LDS-DMA (`global_load_lds_dwordx4`,
-//     16 B per lane, no VGPR round trip): A as 128-byte row pieces [BM][32 floats] whose 16-byte slots are
-//     XOR-swizzled with the row ((row>>1)&7, applied on the SOURCE address since the DMA image is lane-linear), so
-//     that the operand reads are conflict-free `ds_read_b128`; B as [32][BN] ([K,N] weights, `ds_read_b32`) or as
-//     [BN][32] ([N,K] weights, like A);
-//   * a ring of three LDS stages, loads two chunks ahead, ONE barrier per chunk: `s_waitcnt vmcnt(pieces)` (the
-//     next chunk's DMAs stay in flight) -> `s_barrier` -> issue chunk t+2 -> multiply chunk t;
-//   * eight waves as 4 x 2 (four as 4 x 1 for narrow N), each 32 x 96 / 32 x 64 / 32 x 32 outputs; the k order inside a
-//     chunk is permuted (lane half h takes k = 8j + 4h + e), identically for A and B, so one b128 read feeds 4 MFMAs;
-//   * the GroupNorm affine + ReLU of the consumer side (GN -> ReLU -> conv) is applied when a fragment is read, a
-//     missing neighbour stays an exact zero row: fma, then ONE v_med3_f32 that clamps to [0, inf) or to [0, 0]; the
-//     scale / shift of a step arrive with its fragments, the clamp bound of a lane's rows a chunk ahead;
-//   * epilogue as in gemm.hip: bias, residual, ReLU, per-32-row (sum, sum^2) in fp64 for the next GroupNorm.
+//   * A (gathered rows) and B (weights) are staged ONCE per block and K chunk by LDS-DMA (`buffer_load_dwordx4 ... lds`,
+//     16 B per lane, no VGPR round trip; a piece's address = buffer descriptor + one 32-bit lane offset + a scalar
+//     offset, a missing neighbour = an offset out of the buffer's range, whose check writes the zero row): A as 128-byte
+//     row pieces [BM][32 floats] whose 16-byte slots are XOR-swizzled with the row ((row>>1)&7, applied on the SOURCE
+//     offset since the DMA image is lane-linear), so that the operand reads are conflict-free `ds_read_b128`; B as
+//     [32][BN] ([K,N] weights, `ds_read_b32`) or as [BN][32] ([N,K] weights, like A);
+//   * a ring of two LDS stages (three by TLN_V2_STAGES2), ONE barrier per chunk, behind the first MFMA group of the
+//     chunk's last step: `s_waitcnt vmcnt` (this thread's DMAs of the next chunk landed) -> `s_barrier` -> the DMAs of
+//     chunk t + STAGES into this chunk's stage, the first fragments of chunk t + 1 under the remaining MFMAs;
+//   * eight waves as 4 x 2 (four as 4 x 1 for narrow N, 2 x 2 on 64-row tiles), each 32 x 96 / 32 x 64 / 32 x 32
+//     outputs; the k order inside a chunk is permuted (lane half h takes k = 8j + 4h + e), identically for A and B, so
+//     one b128 read feeds 4 MFMAs;
+//   * the K loop is built for `64 cycles per MFMA + ~3 per vector instruction` (tools/micro/mfma_rate.hip: nothing hides
+//     in an fp32 MFMA's shadow): scheduled by hand in groups behind scheduling fences, every LDS address a base register
+//     + immediate (chunk body instantiated per ring stage), 44 vector instructions per 48 MFMAs;
+//   * the GroupNorm affine + ReLU of the consumer side (GN -> ReLU -> conv) is applied to the NEXT step's fragments behind
+//     the current step's last MFMA group, a missing neighbour stays an exact zero row: fma, then ONE v_med3_f32 that
+//     clamps to [0, inf) or to [0, 0];
+//   * epilogue: bias, residual, ReLU by buffer loads / stores from the rows' byte offsets, per-32-row (sum, sum^2) in
+//     fp64 for the next GroupNorm.
 // One source only (the two-source products live on small levels); rows past the source read as zeros (pad = 0).
 #include "gemm_args.h"
 #include <stdlib.h>
 #include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __attribute__((aligned(16))) float g_v2_zero[4] = {0.f, 0.f, 0.f, 0.f};
 
 #define V2_STAGES 3
 
@@ -46,7 +51,7 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
   constexpr int NT = 64 * WM * WN;
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
   // (B: a thread count that does not divide the 16-byte pieces of the weight tile — the 96-row tile's 384 threads on a
-  // 128-column tile — rounds the pieces per thread up; the surplus pieces copy the zero buffer into slack behind the tile)
+  // 128-column tile — rounds the pieces per thread up; the surplus pieces read out of the buffer's range: zeros into slack behind the tile)
   constexpr int A_PIECES = BM * 8 / NT, B_PIECES = (BN * 8 + NT - 1) / NT;
   constexpr bool B_PAD = (BN * 8) % NT != 0;
   constexpr int A_BYTES = BM * 128, B_BYTES = B_PIECES * NT * 16;
