@@ -464,6 +464,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <bool W_NK>
 __device__ __forceinline__ void direct_body(const GemmArgs& g) {
+#if __HIP_DEVICE_COMPILE__   // (the buffer-resource type of the operand loads exists in the device pass only)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int T = blockDim.x, G = T >> 6;
   // the wave index as a SCALAR: everything derived from it (chunk, tap, channel offset, K row, source selection) then
@@ -579,13 +580,22 @@ __device__ __forceinline__ void direct_body(const GemmArgs& g) {
   const int rows0 = (int)g.s[0].src_rows, rows1 = g.nsrc > 1 ? (int)g.s[1].src_rows : 0;
   const unsigned ld0 = (unsigned)g.s[0].ld, ld1 = g.nsrc > 1 ? (unsigned)g.s[1].ld : 0u;
 
+  // The operands come by buffer loads (round 3): address = buffer descriptor + ONE 32-bit lane offset + a scalar offset +
+  // an immediate — the flat-address version spent a 64-bit add per load (36 of the loop's 155 vector instructions for two
+  // chunks, and as many in front of the loop, where twelve waves per CU issue their first forty loads: the kernel's
+  // prologue was as long as its K loop).  Sources and weights below 2 GiB each (host: direct_ok).
+  const unsigned RSRC3 = 0x00020000u;
+  const __amdgpu_buffer_rsrc_t rA0 = __builtin_amdgcn_make_buffer_rsrc((void*)g.s[0].src, 0, (int)(g.s[0].src_rows * g.s[0].ld * 4), RSRC3);
+  const __amdgpu_buffer_rsrc_t rA1 = g.nsrc > 1 ? __builtin_amdgcn_make_buffer_rsrc((void*)g.s[1].src, 0, (int)(g.s[1].src_rows * g.s[1].ld * 4), RSRC3) : rA0;
+  const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)g.W, 0, (int)((W_NK ? (int64_t)g.N : (int64_t)(g.K0 + (g.nsrc > 1 ? g.s[1].taps * g.s[1].cin : 0))) * g.ldw * 4), RSRC3);
+  const unsigned wnk_loff = 4u * (nc * (unsigned)g.ldw + 4u * (unsigned)half);   // [N,K] weights: the lane's fixed byte offset
   // where chunk t lives: branch-free, every address is clamped into range, the mode decides afterwards what the
   // values mean
   struct Chunk {
-    const f32x4* ap;   // the lane's 16 channels of its gathered row
-    const char* wq;    // [K,N] weights: wave-uniform pointer to the chunk's first K row
-    const f32x4* wp;   // [N,K] weights: the lane's 16 K values of its column
-    int mode, sm;
+    unsigned avoff;    // byte offset of the lane's gathered row (+ its half's 16 bytes) in its source
+    int asoff;         // scalar: the chunk's first channel, in bytes
+    int wsoff;         // scalar: [K,N] weights: byte offset of the chunk's first K row; [N,K]: of its first K column
+    int si, mode, sm;
   };
   auto locate = [&](int t_raw) {
     Chunk c;
@@ -606,29 +616,37 @@ __device__ __forceinline__ void direct_body(const GemmArgs& g) {
     if (has_table) srow = Is[si * (32 * TLN_TAPS) + l31 * TLN_TAPS + tap];
     c.mode = (!live || srow < 0) ? 0 : (srow >= src_rows ? 2 : 1);
     c.sm = si | (c0 << 1);
+    c.si = si;
     const unsigned sr = c.mode == 1 ? (unsigned)srow : 0u;
-    c.ap = reinterpret_cast<const f32x4*>(src + (uint64_t)sr * ld + (unsigned)(c0 + 4 * half));
-    c.wq = reinterpret_cast<const char*>(g.W + (int64_t)kb * g.ldw);
-    c.wp = reinterpret_cast<const f32x4*>(g.W + (int64_t)nc * g.ldw + kb + 4 * half);
+    (void)src;
+    c.avoff = 4u * (sr * ld + 4u * (unsigned)half);
+    c.asoff = 4 * c0;
+    c.wsoff = W_NK ? 4 * kb : 4 * kb * (int)g.ldw;
     return c;
   };
-  // [K,N] weights: K row q of the chunk; the lane's part is a fixed 32-bit byte offset on a wave-uniform row pointer
+  auto load_a = [&](const Chunk& c, int q) {   // 16 bytes: channels c0 + 8 q + 4 half ..
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(c.si ? rA1 : rA0, c.avoff, c.asoff + 32 * q, 0));
+  };
+  // [K,N] weights: K row q of the chunk; the lane's part is a fixed 32-bit byte offset, the row a scalar one
   auto load_b_kn = [&](const Chunk& c, int q) {
-    return *reinterpret_cast<const float*>(c.wq + (int64_t)(8 * (q >> 2) + (q & 3)) * g.ldw * 4 + b_loff);   // k = 8j + 4h + e
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rW, b_loff, c.wsoff + (8 * (q >> 2) + (q & 3)) * (int)g.ldw * 4, 0));   // k = 8j + 4h + e
+  };
+  auto load_b_nk = [&](const Chunk& c, int q) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rW, wnk_loff, c.wsoff + 32 * q, 0));
   };
   auto load = [&](int t_raw, f32x4 (&av)[4], float (&bv)[16], int& md, int& sm) {
     const Chunk c = locate(t_raw);
     md = c.mode;
     sm = c.sm;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) av[q] = c.ap[2 * q];
+    for (int q = 0; q < 4; ++q) av[q] = load_a(c, q);
     if (!W_NK) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) bv[q] = load_b_kn(c, q);
     } else {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const f32x4 v = c.wp[2 * q];
+        const f32x4 v = load_b_nk(c, q);
         bv[4 * q] = v[0];
         bv[4 * q + 1] = v[1];
         bv[4 * q + 2] = v[2];
@@ -689,14 +707,14 @@ __device__ __forceinline__ void direct_body(const GemmArgs& g) {
     prepare(av, md, sm, x);
     const Chunk c = locate(t_next);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) av[q] = c.ap[2 * q];
+    for (int q = 0; q < 4; ++q) av[q] = load_a(c, q);
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x[q], bv[q], acc, 0, 0, 0);
       if (!W_NK) {
         bv[q] = load_b_kn(c, q);
       } else if ((q & 3) == 3) {
-        const f32x4 v = c.wp[2 * (q >> 2)];
+        const f32x4 v = load_b_nk(c, q >> 2);
         bv[q - 3] = v[0];
         bv[q - 2] = v[1];
         bv[q - 1] = v[2];
@@ -809,6 +827,7 @@ __device__ __forceinline__ void direct_body(const GemmArgs& g) {
     }
   }
   if (stamp) g.dbg[4] = __builtin_amdgcn_s_memtime();
+#endif
 }
 
 template <bool W_NK>
@@ -1102,11 +1121,13 @@ static int prepare_gemm(int64_t M, int N, const tln_gemm_src* s0, const tln_gemm
   for (int i = 0; i < g.nsrc; ++i) q.nchunks += g.s[i].taps * ((g.s[i].cin + bk - 1) / bk);
   q.p = make_plan(M, N, q.nchunks);
   // small M: one wave per 32x32 tile and K subset, operands straight from global memory
+  const int64_t lim2g = (1ll << 31) - 4096;   // (the direct kernel addresses sources and weights by 32-bit buffer offsets)
   bool direct_ok = vec && q.bk32 && g.s[0].cin <= 1024 && tln_cdiv(N, 32) <= 65535 && M < (1ll << 31) &&
+                   ((int64_t)K + N) * g.ldw * 4 < lim2g &&
                    (int64_t)g.ldw * 17 + N < (1ll << 29);  // 32-bit rows and byte offsets in that kernel
   for (int i = 0; i < g.nsrc; ++i) {
     const SrcDev& d = g.s[i];
-    direct_ok = direct_ok && d.src_rows >= 1 && d.src_rows < (1ll << 31) && d.ld < (1ll << 31) &&
+    direct_ok = direct_ok && d.src_rows >= 1 && d.src_rows < (1ll << 31) && d.ld < (1ll << 31) && d.src_rows * d.ld * 4 < lim2g &&
                 (d.table == nullptr || d.taps == TLN_TAPS);
     if (i > 0) direct_ok = direct_ok && d.scale == nullptr;  // only source 0 carries a prologue there
   }
