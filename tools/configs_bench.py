@@ -36,12 +36,12 @@ def model_config(name, points, frames, rnn, seq_learning, sigma, capacity, steps
     res = {}
     # the pair mode gets a process of its own (argv[2] == "pairs"): streams created after two earlier pools land on
     # hardware queues that share compute pipes, which costs it 30 %
-    runs = ((4, True),) if PAIRS_ONLY else ((1, False), (4, False))
+    runs = ((4, 8),) if PAIRS_ONLY else ((1, False), (4, False))
     for S, pairs in runs:
         with quiet():
             pool = SequenceStreams(model, lambda: build_model(contents).eval(), lambda: make_lattice(contents), seq, S,
                                    pairs=pairs)
-        per = 2 if pairs else 1          # sequences per stream and step
+        per = int(pairs) if pairs else 1          # sequences per stream and step (lock-stepped)
         pool.run([[seq] * (2 * per) for _ in range(S)])
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -53,7 +53,7 @@ def model_config(name, points, frames, rnn, seq_learning, sigma, capacity, steps
     head = "%-9s %7d pts x %d frames, sigma %.2f, rnn %-22s V0/V1/V2 (last frame) %s :" % (
         name, points, frames, sigma, ",".join(rnn) if seq_learning else "(no sequence learning)", counts)
     if PAIRS_ONLY:
-        print(head, "%8.1f clouds/s (4 streams x 2 lock-stepped sequences)" % res[(4, True)], flush=True)
+        print(head, "%8.1f clouds/s (4 streams x 8 lock-stepped sequences)" % res[(4, 8)], flush=True)
     else:
         print(head, "%8.1f clouds/s (1 stream) %8.1f clouds/s (4 streams)" % (res[(1, False)], res[(4, False)]), flush=True)
 
