@@ -28,6 +28,10 @@ class OracleLNN:
                  dtype=torch.float32):
         # dtype = torch.float64: the reference for GRADIENT checks (tests/test_gpu_train.py) — a float32 CPU autograd pass
         # through ~60 layers carries rounding noise of the size of the errors to be measured
+        # dtype = torch.float64 with exact_pool = True: the "truth" reading of the 1e-4 logit bar (tests/test_gpu_fullsize.py,
+        # tools/parity64.py) — the pooled PointNet tensor stays the pinned fp32 fma chain (bit-identical on both sides,
+        # DESIGN.md section 2), everything behind it runs in float64
+        self.dtype = dtype
         self.sd = {k: v.detach().cpu().to(dtype) if v.is_floating_point() else v.detach().cpu() for k, v in sd.items()}
         self.nr_classes = nr_classes
         self.rnn = [m if m in ("linear", "maxpool", "cga", "aflow", "lstm", "gru") else "none" for m in rnn_modules]
@@ -181,6 +185,7 @@ class OracleLNN:
             lv = self._attention_pool(dist, indices, v0)
         else:
             lv = O.pointnet_pool(dist, indices, v0, ws, bs, 0 if early_maxpool else 4, exact=self.exact_pool)
+            lv = lv.to(self.dtype)
         if self.seq and self.rnn[0] == "maxpool":
             rowsum = lv[:, : lv.shape[1] // 2].abs().sum(1, keepdim=True)
             lv = lv.masked_fill(rowsum == 0, -9900)

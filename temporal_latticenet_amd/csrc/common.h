@@ -75,6 +75,29 @@ __device__ __forceinline__ int tln_wave_sum(int v) {
   return v;
 }
 
+// ONE arithmetic for the GRU cell wherever it is evaluated (torch.nn.GRUCell, reference lattice_modules.py:62): the fused
+// large-lattice cell (gemm_v2.hip epilogue) and the small-lattice gates kernel (fused.hip k_gru_gates) call this, so a
+// lattice that crosses the size threshold does not change its gate arithmetic.  Accurate library exp / tanh and a
+// correctly rounded division (round 3's fused cell used the hardware exp2 / rcp approximations and tanh by exp); every
+// multiply-add is spelled out as one fused operation so that translation units with different -ffp-contract settings and
+// different instantiations of one epilogue produce the same bits.
+//   pre_r = gi_r + gh_r (+ biases), pre_z likewise, gi_n / gh_n = the two halves of the n gate, h = padded hidden state
+__device__ __forceinline__ float tln_sigmoid_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float tln_gru_cell_value(float pre_r, float pre_z, float gi_n, float gh_n, float h) {
+#ifdef TLN_GRU_FAST_GATES   // measurement builds only (TLN_EXTRA_FLAGS=-DTLN_GRU_FAST_GATES): round 3's approximations,
+                            // kept to put a number on what they contributed (tools/parity64.py)
+  const float rr = __frcp_rn(1.0f + __expf(-pre_r));
+  const float zz = __frcp_rn(1.0f + __expf(-pre_z));
+  const float na = fmaf(rr, gh_n, gi_n);
+  const float nn = fmaf(-2.0f, __frcp_rn(1.0f + __expf(2.0f * na)), 1.0f);
+  return fmaf(zz, h, __fmul_rn(1.0f - zz, nn));
+#endif
+  const float r = tln_sigmoid_acc(pre_r);
+  const float z = tln_sigmoid_acc(pre_z);
+  const float n = tanhf(fmaf(r, gh_n, gi_n));
+  return fmaf(z, h, __fmul_rn(1.0f - z, n));
+}
+
 // order-preserving map float -> uint32 (larger float => larger uint)
 __device__ __forceinline__ uint32_t tln_f2ord(float f) {
   uint32_t u = __float_as_uint(f);

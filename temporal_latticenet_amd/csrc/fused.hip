@@ -256,11 +256,8 @@ __global__ void __launch_bounds__(256) k_gru_gates(const float* __restrict__ gi,
   const int c = (int)(i - v * C);
   const float* a = gi + v * 3 * C;
   const float* b = gh + v * 3 * C;
-  const float r = 1.0f / (1.0f + expf(-(a[c] + b[c])));
-  const float z = 1.0f / (1.0f + expf(-(a[C + c] + b[C + c])));
-  const float n = tanhf(a[2 * C + c] + r * b[2 * C + c]);
   const float hp = (v < Vh) ? h[v * C + c] : 0.0f;
-  out[i] = (1.0f - z) * n + z * hp;
+  out[i] = tln_gru_cell_value(a[c] + b[c], a[C + c] + b[C + c], a[2 * C + c], b[2 * C + c], hp);   // common.h: one arithmetic
 }
 
 extern "C" int tln_gru_cell(const float* d_x, const float* d_h, int64_t V, int64_t Vh, int C, const float* d_w_ih,

@@ -484,15 +484,13 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
     for (int r = 0; r < 16; ++r) hv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rA1, voff[r], 0, 0));
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      // (hardware exp2 / reciprocal: 1-2 ulp, far inside the 1e-4 the outputs are held to; tanh(x) = 1 - 2 / (1 + e^2x))
-      // every multiply-add spelled out as ONE fused operation: left to the compiler's contraction, the single-cell and the
-      // batched instantiation of this body (k_gather_gemm_v2_gru / _gru_multi) fused different ones and differed in the
-      // last bit — a lock-step group must compute exactly what its sequences compute alone
-      const float rr = __frcp_rn(1.0f + __expf(-(acc[0][0][r] + br)));
-      const float zz = __frcp_rn(1.0f + __expf(-(acc[0][1][r] + bz)));
-      const float na = fmaf(rr, acc[0][2][r] + bnh, acc[0][3][r] + bni);   // tile 3: gi_n (x's share, parked), tile 2: gh_n
-      const float nn = fmaf(-2.0f, __frcp_rn(1.0f + __expf(2.0f * na)), 1.0f);
-      const float hn = fmaf(zz, hv[r], __fmul_rn(1.0f - zz, nn));
+      // the cell's arithmetic is common.h's tln_gru_cell_value — the SAME function the small-lattice gates kernel calls
+      // (accurate exp / tanh / division; round 3 had hardware approximations here).  Every multiply-add in it is spelled
+      // out as ONE fused operation: left to the compiler's contraction, the single-cell and the batched instantiation of
+      // this body (k_gather_gemm_v2_gru / _gru_multi) fused different ones and differed in the last bit — a lock-step
+      // group must compute exactly what its sequences compute alone
+      // tile 3: gi_n (x's share, parked), tile 2: gh_n
+      const float hn = tln_gru_cell_value(acc[0][0][r] + br, acc[0][1][r] + bz, acc[0][3][r] + bni, acc[0][2][r] + bnh, hv[r]);
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, hn), rOut, voff[r], 0, 0);
     }
     return;

@@ -29,7 +29,7 @@ class LovaszSoftmax(torch.nn.Module):
             return probs.sum() * 0.0
         losses = []
         for c in range(probs.shape[1]):
-            fg = (target == c).float()
+            fg = (target == c).to(probs.dtype)
             if self.classes == "present" and fg.sum() == 0:
                 continue
             errors = (fg - probs[:, c]).abs()

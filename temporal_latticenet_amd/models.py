@@ -15,7 +15,9 @@ from .lattice_modules import (BottleneckBlock, DistributeLatticeModule, GnReluCo
 from .seq_modules import (CrossframeGlobalAttentionModule, CrossframeLocalInterpolationModule, GRUModule, LSTMModule,
                           PointNetSeqModule, TemporalLinearModule, TemporalMaxPoolModule)
 
-__all__ = ["LNN_SEQ", "make_fusion_module"]
+from .checkpoint import load_checkpoint, summary  # noqa: F401  (summary: models.py:551-602, exported by `import *`)
+
+__all__ = ["LNN_SEQ", "make_fusion_module", "summary", "load_checkpoint"]
 
 VALID_EXPERIMENTS = ["none", "slice_no_deform", "pointnet_no_elevate", "pointnet_no_local_mean",
                      "pointnet_no_elevate_no_local_mean", "splat", "attention_pool"]

@@ -58,6 +58,10 @@ class _KeyBoard:
             for k in [k for k in self._items if k[0] == seq]:
                 del self._items[k]
 
+    def clear(self):
+        with self._cv:
+            self._items.clear()
+
 
 class _Slot(FrameShardRunner):
     """the owner of frame `slot` of every sequence: FrameShardRunner with the process group replaced by queues"""
@@ -74,21 +78,31 @@ class _Slot(FrameShardRunner):
             ev.record(self.stream)
             self.trace.append((label, ev))
 
+    _cur_seq = None   # (run generation, sequence index) of the job in hand: stamps every message this slot sends
+
     def _send_state(self, sid, t):
         ev = torch.cuda.Event()
         ev.record(self.stream)
-        self.outbox.put((sid, t, ev))
+        self.outbox.put((self._cur_seq, sid, t, ev))
         self._mark("sent %d" % sid)
 
     def _recv_state(self, sid):
         try:
-            got, t, ev = self.inbox.get(timeout=_WAIT_S)
+            seq, got, t, ev = self.inbox.get(timeout=_WAIT_S)
         except queue.Empty:
             raise RuntimeError("frame pipeline: hidden state %d of the previous frame never arrived" % sid)
+        if seq != self._cur_seq:      # a message left over from a sequence that failed: never consumed silently
+            raise RuntimeError("frame pipeline: hidden state %d belongs to sequence %r, this slot is on %r"
+                               % (got, seq, self._cur_seq))
         if got != sid:
             raise RuntimeError("frame pipeline: expected hidden state %d, the previous frame sent %d" % (sid, got))
         self._mark("wants %d" % sid)
         self.stream.wait_event(ev)
+        if t is not None:
+            # the tensor was allocated on the SENDER's stream: tell the caching allocator that this stream reads it too,
+            # or the block returns to the sender's pool when the last reference drops and the sender (already on its next
+            # sequence) may overwrite it while this stream's copy is still pending
+            t.record_stream(self.stream)
         self._mark("has %d" % sid)
         return t if (t is not None and t.numel()) else None
 
@@ -96,6 +110,7 @@ class _Slot(FrameShardRunner):
         """this slot's frame of sequence `seq`: publish its keys, take in the keys of the frames before it, run"""
         f = self.plan.frames[0]
         pos, val = frame_data
+        self._cur_seq = seq
         self._mark("start")
         if self.plan.next_rank is not None:          # (nobody needs the last frame's keys)
             self.scratch.distribute(pos, val, reset_hashmap=True, subtract_mean=False)
@@ -107,6 +122,7 @@ class _Slot(FrameShardRunner):
         for g in range(f):
             k, ev = self.board.get(seq, g)
             self.stream.wait_event(ev)
+            k.record_stream(self.stream)      # produced on slot g's stream, read by insert_keys on this one
             all_keys[g] = k
         self._mark("keys in")
         out = self.run_sequence({f: frame_data}, all_keys)
@@ -140,6 +156,8 @@ class FramePipeline:
         self.slots = [_Slot(self.models[g], make_lattice, FrameShardPlan(T, g, T), self.streams[g],
                             links[g - 1] if g > 0 else None, links[g] if g < T - 1 else None, self.board)
                       for g in range(T)]
+        self._links = links
+        self._gen = 0                                             # run generation: stamps board entries and link messages
         self._jobs = [queue.Queue() for _ in range(T)]
         self._done = queue.Queue()
         self._threads = [threading.Thread(target=self._loop, args=(g,), daemon=True) for g in range(T)]
@@ -185,10 +203,12 @@ class FramePipeline:
         start.record(cur)
         for s in self.streams:
             s.wait_event(start)                       # the inputs were produced on the caller's stream
+        self._gen += 1
+        gen = self._gen
         for i, sq in enumerate(sequences):
             assert len(sq) == T, "a sequence of %d frames on a pipeline of %d slots" % (len(sq), T)
             for g in range(T):
-                self._jobs[g].put((i, sq[g]))
+                self._jobs[g].put(((gen, i), sq[g]))
         outs = [None] * len(sequences)
         err = None
         for _ in range(T * len(sequences)):
@@ -197,14 +217,29 @@ class FramePipeline:
                 err = e
             if g == T - 1:
                 if keep_outputs and out is not None:
-                    outs[seq] = (out[0], out[1])
+                    outs[seq[1]] = (out[0], out[1])
                 self.board.drop(seq)
         for s in self.streams:
             ev = torch.cuda.Event()
             ev.record(s)
             cur.wait_event(ev)
+        for o in outs:                        # allocated on the last slot's stream, used on the caller's from here on
+            if o is not None:
+                for t in o:
+                    if torch.is_tensor(t):
+                        t.record_stream(cur)
         for m in self.models:                 # (slot 0's model is the caller's: leave it at the start of a sequence)
             m.reset_sequence()
         if err is not None:
+            # nothing of the failed run may meet a later one: the slots are idle here (every job reported), so what is
+            # left on the board and in the links is stale (and a message that slipped through would fail the generation
+            # check of _recv_state / be an unknown board key)
+            self.board.clear()
+            for q in self._links:
+                while True:
+                    try:
+                        q.get_nowait()
+                    except queue.Empty:
+                        break
             raise err
         return outs

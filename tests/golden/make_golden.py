@@ -15,6 +15,12 @@ reference's own code; the stand-ins only provide
   * Im2RowLattice / Im2RowIndicesLattice: a gather through an explicit [V,9] neighbour table (centre last, -1 holes)
   * scatter_max / scatter_add: pure-torch segment reductions
   * ConvLatticeModule: identity (so PointNetSeqModule's output is the tensor that enters `last_conv`)
+  * for CrossframeGlobalAttentionModule (lm:70-116) only: Conv1x1 = a lazily created, seeded torch.nn.Linear without
+    bias applied per vertex (called with ONE argument and returning ONE tensor, as lm:95, 102 call it); Gn = a lazily
+    created torch.nn.GroupNorm(32, C) over the lattice in [1, C, V] layout with seeded affine parameters, returning
+    (lv, ls) as lm:100 unpacks it.  Parameter names follow the build's modules (conv.linear.weight, groupnorm.norm.*).
+    What the fixture pins is the module's own glue: hidden_linear, the zero padding to V rows, conv -> ReLU -> Gn ->
+    conv with ONE shared conv weight, the 1 / (V + C) scale, the sigmoid, the ones for rows born in this frame, the gate.
 No reference source text is stored in this repository: only inputs, seeded weights and outputs.
 """
 import importlib.util
@@ -93,6 +99,37 @@ class IdentityConv(torch.nn.Module):
 
     def forward(self, lv, ls):
         return lv, ls
+
+
+class SeededConv1x1(torch.nn.Module):
+    """Conv1x1(out_channels, bias) stand-in for the CGA fixture: per-vertex Linear, created at the first call"""
+
+    def __init__(self, out_channels=None, bias=True, *a, **k):
+        super().__init__()
+        self.out_channels, self.use_bias, self.linear = out_channels, bias, None
+
+    def forward(self, lv, ls=None):
+        if self.linear is None:
+            self.linear = torch.nn.Linear(lv.shape[1], self.out_channels, bias=self.use_bias)
+        out = self.linear(lv)
+        return out if ls is None else (out, ls)
+
+
+class SeededGn(torch.nn.Module):
+    """Gn() stand-in for the CGA fixture: GroupNorm(32 groups, or C/2) over all vertices of a group ([1, C, V] layout)"""
+
+    def __init__(self, *a, **k):
+        super().__init__()
+        self.norm = None
+
+    def forward(self, lv, ls):
+        if self.norm is None:
+            c = lv.shape[1]
+            self.norm = torch.nn.GroupNorm(32 if c % 32 == 0 else c // 2, c)
+            with torch.no_grad():
+                self.norm.weight.copy_(torch.rand(c) * 0.5 + 0.75)
+                self.norm.bias.copy_(torch.randn(c) * 0.05)
+        return self.norm(lv.t().unsqueeze(0)).squeeze(0).t(), ls
 
 
 def install_stand_ins():
@@ -202,6 +239,11 @@ def main():
     for c in (32, 256):
         np.savez_compressed(os.path.join(HERE, "aflow_c%d.npz" % c),
                             **run_fusion(ref, lambda: ref.CrossframeLocalInterpolationModule(c), c, 300 + c, True))
+    # CrossframeGlobalAttentionModule (lm:70-116) with seeded stand-ins for its two un-vendored sub-modules
+    ref.Conv1x1, ref.Gn = SeededConv1x1, SeededGn
+    np.savez_compressed(os.path.join(HERE, "cga_c64.npz"),
+                        **run_fusion(ref, lambda: ref.CrossframeGlobalAttentionModule(64), 64, 21))
+    ref.Conv1x1 = ref.Gn = IdentityConv
 
     # PointNetSeqModule: distributed [4N,5], indices with -1s, a vertex with < 4 rows, winning rows both <= V and > V
     torch.manual_seed(11)

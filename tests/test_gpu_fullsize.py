@@ -10,7 +10,7 @@ import pytest
 import torch
 
 from oracle import ops as O
-from tests.helpers import build_model, make_config, make_lattice, oracle_from_model, randomize_parameters
+from tests.helpers import build_model, make_config, make_lattice, oracle_from_model, oracle_pair, randomize_parameters
 from temporal_latticenet_amd.synthetic import make_sequence
 
 pytestmark = pytest.mark.gpu
@@ -39,19 +39,16 @@ def _prepared(contents, seq, gpu, seed):
     return model
 
 
-def _check(got, want, what, tol=TOL):
-    """north-star tolerance: |logit - oracle| <= 1e-4 relative to the largest logit (fp32: the scores reach |x| ~ 30, one
-    ulp there is 2e-6).  Both readings are recorded (tests/helpers.py::parity_log -> gpurun_out/parity_errors.json, the
-    table of DESIGN.md section 2): max_abs and max_abs / max|logit|."""
-    from tests.helpers import parity_log
-    got = got.cpu()
-    assert got.shape == want.shape
-    scale = max(1.0, float(want.abs().max()))
-    err = float((got - want).abs().max())
-    parity_log(what, err, scale, tuple(got.shape))
-    assert err <= tol * scale, "%s: max abs err %.3e (scale %.2f)" % (what, err, scale)
-    assert err <= ABS_TOL, "%s: max abs err %.3e exceeds the recorded absolute level" % (what, err)
-    return err
+def _check(got, want, what, want64, tol=TOL):
+    """tests/helpers.py::check_logits: |HIP - o64| <= max(1e-4, |o32 - o64|) (the north star's bar read against a float64
+    evaluation of the same algorithm), |HIP - o32| <= 1e-4 relative to the largest logit and <= ABS_TOL absolutely; the three
+    numbers go to gpurun_out/parity_errors.json (profiles/r04_parity_errors.json, table of DESIGN.md section 2)."""
+    from tests.helpers import check_logits
+    return check_logits(got, want, want64, what, rel_tol=tol, abs_ceiling=ABS_TOL)
+
+
+def _both(o32, o64, pos, val, **kw):
+    return o32.forward(pos, val, **kw), o64.forward(pos, val, **kw)
 
 
 @pytest.mark.parametrize("rnn", [("gru", "gru", "aflow", "gru"), ("gru", "gru", "gru", "gru")])
@@ -62,10 +59,10 @@ def test_four_frames_of_120k_points_match_the_oracle(gpu, rnn):
     outs, lat = _run(model, contents, seq, gpu)
     assert getattr(model, "_program", None) is not None, "the frame program was not used"
     assert lat.nr_lattice_vertices() > 25000 and lat.overflow_rows() == 0
-    oracle = oracle_from_model(model, contents)
+    oracle, oracle64 = oracle_pair(model, contents)
     for t, (pos, val) in enumerate(seq):
-        want = oracle.forward(pos, val, early_return=(t != len(seq) - 1))
-        _check(outs[t], want, "%s frame %d" % (",".join(rnn), t))
+        want, want64 = _both(oracle, oracle64, pos, val, early_return=(t != len(seq) - 1))
+        _check(outs[t], want, "%s frame %d" % (",".join(rnn), t), want64)
     assert outs[-1].shape == (120000, 26)
     # the same sequence as one of two lock-stepped sequences of a stream (shared gather-GEMM launches where eligible)
     from temporal_latticenet_amd.configs import build_model as bm
@@ -83,7 +80,40 @@ def test_four_frames_of_120k_points_match_the_oracle(gpu, rnn):
             lats = [r[2] for r in res]
     model.reset_sequence()
     other.reset_sequence()
-    _check(res[0][1], want, "lock-step group, last frame")
+    _check(res[0][1], want, "lock-step group, last frame", want64)
+
+
+def test_config2_one_120k_cloud_without_sequence_learning(gpu):
+    """BASELINE config 2 exactly: ONE SemanticKITTI-shaped 120 000-point cloud, sigma 0.6, sequence_learning = false, the
+    full U-Net of cfg:31-42 (models.py:284-476 with every `if self.sequence_learning` branch off: no fusion module is
+    built, the lattice is cleared on every call — models.py:287-289), one MI355X.  A second cloud through the same model
+    and the same Lattice object checks that clearing: it must give what a fresh lattice gives."""
+    contents = make_config(sequence_learning=False, frames=1, sigma=0.6)
+    seq = make_sequence(120000, 2, seed=1234)
+    model = build_model(contents).eval()
+    with torch.no_grad():
+        model(make_lattice(contents), torch.from_numpy(seq[0][0][:4096]).to(gpu), torch.from_numpy(seq[0][1][:4096]).to(gpu),
+              False, False)
+    randomize_parameters(model, seed=15)
+    assert not any("fusion" in k or "recurrent" in k for k in model.state_dict()), "no fusion module without sequence learning"
+    lat = make_lattice(contents)
+    outs = []
+    with torch.no_grad():
+        for pos, val in seq:
+            a, b, lat = model(lat, torch.from_numpy(pos).to(gpu), torch.from_numpy(val).to(gpu), False, False)
+            assert a.shape == b.shape == (120000, 26)
+            np.testing.assert_allclose(a.exp().sum(1).cpu().numpy(), 1.0, rtol=0, atol=1e-4)     # logsoftmax, models.py:468
+            outs.append(b.clone())
+        fresh = model(make_lattice(contents), torch.from_numpy(seq[1][0]).to(gpu), torch.from_numpy(seq[1][1]).to(gpu),
+                      False, False)[1]
+    assert torch.equal(outs[1], fresh), "the lattice is cleared per call when sequence_learning is off"
+    v0 = lat.nr_lattice_vertices()
+    assert 15000 < v0 < 30000 and lat.overflow_rows() == 0, v0
+    oracle, oracle64 = oracle_pair(model, contents)
+    for t, (pos, val) in enumerate(seq):
+        want, want64 = _both(oracle, oracle64, pos, val)
+        assert oracle.levels[0].table.nr_vertices == (v0 if t == 1 else oracle.levels[0].table.nr_vertices)
+        _check(outs[t], want, "config 2: one 120k cloud, no sequence learning, cloud %d" % t, want64)
 
 
 def test_the_timed_configuration_matches_the_oracle(gpu):
@@ -141,13 +171,14 @@ def test_the_timed_configuration_matches_the_oracle(gpu):
         assert worst <= TOL, worst
         assert len(v_counts) >= 24, "the sequences of the groups are meant to differ in their vertex counts"
         # (1) + (3) one per stream at a different group position: the oracle, and a solo run on the group's kernels
-        oracle = oracle_from_model(model, contents)
+        oracle, oracle64 = oracle_pair(model, contents)
         for i, j in ((0, 0), (1, 3), (2, 5), (3, 7)):
             seq = seqs[per * i + j]
             oracle.reset_sequence()
+            oracle64.reset_sequence()
             for t, (p, v) in enumerate(seq):
-                want = oracle.forward(p.cpu().numpy(), v.cpu().numpy(), early_return=(t != T - 1))
-            _check(got[i][j], want, "timed configuration 4 streams x 8: stream %d position %d vs oracle" % (i, j))
+                want, want64 = _both(oracle, oracle64, p.cpu().numpy(), v.cpu().numpy(), early_return=(t != T - 1))
+            _check(got[i][j], want, "timed configuration 4 streams x 8: stream %d position %d vs oracle" % (i, j), want64)
             lib.tln_gemm_v2_config(0, 1)
             try:
                 same, _ = alone(seq)
@@ -182,8 +213,8 @@ def test_accumulated_cloud_and_prediction_tail(gpu, tmp_path):
     outs, lat = _run(model, contents, [(pos, val)], gpu, lattice=lat)
     assert lat.overflow_rows() == 0 and lat.nr_lattice_vertices() < cap
     contents_o = make_config(rnn_modules=("gru", "gru", "aflow", "gru"), frames=1, sigma=0.6, capacity=cap)
-    want = oracle_from_model(model, contents_o).forward(pos, val)
-    _check(outs[0], want, "accumulated cloud of %d points" % pos.shape[0])
+    want, want64 = _both(*oracle_pair(model, contents_o), pos, val)
+    _check(outs[0], want, "accumulated cloud of %d points" % pos.shape[0], want64)
     pred = outs[0].argmax(1).cpu().numpy()
     path = str(tmp_path / "sequences" / "08" / "predictions" / "000007.label")
     K.write_prediction_labels(path, pred, len_last_cloud=lens[-1])
@@ -196,10 +227,10 @@ def test_eight_recurrent_frames_match_the_oracle(gpu):
     seq = make_sequence(30000, 8, seed=21)
     model = _prepared(contents, seq, gpu, seed=7)
     outs, lat = _run(model, contents, seq, gpu)
-    oracle = oracle_from_model(model, contents)
+    oracle, oracle64 = oracle_pair(model, contents)
     for t, (pos, val) in enumerate(seq):
-        want = oracle.forward(pos, val, early_return=(t != len(seq) - 1))
-        _check(outs[t], want, "frame %d of 8" % t)
+        want, want64 = _both(oracle, oracle64, pos, val, early_return=(t != len(seq) - 1))
+        _check(outs[t], want, "frame %d of 8" % t, want64)
 
 
 def test_config5_eight_frames_of_120k_points_match_the_oracle(gpu):
@@ -214,10 +245,10 @@ def test_config5_eight_frames_of_120k_points_match_the_oracle(gpu):
     v0 = lat.nr_lattice_vertices()
     print("[config 5] 8 x 120k recurrent: V0 after the last frame = %d" % v0)
     assert v0 > 35000 and lat.overflow_rows() == 0
-    oracle = oracle_from_model(model, contents)
+    oracle, oracle64 = oracle_pair(model, contents)
     for t, (pos, val) in enumerate(seq):
-        want = oracle.forward(pos, val, early_return=(t != len(seq) - 1))
-        _check(outs[t], want, "config 5: frame %d of 8 x 120k" % t)
+        want, want64 = _both(oracle, oracle64, pos, val, early_return=(t != len(seq) - 1))
+        _check(outs[t], want, "config 5: frame %d of 8 x 120k" % t, want64)
     assert outs[-1].shape == (120000, 26)
 
 
@@ -249,9 +280,9 @@ def test_config5_accumulated_960k_cloud_through_the_whole_model(gpu, sigma):
     assert torch.equal(outs[0], again[0]), "two runs, same bits"
     t0 = time.time()
     contents_o = make_config(rnn_modules=rnn, frames=1, sigma=sigma, capacity=cap)
-    want = oracle_from_model(model, contents_o).forward(pos, val)
-    print("[config 5] oracle: %.1f s" % (time.time() - t0))
-    _check(outs[0], want, "config 5: accumulated cloud of 960k points, sigma %.2f, V0 = %d" % (sigma, counts[0]))
+    want, want64 = _both(*oracle_pair(model, contents_o), pos, val)
+    print("[config 5] oracle (fp32 + float64): %.1f s" % (time.time() - t0))
+    _check(outs[0], want, "config 5: accumulated cloud of 960k points, sigma %.2f, V0 = %d" % (sigma, counts[0]), want64)
 
 
 def test_vis_aflow_forward(gpu, monkeypatch):
@@ -284,10 +315,13 @@ def test_vis_aflow_forward(gpu, monkeypatch):
         return out, w, tab
 
     monkeypatch.setattr(O, "aflow_correlation", spy)
-    oracle = oracle_from_model(model, contents)
+    oracle, oracle64 = oracle_pair(model, contents)
     for t, (pos, val) in enumerate(seq):
         want = oracle.forward(pos, val, early_return=(t != len(seq) - 1))
-    _check(outs[-1], want, "vis_aflow logits")
+    monkeypatch.setattr(O, "aflow_correlation", real)
+    for t, (pos, val) in enumerate(seq):
+        want64 = oracle64.forward(pos, val, early_return=(t != len(seq) - 1))
+    _check(outs[-1], want, "vis_aflow logits", want64)
     w = w_list[0].cpu().numpy()
     assert w.shape == tuple(seen["w"].shape) and w.shape[1] == 9
     np.testing.assert_allclose(w, seen["w"].numpy(), rtol=1e-4, atol=1e-6)

@@ -88,6 +88,22 @@ def test_other_fusion_modules(gpu, cls, name, args):
     _run(m, z, 2e-5)
 
 
+def test_cga_module(gpu):
+    """CrossframeGlobalAttentionModule (lm:70-116) on the library's kernels against what the reference's own class
+    computed with seeded stand-ins for Conv1x1 / Gn (tests/golden/make_golden.py): hidden_linear, zero padding to V rows,
+    conv -> ReLU -> Gn -> the SAME conv, 1 / (V + C), sigmoid, ones for the rows born in this frame, the gate"""
+    from temporal_latticenet_amd.seq_modules import CrossframeGlobalAttentionModule
+    z, sd = _load("cga_c64.npz")
+    m = CrossframeGlobalAttentionModule(64).cuda()
+    m.conv._make(64)                                  # the lazily created parameters (created at the first use upstream)
+    m.groupnorm.ensure(torch.zeros(1, 64))
+    assert set(m.state_dict()) == set(sd), (sorted(m.state_dict()), sorted(sd))
+    m.load_state_dict(sd)
+    m = m.cuda()
+    _run(m, z, 2e-5)
+    assert float(np.abs(z["lv3"][53:] - z["x3"][53:]).max()) == 0.0      # rows born in the frame pass through (gate = 1)
+
+
 def test_pointnet_pool_against_the_reference_vectors(gpu):
     """tests/golden/pointnet_pool.npz came out of the reference's own PointNetSeqModule.forward (lm:407-576, generator
     tests/golden/make_golden.py): -1 indices, an empty vertex, a vertex with < 4 rows, arg-max rows both <= V and > V.

@@ -192,3 +192,68 @@ def test_lattice_scale_constant_cfg_values():
     assert make_config(scale_constant="unit")["lattice_gpu"]["scale_constant"] == "unit"
     from tests.helpers import _scale_constant
     assert _scale_constant(None) is None and _scale_constant("unit") == 1.0 and _scale_constant(2) == 2.0
+
+
+def test_summary_counts_parameters_and_prints_the_tree():
+    """summary() of seq_lattice/models.py:551-602: returns the parameter count, prints one line per module"""
+    import io
+
+    import torch
+    from temporal_latticenet_amd.checkpoint import summary
+    m = torch.nn.Sequential(torch.nn.Linear(3, 5), torch.nn.Sequential(torch.nn.Linear(5, 2, bias=False), torch.nn.ReLU()))
+    buf = io.StringIO()
+    n = summary(m, file=buf)
+    assert n == 3 * 5 + 5 + 5 * 2 == sum(p.numel() for p in m.parameters())
+    text = buf.getvalue()
+    assert "(0): Linear(in_features=3, out_features=5, bias=True), 20 params" in text
+    assert text.splitlines()[0].startswith("Sequential(") and text.splitlines()[0].endswith("30 params")
+    assert summary(m, file=None) == n
+    import temporal_latticenet_amd.models as M
+    assert M.summary is summary and "summary" in M.__all__
+
+
+def test_load_checkpoint_reports_every_key_and_takes_a_rename_map(tmp_path):
+    """test_ln.py:174 / train_ln.py:198 call model.load_state_dict(torch.load(path)); the names inside the un-vendored
+    modules are unknown here, so the helper reports instead of failing half-way"""
+    import pytest
+    import torch
+    from temporal_latticenet_amd.checkpoint import load_checkpoint
+
+    class Block(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.norm = torch.nn.GroupNorm(2, 4)
+            self.conv = torch.nn.Linear(4, 4)
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.blocks = torch.nn.ModuleList([Block(), Block()])
+            self.head = torch.nn.Linear(4, 3)
+
+    torch.manual_seed(0)
+    src, dst = Net(), Net()
+    # a checkpoint with upstream-style names: blocks.N.gn.* instead of blocks.N.norm.*, one stray key, one wrong shape
+    sd = {k.replace(".norm.", ".gn."): v.clone() for k, v in src.state_dict().items()}
+    sd["optimizer_step"] = torch.tensor(3)
+    sd["head.weight"] = torch.zeros(5, 4)
+    path = str(tmp_path / "model_e_2.pt")
+    torch.save(sd, path)
+    with pytest.raises(KeyError) as e:
+        load_checkpoint(dst, path)
+    msg = str(e.value)
+    assert "blocks.0.norm.weight" in msg and "blocks.0.gn.weight" in msg and "optimizer_step" in msg and "head.weight" in msg
+    before = {k: v.clone() for k, v in dst.state_dict().items()}
+    assert all(torch.equal(before[k], v) for k, v in dst.state_dict().items()), "strict failure copies nothing"
+    rep = load_checkpoint(dst, path, rename={r"^blocks\.(\d+)\.gn\.": r"blocks.\1.norm."}, strict=False)
+    assert rep.unexpected == ["optimizer_step"] and rep.missing == [] and [r[0] for r in rep.shape_mismatch] == ["head.weight"]
+    assert len(rep.renamed) == 4 and ("blocks.1.gn.bias", "blocks.1.norm.bias") in rep.renamed
+    for k, v in src.state_dict().items():
+        if k != "head.weight":
+            assert torch.equal(dst.state_dict()[k], v), k
+    assert torch.equal(dst.state_dict()["head.weight"], before["head.weight"])
+    assert not rep.ok and "1 unexpected" in str(rep)
+    # plain prefix form, exact checkpoint: strict passes
+    sd2 = {("module." + k): v for k, v in src.state_dict().items()}
+    rep = load_checkpoint(Net(), sd2, rename={"module.": ""})
+    assert rep.ok and len(rep.loaded) == len(sd2)

@@ -53,8 +53,10 @@ def _run_model_fusion(kind, z, sd):
 
 
 @pytest.mark.parametrize("kind,name", [("lstm", "lstm_c64.npz"), ("maxpool", "maxpool_c64.npz"),
-                                       ("linear", "linear_c64.npz")])
+                                       ("linear", "linear_c64.npz"), ("cga", "cga_c64.npz")])
 def test_other_fusion_modules_match_reference(kind, name):
+    """cga: lm:70-116 run by the reference's own class with seeded stand-ins for its two un-vendored sub-modules
+    (tests/golden/make_golden.py: Conv1x1 = Linear without bias, Gn = GroupNorm(32, C) over [1, C, V])"""
     z, sd = _load(name)
     for t, lv in enumerate(_run_model_fusion(kind, z, sd)):
         np.testing.assert_allclose(lv.numpy(), z["lv%d" % t], rtol=1e-5, atol=1e-6)
