@@ -571,14 +571,13 @@ def self_check(pool, per_stream, S, per, model, contents, make_lattice):
     """The timed region keeps no outputs; this runs ONE more step of exactly that configuration (same pool, same
     sequences, same kernel selection) with the last-frame scores kept and compares one sequence per stream -- at a
     different position of its lock-step group each -- with the same sequence run alone on the null stream:
-      * with the lone run held on the kernels the group takes (tln_gemm_v2_config(0, 1): every product on gemm_v2, as the
+      * with the lone run held on the kernels the group takes (options(v2_min_m=1): every product on gemm_v2, as the
         shared launches of a group are): expected BITWISE equal -- a shared launch must not change a bit;
       * with the lone run on its own default kernels (direct kernel on the coarse levels): equal up to the order of the
         K summation; max |difference| reported.
     cpu_baseline() adds the comparison of stream 0's first sequence with the CPU oracle (models.py:284-476 restated)."""
     import torch
-    from temporal_latticenet_amd import _lib
-    lib = _lib.lib()
+    from temporal_latticenet_amd import options as OPT
     got = pool.run([per_stream[per * i:per * i + per] for i in range(S)], keep_outputs=True)
 
     def alone(seq):
@@ -593,12 +592,9 @@ def self_check(pool, per_stream, S, per, model, contents, make_lattice):
     for i, j in picks:
         g = got[i][j]
         seq = per_stream[per * i + j]
-        if per > 1:
-            lib.tln_gemm_v2_config(0, 1)
-        try:
+        # (kernel-selection options of this host thread — temporal_latticenet_amd/options.py; the library has no global switch)
+        with OPT.options(**({"v2_min_m": 1} if per > 1 else {})):
             a = alone(seq)
-        finally:
-            lib.tln_gemm_v2_config(0, 12288)
         b = alone(seq) if per > 1 else a
         bitwise = bitwise and bool(torch.equal(g, a))
         d_same = max(d_same, float((g - a).abs().max()))
@@ -652,6 +648,21 @@ def cpu_baseline(model, contents, args, checked=None, kept0=None):
         err = float((kept0 - want).abs().max())
         checked["max_abs_vs_oracle"] = err
         checked["max_abs_vs_oracle_over_max_logit"] = err / max(1.0, float(want.abs().max()))
+        # the same sequence through a FLOAT64 evaluation of the oracle (pooled PointNet tensor in the pinned fp32 order,
+        # everything behind it in float64): how far the HIP path and the fp32 CPU restatement each are from it
+        o64 = OracleLNN(model.state_dict(), 26, m["rnn_modules"], m["sequence_learning"], m["pointnet_layers"],
+                        m["nr_downsamples"], m["nr_blocks_down_stage"], m["nr_blocks_bottleneck"],
+                        m["nr_blocks_up_stage"], [args.sigma] * 3, 1 << 18, m["experiment"],
+                        scale_constant=oracle.scale_constant, dtype=torch.float64)
+        for t, (pos, val) in enumerate(seq):
+            want64 = o64.forward(pos, val, early_return=(t != len(seq) - 1))
+        d_h, d_o = kept0.double() - want64, want.double() - want64
+        checked["vs_float64_oracle"] = {
+            "hip_max_abs": float(d_h.abs().max()), "oracle_f32_max_abs": float(d_o.abs().max()),
+            "hip_rms": float(d_h.pow(2).mean().sqrt()), "oracle_f32_rms": float(d_o.pow(2).mean().sqrt()),
+            "note": "north star: logits within 1e-4 fp32; the fp32 CPU restatement itself is this far from a float64 "
+                    "evaluation of the same algorithm (tests/helpers.py::check_logits asserts HIP <= max(1e-4, 1.25 x "
+                    "oracle) on the maximum and <= 1.15 x on the rms at every BASELINE size)"}
         checked["oracle_sequence"] = "stream 0, group position 0 (%d frames x %d points, last frame's %d x %d scores)" % (
             len(seq), args.points, want.shape[0], want.shape[1])
     return {"value": round(done / dt, 4), "unit": "clouds/s", "cores": cores, "kind": "port",

@@ -30,6 +30,33 @@ typedef struct tln_lattice tln_lattice_t;
 const char* tln_last_error(void);
 int tln_version(void);
 
+/* ---- Kernel-selection options -------------------------------------------------------------
+ * The library holds NO process-wide mutable state ("no global state except explicit handles"): every
+ * test / measurement switch is a field of this struct, and the struct travels explicitly -- stored in a lattice handle
+ * (tln_lattice_set_options: K1, K2), in a frame program (tln_program_set_options: every product, GRU cell and batched
+ * stage the program issues) or passed with an operator call (tln_gather_gemm_opt, tln_gather_gemm_multi_opt,
+ * tln_gru_cell_opt).  NULL / tln_options_init() = what the library chooses by itself; results are the same bits under
+ * every setting unless a field says otherwise.  (Until round 3 these were tln_*_config / tln_gemm_force_* setters on
+ * file-scope variables, racy under the four host threads of streams.py.) */
+typedef struct tln_options {
+  int k1_legacy;         /* K1: 0 = partitioned kernels (default), 1 = one global atomic per row (always taken for val_dim > 1) */
+  int k1_bucket_rows;    /* K1: rows per bucket the partitioned kernels aim at; 0 = default (512) */
+  int pool_mode;         /* K2: -1 = default, 0 = VALU fma chains, 1 / 2 = wide layers on the matrix cores (same bits) */
+  int gemm_direct;       /* small-M "direct" kernel: 0 = heuristic, 1 = whenever eligible, -1 = never */
+  int gemm_pair_off;     /* 1 = tln_gather_gemm_pair / _multi as separate launches */
+  int gemm_tn;           /* force the column tile of the tiled kernel (1 / 2: 64 / 128 columns; 0 = heuristic) */
+  int gemm_groups;       /* force the K-groups (waves per tile; 0 = heuristic): changes the K-summation order */
+  int gemm_splits;       /* force the split-K slices over the grid (0 = heuristic) */
+  int gemm_wm;           /* force the tile height with gemm_splits (1 = 32 rows, 2 = 64 rows; 0 = heuristic) */
+  int v2_off;            /* large-M kernel (gemm_v2.hip): bit 0 off, bit 2 no row orders / tap skipping, bit 3 = 64-row
+                          * tiles for every shared 128-column launch with the GroupNorm prologue, bit 4 = never */
+  int64_t v2_min_m;      /* smallest M that takes the large-M kernel; 0 = default (12288, env TLN_V2_MIN_M) */
+  void* gemm_stamps;     /* diagnostic: block (0,0,0) of a gather-GEMM writes five s_memtime stamps to this device buffer */
+  int group_off_mask;    /* frame programs in group mode: bit k = ops of kind k (TLN_OP_*) launched per program instead
+                          * of batched; bit 0 = the K1 / coarse-level / table batches */
+} tln_options;
+void tln_options_init(tln_options* o);    /* the defaults (pool_mode = -1, everything else 0) */
+
 /* ---- Lattice handle: replaces latticenet.Lattice (train_ln.py:106, 239) -------------- */
 int tln_lattice_create(tln_lattice_t** out, int pos_dim, const double* sigmas, int64_t capacity);
 /* the same with the lattice scale constant c of scale_i = c / (sigma_i * sqrt((i+1)(i+2))) given: a free choice of the
@@ -41,6 +68,9 @@ int tln_lattice_create_ex(tln_lattice_t** out, int pos_dim, const double* sigmas
 double tln_lattice_default_scale_constant(void);
 double tln_lattice_scale_constant(const tln_lattice_t* l);
 int tln_lattice_destroy(tln_lattice_t* l);
+/* copies *opt (NULL: the defaults) into the handle: k1_* for its distributes, pool_mode for its pools.  A batch of
+ * lattices (tln_distribute_begin_multi, tln_pointnet_pool_multi) follows the first lattice's options. */
+int tln_lattice_set_options(tln_lattice_t* l, const tln_options* opt);
 /* reset_hashmap=True of DistributeLatticeModule (models.py:287-298): clears every level */
 int tln_lattice_clear(tln_lattice_t* l, void* stream);
 /* the same for n lattices (lock-stepped sequences), as few launches as their levels allow */
@@ -48,6 +78,10 @@ int tln_lattice_clear_multi(tln_lattice_t* const* l, int n, void* stream);
 int64_t tln_lattice_nr_vertices(const tln_lattice_t* l);      /* Lattice.nr_lattice_vertices(), train_ln.py:220 */
 int64_t tln_lattice_capacity(const tln_lattice_t* l);
 int tln_lattice_level(const tln_lattice_t* l);
+/* device memory the handle owns over its whole level stack, in bytes: out[0] hash tables + per-vertex arrays, [1] per-row
+ * workspaces of the distribute (records, vertex bins, sort scratch), [2] the pool's accumulators, [3] neighbour /
+ * cross-level tables + row orders, [4] total */
+int tln_lattice_memory(const tln_lattice_t* l, int64_t* out /* [5] */);
 int64_t tln_lattice_overflow_rows(const tln_lattice_t* l);    /* rows that got index -1 in the last distribute */
 /* vertex keys [V,3] int32 (first d coordinates), for tests and the multi-GPU key exchange */
 int tln_lattice_keys(const tln_lattice_t* l, int32_t* d_keys_out, int64_t max_rows, void* stream);
@@ -90,14 +124,9 @@ int tln_distribute_begin_multi(const tln_distribute_call* calls, int n, void* st
 
 /* forget the bins of the last distribute (the caller edited d_distributed in place): the next pool goes through a CSR */
 int tln_lattice_drop_bins(tln_lattice_t* l);
-/* K1 variant for the distributes that follow (process-wide): 0 = partitioned (rows split by key hash into buckets owned
- * by one workgroup each, LDS atomics only; the default), 1 = one global atomic per row (also env TLN_K1_LEGACY=1; always
- * taken for val_dim > 1).  Same results bit for bit; a test / measurement switch. */
-int tln_distribute_config(int legacy);
-/* rows per bucket the partitioned kernels aim at (0 = default 512).  A bucket (one workgroup, a 1024-entry LDS table)
- * that meets more distinct keys than its table holds makes the library redo the frame with the per-row-atomic kernels
- * (same results); tln_lattice_bucket_fallbacks counts those frames.  Test / measurement hook. */
-int tln_distribute_bucket_rows(int rows);
+/* (K1 variant and bucket size: tln_options.k1_legacy / k1_bucket_rows via tln_lattice_set_options.)  A bucket (one
+ * workgroup, a 1024-entry LDS table) that meets more distinct keys than its table holds makes the library redo the frame
+ * with the per-row-atomic kernels (same results); tln_lattice_bucket_fallbacks counts those frames. */
 int64_t tln_lattice_bucket_fallbacks(const tln_lattice_t* l);
 
 /* build the vertex-sorted row list (CSR) from caller-supplied indices (R rows, -1 folded into the tail bucket) */
@@ -110,10 +139,8 @@ int tln_lattice_csr(tln_lattice_t* l, int32_t* d_order, int32_t* d_sorted_vertex
                     int64_t* rows_out, void* stream);
 
 /* ---- K2 PointNet pool: PointNetSeqModule.forward lm:448-530 --------------------------- */
-/* Kernel choice for the 4-16-32-64 PointNet MLP pooled from the bins of the frame's distribute (process-wide):
- * 0 = all-VALU fma chains (default), 1 = layers 2 and 3 on the matrix cores (v_mfma_f32_32x32x2_f32 accumulates as the
- * same ascending fma chain: identical bits; also env TLN_POOL_MFMA=1).  A test / measurement switch. */
-int tln_pool_config(int mfma);
+/* (Kernel choice for the 4-16-32-64 PointNet MLP pooled from the bins of the frame's distribute: tln_options.pool_mode of
+ * the lattice handle; identical bits under every mode.) */
 
 /* per-row MLP (nr_layers linears, ReLU between) on distributed[:, :cin] then segment-max by
  * vertex with argmax, barycentric-of-argmax (with the lm:514 clamp quirk), <min_points mask.
@@ -205,9 +232,6 @@ int tln_gather_gemm_ex(int64_t M, int N, const tln_gemm_src* s0, const tln_gemm_
                        const float* d_w, int w_is_nk, const float* d_bias, const float* d_residual,
                        int64_t ld_res, int relu, float* d_out, int64_t ld_out, void* d_stats, void* stream);
 
-/* tuning hook: force the block tile of the tiled kernel (tn in {1,2}: 64 / 128 columns; 0 = heuristic; tm is ignored
- * since round 3: the 128-row tiles were removed, large M belongs to the gemm_v2 kernel) */
-void tln_gemm_force_tiles(int tm, int tn);
 /* Two independent products in one launch: for a host that steps two sequences in lock-step on one stream (the
  * frame program's pair mode, tln_program_run_pair).  Each call is what tln_gather_gemm_ex would take.  When both
  * are products of the same shape class (same N, K layout, channel counts, weight layout; M may differ) that take the
@@ -231,23 +255,9 @@ typedef struct {
 int tln_gather_gemm_pair(const tln_gemm_call* a, const tln_gemm_call* b, void* stream);
 /* the same for n = 1..8 calls (more than 8: one launch each) */
 int tln_gather_gemm_multi(const tln_gemm_call* calls, int n, void* stream);
-/* test hook: run tln_gather_gemm_pair as two separate launches (1) or as designed (0) */
-void tln_gemm_pair_disable(int off);
-/* tuning hook: force the number of K-groups per block (1, 2, 4; 0 = heuristic) for 64x64 tiles */
-void tln_gemm_force_groups(int groups);
-/* tuning hook: force the split-K slices over the grid and the tile height (wm: 1 = 32 rows, 2 = 64 rows) */
-void tln_gemm_force_splits(int splits, int wm);
-/* tuning hook: the small-M "direct" kernel (operands from global memory, no LDS tiles): 0 = heuristic,
- * 1 = whenever the shape is eligible (channels multiple of 32, aligned), -1 = never */
-void tln_gemm_force_direct(int mode);
-/* tuning hook: the large-M kernel (csrc/gemm_v2.hip: 128-row block tiles, operands staged once per block by LDS-DMA):
- * off: bit 0 switches it off, bit 2 the row orders / tap skipping, bit 3 = 64-row tiles for every shared 128-column
- * launch with the GroupNorm prologue, bit 4 = never (default: where they save a round of blocks); min_m > 0 sets the
- * smallest M that takes it (default 12288) */
-void tln_gemm_v2_config(int off, int64_t min_m);
-/* diagnostic hook: block (0,0,0) of every following gather-GEMM writes five s_memtime stamps (start, after the
- * index/GroupNorm prologue, after the K loop, after the reductions, end) to d_buf (5 x u64); NULL switches it off */
-void tln_gemm_debug_stamps(void* d_buf);
+/* the same under explicit kernel-selection options (NULL = defaults); tln_gather_gemm_opt = one call */
+int tln_gather_gemm_opt(const tln_gemm_call* call, const tln_options* opt, void* stream);
+int tln_gather_gemm_multi_opt(const tln_gemm_call* calls, int n, const tln_options* opt, void* stream);
 
 /* ---- backward of the gather-GEMM (training: train_ln.py:212-233 calls loss.backward() through these products) ------
  * dW [taps*cin, N] (the [K, N] layout of lm:291; a Linear's [N, K] gradient is its transpose) =
@@ -307,6 +317,10 @@ typedef struct {
 int tln_gn_gather_gemm(const tln_gn_desc* gn, int64_t M, int N, const tln_gemm_src* s0, const tln_gemm_src* s1,
                        const float* d_w, int w_is_nk, const float* d_bias, const float* d_residual,
                        int64_t ld_res, int relu, float* d_out, int64_t ld_out, void* d_stats, void* stream);
+int tln_gn_gather_gemm_opt(const tln_gn_desc* gn, int64_t M, int N, const tln_gemm_src* s0, const tln_gemm_src* s1,
+                           const float* d_w, int w_is_nk, const float* d_bias, const float* d_residual,
+                           int64_t ld_res, int relu, float* d_out, int64_t ld_out, void* d_stats,
+                           const tln_options* opt, void* stream);
 int tln_affine_act(const float* d_x, int64_t V, int C, const float* d_scale, const float* d_shift,
                    int relu, float* d_out, void* stream);
 
@@ -328,6 +342,12 @@ typedef struct {
 } tln_gru_call;
 int tln_gru_cell_multi(const tln_gru_call* calls, int n, int C, const float* d_w_ih, const float* d_w_hh,
                        const float* d_b_ih, const float* d_b_hh, void* stream);
+/* both under explicit kernel-selection options (NULL = defaults: the entry points above) */
+int tln_gru_cell_opt(const float* d_x, const float* d_h, int64_t V, int64_t Vh, int C, const float* d_w_ih,
+                     const float* d_w_hh, const float* d_b_ih, const float* d_b_hh, float* d_out,
+                     float* d_ws /* [V,6C] */, int64_t ws_floats, const tln_options* opt, void* stream);
+int tln_gru_cell_multi_opt(const tln_gru_call* calls, int n, int C, const float* d_w_ih, const float* d_w_hh,
+                           const float* d_b_ih, const float* d_b_hh, const tln_options* opt, void* stream);
 
 /* ---- element-wise steps of the alternative fusion modules (rnn_modules = lstm / maxpool / cga, lm:17-185) ---- */
 /* LSTMModule lm:36-38: gates [V,4C] in torch LSTMCell order i|f|g|o, zero cell state: out = sig(o)*tanh(sig(i)*tanh(g)) */
@@ -565,9 +585,12 @@ int tln_program_run_pair(tln_program_t* a, tln_program_t* b, int early, float* d
 /* the same for a group of n = 1..8 programs (tln_gather_gemm_multi) */
 int tln_program_run_group(tln_program_t* const* programs, int n, int early, float* const* d_out,
                           const int64_t* out_rows, int out_cols, void* stream);
-/* test / measurement switch for group mode: bit k of off_mask set = ops of kind k (TLN_OP_*) are launched per program
- * instead of as one batch for the group; bit 0 = the K1 / coarse-level / table batches.  0 = everything batched. */
-int tln_program_group_config(int off_mask);
+/* copies *opt (NULL: the defaults) into the program: every product / GRU cell it issues is selected under it, group mode
+ * batches what opt->group_off_mask leaves (a group follows its first program's options) */
+int tln_program_set_options(tln_program_t* p, const tln_options* opt);
+/* device memory the program owns, in bytes: out[0] arena of the frame's temporaries (capacity), [1] its high-water mark in
+ * the last frame, [2] the K1 output buffer, [3] the hidden-state buffers, [4] total of 0, 2, 3 */
+int tln_program_memory(const tln_program_t* p, int64_t* out /* [5] */);
 /* device pointers of the current frame's K1 outputs ([4N, 3+val_dim+1], [4N], [4N]); valid until the next frame */
 int tln_program_frame_rows(tln_program_t* p, const float** d_distributed, const int32_t** d_indices,
                            const float** d_weights, int64_t* rows, int* cols);

@@ -32,6 +32,14 @@ class GemmCall(C.Structure):
     ]
 
 
+class Options(C.Structure):
+    """tln_options: kernel-selection options, stored in a handle or passed with a call (never process-wide)"""
+    _fields_ = [("k1_legacy", C.c_int), ("k1_bucket_rows", C.c_int), ("pool_mode", C.c_int), ("gemm_direct", C.c_int),
+                ("gemm_pair_off", C.c_int), ("gemm_tn", C.c_int), ("gemm_groups", C.c_int), ("gemm_splits", C.c_int),
+                ("gemm_wm", C.c_int), ("v2_off", C.c_int), ("v2_min_m", C.c_int64), ("gemm_stamps", C.c_void_p),
+                ("group_off_mask", C.c_int)]
+
+
 class GnDesc(C.Structure):
     _fields_ = [
         ("d_partials", C.c_void_p), ("d_x", C.c_void_p), ("V", C.c_int64), ("C", C.c_int), ("groups", C.c_int),
@@ -76,6 +84,16 @@ _PROTOS = {
     "tln_lattice_default_scale_constant": (C.c_double, []),
     "tln_lattice_scale_constant": (C.c_double, [_vp]),
     "tln_lattice_destroy": (_i, [_vp]),
+    "tln_lattice_memory": (_i, [_vp, C.POINTER(_i64)]),
+    "tln_program_memory": (_i, [_vp, C.POINTER(_i64)]),
+    "tln_options_init": (None, [C.POINTER(Options)]),
+    "tln_lattice_set_options": (_i, [_vp, C.POINTER(Options)]),
+    "tln_program_set_options": (_i, [_vp, C.POINTER(Options)]),
+    "tln_gather_gemm_opt": (_i, [C.POINTER(GemmCall), C.POINTER(Options), _vp]),
+    "tln_gather_gemm_multi_opt": (_i, [C.POINTER(GemmCall), _i, C.POINTER(Options), _vp]),
+    "tln_gn_gather_gemm_opt": (_i, [C.POINTER(GnDesc), _i64, _i, C.POINTER(GemmSrc), C.POINTER(GemmSrc), _vp, _i, _vp, _vp, _i64, _i, _vp, _i64, _vp, C.POINTER(Options), _vp]),
+    "tln_gru_cell_opt": (_i, [_vp, _vp, _i64, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, C.POINTER(Options), _vp]),
+    "tln_gru_cell_multi_opt": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, C.POINTER(Options), _vp]),
     "tln_lattice_clear": (_i, [_vp, _vp]),
     "tln_lattice_clear_multi": (_i, [_vp, _i, _vp]),
     "tln_distribute_begin_multi": (_i, [_vp, _i, _vp]),
@@ -90,16 +108,12 @@ _PROTOS = {
     "tln_slice_blend_bwd_lv": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp, _i64, _vp, _vp]),
     "tln_slice_blend_bwd_w": (_i, [_vp, _i64, _i, _vp, _vp, _i64, _vp, _vp]),
     "tln_pointnet_pool_multi": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp]),
-    "tln_program_group_config": (_i, [_i]),
     "tln_program_begin_frame_group": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "tln_lattice_nr_vertices": (_i64, [_vp]),
     "tln_lattice_capacity": (_i64, [_vp]),
     "tln_lattice_level": (_i, [_vp]),
     "tln_lattice_overflow_rows": (_i64, [_vp]),
     "tln_lattice_drop_bins": (_i, [_vp]),
-    "tln_distribute_config": (_i, [_i]),
-    "tln_pool_config": (_i, [_i]),
-    "tln_distribute_bucket_rows": (_i, [_i]),
     "tln_lattice_bucket_fallbacks": (_i64, [_vp]),
     "tln_lattice_keys": (_i, [_vp, _vp, _i64, _vp]),
     "tln_lattice_insert_keys": (_i, [_vp, _vp, _i64, _vp, _vp]),
@@ -119,15 +133,8 @@ _PROTOS = {
     "tln_coarse_to_fine_table": (_i, [_vp, C.POINTER(_vp), _vp]),
     "tln_fine_to_coarse_table": (_i, [_vp, C.POINTER(_vp), _vp]),
     "tln_gather_gemm": (_i, [_i64, _i, C.POINTER(GemmSrc), C.POINTER(GemmSrc), _vp, _i, _vp, _vp, _i64, _i, _vp, _i64, _vp]),
-    "tln_gemm_force_tiles": (None, [_i, _i]),
-    "tln_gemm_force_groups": (None, [_i]),
-    "tln_gemm_force_splits": (None, [_i, _i]),
-    "tln_gemm_force_direct": (None, [_i]),
-    "tln_gemm_v2_config": (None, [_i, _i64]),
     "tln_gather_gemm_pair": (_i, [C.POINTER(GemmCall), C.POINTER(GemmCall), _vp]),
     "tln_gather_gemm_multi": (_i, [C.POINTER(GemmCall), _i, _vp]),
-    "tln_gemm_pair_disable": (None, [_i]),
-    "tln_gemm_debug_stamps": (None, [_vp]),
     "tln_gather_gemm_ex": (_i, [_i64, _i, C.POINTER(GemmSrc), C.POINTER(GemmSrc), _vp, _i, _vp, _vp, _i64, _i, _vp, _i64, _vp, _vp]),
     "tln_gn_gather_gemm": (_i, [C.POINTER(GnDesc), _i64, _i, C.POINTER(GemmSrc), C.POINTER(GemmSrc), _vp, _i, _vp, _vp, _i64, _i, _vp, _i64, _vp, _vp]),
     "tln_groupnorm_partials": (_i, [_vp, _i64, _i, _vp, _vp]),

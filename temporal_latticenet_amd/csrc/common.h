@@ -8,6 +8,7 @@
 #define TLN_WAVE 64
 
 void tln_set_error(const char* fmt, ...);
+const tln_options& tln_opt(const tln_options* o);   // *o, or the immutable defaults for NULL (gemm.hip)
 
 #define TLN_HIP(call)                                                                   \
   do {                                                                                  \
@@ -133,6 +134,7 @@ struct TlnBins {
   int stamp;               // (NULL: every vertex was visited)
 };
 bool tln_lat_bins(const tln_lattice* l, const float* d_distributed, int64_t rows, TlnBins* out);
+const tln_options& tln_lat_options(const tln_lattice* l);   // the handle's kernel-selection options (tln_lattice_set_options)
 
 // ---- key packing / hashing (d = 3) ------------------------------------------------------
 #define TLN_KEY_BIAS (1 << 20)

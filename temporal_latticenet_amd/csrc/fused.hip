@@ -260,9 +260,10 @@ __global__ void __launch_bounds__(256) k_gru_gates(const float* __restrict__ gi,
   out[i] = tln_gru_cell_value(a[c] + b[c], a[C + c] + b[C + c], a[2 * C + c], b[2 * C + c], hp);   // common.h: one arithmetic
 }
 
-extern "C" int tln_gru_cell(const float* d_x, const float* d_h, int64_t V, int64_t Vh, int C, const float* d_w_ih,
-                            const float* d_w_hh, const float* d_b_ih, const float* d_b_hh, float* d_out, float* d_ws,
-                            int64_t ws_floats, void* stream_) {
+extern "C" int tln_gru_cell_opt(const float* d_x, const float* d_h, int64_t V, int64_t Vh, int C, const float* d_w_ih,
+                                const float* d_w_hh, const float* d_b_ih, const float* d_b_hh, float* d_out, float* d_ws,
+                                int64_t ws_floats, const tln_options* opt, void* stream_) {
+  const tln_options& o = tln_opt(opt);
   TLN_REQUIRE(d_x && d_h && d_w_ih && d_w_hh && d_out && d_ws, "null argument");
   TLN_REQUIRE(V > 0 && Vh >= 0 && Vh <= V && C > 0, "bad GRU shape V=%lld Vh=%lld C=%d", (long long)V, (long long)Vh, C);
   TLN_REQUIRE(ws_floats >= V * 6 * (int64_t)C, "GRU workspace too small");
@@ -281,7 +282,7 @@ extern "C" int tln_gru_cell(const float* d_x, const float* d_h, int64_t V, int64
   const tln_gemm_call ci{V, 3 * C, &sx, nullptr, d_w_ih, 1, d_b_ih, nullptr, 0, 0, gi, 3 * (int64_t)C, nullptr};
   // large lattices: the whole cell as ONE two-source product with the gates in its epilogue — neither gi nor gh in
   // memory, no gates kernel (gemm_v2.hip); rows and channels must be 16-byte aligned as for every gemm_v2 launch
-  if (tln_gemm_v2_gru_ok(V, Vh, C) && d_b_ih && d_b_hh && ((uintptr_t)d_x % 16 == 0) && ((uintptr_t)d_h % 16 == 0) &&
+  if (tln_gemm_v2_gru_ok(V, Vh, C, o) && d_b_ih && d_b_hh && ((uintptr_t)d_x % 16 == 0) && ((uintptr_t)d_h % 16 == 0) &&
       ((uintptr_t)d_w_ih % 16 == 0) && ((uintptr_t)d_w_hh % 16 == 0)) {
     int rc = tln_gemm_v2_launch_gru(d_x, d_h, Vh, V, C, d_w_ih, d_w_hh, d_b_ih, d_b_hh, d_out, (hipStream_t)stream_);
     if (rc) return rc;
@@ -290,7 +291,8 @@ extern "C" int tln_gru_cell(const float* d_x, const float* d_h, int64_t V, int64
   }
   // the two products have the same shape: one launch (blockIdx.z = product) when they take the small-M kernel
   const tln_gemm_call ch{V, 3 * C, &sh, nullptr, d_w_hh, 1, d_b_hh, nullptr, 0, 0, gh, 3 * (int64_t)C, nullptr};
-  int rc = tln_gather_gemm_pair(&ci, &ch, stream_);
+  const tln_gemm_call two[2] = {ci, ch};
+  int rc = tln_gather_gemm_multi_opt(two, 2, &o, stream_);
   if (rc) return rc;
   const int64_t total = V * C;
   hipLaunchKernelGGL(k_gru_gates, dim3((unsigned)tln_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream_, gi, gh, d_h,
@@ -301,13 +303,20 @@ extern "C" int tln_gru_cell(const float* d_x, const float* d_h, int64_t V, int64
 
 // the GRU cells of n lock-stepped sequences (same weights): ONE launch of the fused cell kernel (blockIdx.z = sequence)
 // when every lattice is large enough for it, else one tln_gru_cell per sequence
-extern "C" int tln_gru_cell_multi(const tln_gru_call* c, int n, int C, const float* d_w_ih, const float* d_w_hh,
-                                  const float* d_b_ih, const float* d_b_hh, void* stream_) {
+extern "C" int tln_gru_cell(const float* d_x, const float* d_h, int64_t V, int64_t Vh, int C, const float* d_w_ih,
+                            const float* d_w_hh, const float* d_b_ih, const float* d_b_hh, float* d_out, float* d_ws,
+                            int64_t ws_floats, void* stream_) {
+  return tln_gru_cell_opt(d_x, d_h, V, Vh, C, d_w_ih, d_w_hh, d_b_ih, d_b_hh, d_out, d_ws, ws_floats, nullptr, stream_);
+}
+
+extern "C" int tln_gru_cell_multi_opt(const tln_gru_call* c, int n, int C, const float* d_w_ih, const float* d_w_hh,
+                                      const float* d_b_ih, const float* d_b_hh, const tln_options* opt, void* stream_) {
   TLN_REQUIRE(c && n >= 1 && d_w_ih && d_w_hh && C > 0, "bad GRU batch");
+  const tln_options& o = tln_opt(opt);
   bool fused = n >= 2 && n <= TLN_GEMM_MULTI_MAX && d_b_ih && d_b_hh && ((uintptr_t)d_w_ih % 16 == 0) &&
                ((uintptr_t)d_w_hh % 16 == 0);
   for (int i = 0; i < n && fused; ++i)
-    fused = c[i].d_x && c[i].d_h && c[i].d_out && tln_gemm_v2_gru_ok(c[i].V, c[i].Vh, C) && ((uintptr_t)c[i].d_x % 16 == 0) &&
+    fused = c[i].d_x && c[i].d_h && c[i].d_out && tln_gemm_v2_gru_ok(c[i].V, c[i].Vh, C, o) && ((uintptr_t)c[i].d_x % 16 == 0) &&
             ((uintptr_t)c[i].d_h % 16 == 0);
   if (fused) {
     const float* x[TLN_GEMM_MULTI_MAX];
@@ -327,11 +336,16 @@ extern "C" int tln_gru_cell_multi(const tln_gru_call* c, int n, int C, const flo
     return TLN_OK;
   }
   for (int i = 0; i < n; ++i) {
-    int rc = tln_gru_cell(c[i].d_x, c[i].d_h, c[i].V, c[i].Vh, C, d_w_ih, d_w_hh, d_b_ih, d_b_hh, c[i].d_out, c[i].d_ws,
-                          c[i].ws_floats, stream_);
+    int rc = tln_gru_cell_opt(c[i].d_x, c[i].d_h, c[i].V, c[i].Vh, C, d_w_ih, d_w_hh, d_b_ih, d_b_hh, c[i].d_out, c[i].d_ws,
+                              c[i].ws_floats, &o, stream_);
     if (rc) return rc;
   }
   return TLN_OK;
+}
+
+extern "C" int tln_gru_cell_multi(const tln_gru_call* c, int n, int C, const float* d_w_ih, const float* d_w_hh,
+                                  const float* d_b_ih, const float* d_b_hh, void* stream_) {
+  return tln_gru_cell_multi_opt(c, n, C, d_w_ih, d_w_hh, d_b_ih, d_b_hh, nullptr, stream_);
 }
 
 // =======================================================================================
@@ -892,10 +906,10 @@ extern "C" int tln_scatter_add(const float* d_src, const int64_t* d_index, int64
 // followed by the gather-GEMM that applies them in its operand staging.  One call from the host instead of two or
 // three: on a lattice of a few thousand vertices the host-side launch path is the bottleneck, not the kernels.
 // =======================================================================================
-extern "C" int tln_gn_gather_gemm(const tln_gn_desc* gn, int64_t M, int N, const tln_gemm_src* s0,
-                                  const tln_gemm_src* s1, const float* d_w, int w_is_nk, const float* d_bias,
-                                  const float* d_residual, int64_t ld_res, int relu, float* d_out, int64_t ld_out,
-                                  void* d_stats, void* stream_) {
+extern "C" int tln_gn_gather_gemm_opt(const tln_gn_desc* gn, int64_t M, int N, const tln_gemm_src* s0,
+                                      const tln_gemm_src* s1, const float* d_w, int w_is_nk, const float* d_bias,
+                                      const float* d_residual, int64_t ld_res, int relu, float* d_out, int64_t ld_out,
+                                      void* d_stats, const tln_options* opt, void* stream_) {
   TLN_REQUIRE(gn && s0, "null argument");
   const void* partials = gn->d_partials;
   if (!partials) {  // the tensor did not come out of a gather-GEMM: one pass for the partial sums
@@ -915,6 +929,14 @@ extern "C" int tln_gn_gather_gemm(const tln_gn_desc* gn, int64_t M, int N, const
   a.gn_rows = gn->V;
   a.gn_groups = gn->groups;
   a.gn_eps = gn->eps;
-  return tln_gather_gemm_ex(M, N, &a, s1, d_w, w_is_nk, d_bias, d_residual, ld_res, relu, d_out, ld_out, d_stats,
-                            stream_);
+  const tln_gemm_call call{M, N, &a, s1, d_w, w_is_nk, d_bias, d_residual, ld_res, relu, d_out, ld_out, d_stats};
+  return tln_gather_gemm_opt(&call, opt, stream_);
+}
+
+extern "C" int tln_gn_gather_gemm(const tln_gn_desc* gn, int64_t M, int N, const tln_gemm_src* s0,
+                                  const tln_gemm_src* s1, const float* d_w, int w_is_nk, const float* d_bias,
+                                  const float* d_residual, int64_t ld_res, int relu, float* d_out, int64_t ld_out,
+                                  void* d_stats, void* stream_) {
+  return tln_gn_gather_gemm_opt(gn, M, N, s0, s1, d_w, w_is_nk, d_bias, d_residual, ld_res, relu, d_out, ld_out, d_stats,
+                                nullptr, stream_);
 }

@@ -1015,25 +1015,22 @@ static int launch_direct(GemmArgs& g, int nchunks, int groups, hipStream_t s) {
   return TLN_OK;
 }
 
-// optional overrides for tuning / tests (0 = heuristic)
-static int g_force_direct = 0;  // 0 heuristic, 1 always when eligible, -1 never
-static int g_pair_off = 0;      // tests: tln_gather_gemm_pair as two separate launches
-extern "C" void tln_gemm_pair_disable(int off) { g_pair_off = off; }
-extern "C" void tln_gemm_force_direct(int mode) { g_force_direct = mode; }
-static int g_force_tm = 0, g_force_tn = 0, g_force_groups = 0, g_force_splits = 0, g_force_wm = 0;
-static unsigned long long* g_dbg = nullptr;
-extern "C" void tln_gemm_debug_stamps(void* d_buf) { g_dbg = reinterpret_cast<unsigned long long*>(d_buf); }
-extern "C" void tln_gemm_force_tiles(int tm, int tn) {
-  g_force_tm = tm;
-  g_force_tn = tn;
+// (tuning / test overrides: fields of the caller's tln_options, include/tln.h — no file-scope switches)
+const tln_options& tln_opt(const tln_options* o) {
+  static const tln_options defaults = [] {
+    tln_options d;
+    tln_options_init(&d);
+    return d;
+  }();
+  return o ? *o : defaults;
 }
-extern "C" void tln_gemm_force_groups(int groups) { g_force_groups = groups; }
-extern "C" void tln_gemm_force_splits(int splits, int wm) {
-  g_force_splits = splits;
-  g_force_wm = wm;
+extern "C" void tln_options_init(tln_options* o) {
+  if (!o) return;
+  *o = tln_options{};
+  o->pool_mode = -1;
 }
 
-static Plan make_plan(int64_t M, int N, int nchunks) {
+static Plan make_plan(int64_t M, int N, int nchunks, const tln_options& o) {
   Plan p{2, 1, 1, 1, 1};
   auto nblk = [&](int bm, int bn) { return tln_cdiv(M, bm) * tln_cdiv(N, bn); };
   // large M (fine lattices, accumulated clouds): measured on MI355X (tools/gemm_bench_large.py, M = 168k) the
@@ -1054,10 +1051,10 @@ static Plan make_plan(int64_t M, int N, int nchunks) {
     const int per = (nchunks + splits - 1) / splits;
     p.groups = splits == 1 ? (per >= 8 ? 4 : (per >= 4 ? 2 : 1)) : (per >= 4 ? 2 : 1);
   }
-  if (g_force_tn) p.tn = g_force_tn;
-  if (g_force_wm) p.wm = g_force_wm;
-  if (g_force_groups) p.groups = g_force_groups;
-  if (g_force_splits) p.splits = g_force_splits;
+  if (o.gemm_tn) p.tn = o.gemm_tn;
+  if (o.gemm_wm) p.wm = o.gemm_wm;
+  if (o.gemm_groups) p.groups = o.gemm_groups;
+  if (o.gemm_splits) p.splits = o.gemm_splits;
   if (p.tn == 2) p.wm = 2;
   if (p.wm == 2) p.groups = 1;
   if (p.splits > nchunks) p.splits = nchunks > 0 ? nchunks : 1;
@@ -1074,7 +1071,7 @@ struct Prep {
 
 static int prepare_gemm(int64_t M, int N, const tln_gemm_src* s0, const tln_gemm_src* s1, const float* d_w, int w_is_nk,
                         const float* d_bias, const float* d_residual, int64_t ld_res, int relu, float* d_out,
-                        int64_t ld_out, void* d_stats, Prep& q) {
+                        int64_t ld_out, void* d_stats, Prep& q, const tln_options& o) {
   TLN_REQUIRE(s0 && d_w && d_out, "null argument");
   TLN_REQUIRE(M > 0 && N > 0 && ld_out >= N, "bad gemm shape M=%lld N=%d", (long long)M, N);
   TLN_REQUIRE(tln_cdiv(M, 32) < (1ll << 31), "M too large");
@@ -1104,7 +1101,7 @@ static int prepare_gemm(int64_t M, int N, const tln_gemm_src* s0, const tln_gemm
   g.ld_out = ld_out;
   g.stats = reinterpret_cast<double2*>(d_stats);
   g.splits = 1;
-  g.dbg = g_dbg;
+  g.dbg = reinterpret_cast<unsigned long long*>(o.gemm_stamps);
 
   bool vec = aligned16(d_w);
   for (int i = 0; i < g.nsrc; ++i) {
@@ -1119,7 +1116,7 @@ static int prepare_gemm(int64_t M, int N, const tln_gemm_src* s0, const tln_gemm
   const int bk = q.bk32 ? 32 : 16;
   q.nchunks = 0;
   for (int i = 0; i < g.nsrc; ++i) q.nchunks += g.s[i].taps * ((g.s[i].cin + bk - 1) / bk);
-  q.p = make_plan(M, N, q.nchunks);
+  q.p = make_plan(M, N, q.nchunks, o);
   // small M: one wave per 32x32 tile and K subset, operands straight from global memory
   const int64_t lim2g = (1ll << 31) - 4096;   // (the direct kernel addresses sources and weights by 32-bit buffer offsets)
   bool direct_ok = vec && q.bk32 && g.s[0].cin <= 1024 && tln_cdiv(N, 32) <= 65535 && M < (1ll << 31) &&
@@ -1132,10 +1129,9 @@ static int prepare_gemm(int64_t M, int N, const tln_gemm_src* s0, const tln_gemm
     if (i > 0) direct_ok = direct_ok && d.scale == nullptr;  // only source 0 carries a prologue there
   }
   const bool direct_small = q.p.wm == 1;
-  q.direct = direct_ok && g_force_direct >= 0 && (direct_small || g_force_direct > 0);
+  q.direct = direct_ok && o.gemm_direct >= 0 && (direct_small || o.gemm_direct > 0);
   // large M: 128-row block tiles with both operands staged once per block (gemm_v2.hip); not under the tuning overrides
-  q.v2 = g_force_direct == 0 && !g_force_tm && !g_force_tn && !g_force_groups && !g_force_splits &&
-         tln_gemm_v2_ok(g, w_is_nk != 0, vec);
+  q.v2 = o.gemm_direct == 0 && !o.gemm_tn && !o.gemm_groups && !o.gemm_splits && tln_gemm_v2_ok(g, w_is_nk != 0, vec, o);
   if (q.v2) {
     q.direct = false;
     q.gn_fallback = g.s[0].gn_part != nullptr;   // statistics finalised by their own (parallel) launch
@@ -1144,8 +1140,8 @@ static int prepare_gemm(int64_t M, int N, const tln_gemm_src* s0, const tln_gemm
 }
 
 // waves per 32x32 tile of the direct kernel
-static int choose_groups(int64_t tiles, int nchunks) {
-  if (g_force_groups) return g_force_groups;
+static int choose_groups(int64_t tiles, int nchunks, const tln_options& o) {
+  if (o.gemm_groups) return o.gemm_groups;
   int G = 1;
   if (tiles <= 256) {
     // at most one block per CU: the fewest chunks per wave (down to 2: both in flight before the first MFMA)
@@ -1178,16 +1174,16 @@ static int choose_groups(int64_t tiles, int nchunks) {
   return G;
 }
 
-extern "C" int tln_gather_gemm_ex(int64_t M, int N, const tln_gemm_src* s0, const tln_gemm_src* s1, const float* d_w,
-                                  int w_is_nk, const float* d_bias, const float* d_residual, int64_t ld_res, int relu,
-                                  float* d_out, int64_t ld_out, void* d_stats, void* stream_) {
+static int gather_gemm_one(int64_t M, int N, const tln_gemm_src* s0, const tln_gemm_src* s1, const float* d_w,
+                           int w_is_nk, const float* d_bias, const float* d_residual, int64_t ld_res, int relu,
+                           float* d_out, int64_t ld_out, void* d_stats, const tln_options& o, void* stream_) {
   TLN_REQUIRE(M >= 0, "bad gemm shape M=%lld", (long long)M);
   if (M == 0) {
     TLN_REQUIRE(s0 && d_w && d_out && N > 0 && ld_out >= N, "bad gemm arguments");
     return TLN_OK;
   }
   Prep q;
-  int rc = prepare_gemm(M, N, s0, s1, d_w, w_is_nk, d_bias, d_residual, ld_res, relu, d_out, ld_out, d_stats, q);
+  int rc = prepare_gemm(M, N, s0, s1, d_w, w_is_nk, d_bias, d_residual, ld_res, relu, d_out, ld_out, d_stats, q, o);
   if (rc) return rc;
   GemmArgs& g = q.g;
   hipStream_t s = (hipStream_t)stream_;
@@ -1200,7 +1196,7 @@ extern "C" int tln_gather_gemm_ex(int64_t M, int N, const tln_gemm_src* s0, cons
     g.s[0].gn_part = nullptr;
   }
   if (q.v2) {
-    rc = tln_gemm_v2_launch(g, w_is_nk != 0, s);
+    rc = tln_gemm_v2_launch(g, w_is_nk != 0, s, o);
     if (rc) return rc;
     TLN_LAUNCH_CHECK();
     return TLN_OK;
@@ -1213,7 +1209,7 @@ extern "C" int tln_gather_gemm_ex(int64_t M, int N, const tln_gemm_src* s0, cons
   }
   if (q.direct) {
     const int64_t tiles = tln_cdiv(M, 32) * tln_cdiv(N, 32);
-    const int G = choose_groups(tiles, q.nchunks);
+    const int G = choose_groups(tiles, q.nchunks, o);
     rc = w_is_nk ? launch_direct<true>(g, q.nchunks, G, s) : launch_direct<false>(g, q.nchunks, G, s);
     if (rc) return rc;
     TLN_LAUNCH_CHECK();
@@ -1226,9 +1222,9 @@ extern "C" int tln_gather_gemm_ex(int64_t M, int N, const tln_gemm_src* s0, cons
   return TLN_OK;
 }
 
-static int run_call(const tln_gemm_call* c, void* stream_) {
-  return tln_gather_gemm_ex(c->M, c->N, c->s0, c->s1, c->d_w, c->w_is_nk, c->d_bias, c->d_residual, c->ld_res, c->relu,
-                            c->d_out, c->ld_out, c->d_stats, stream_);
+static int run_call(const tln_gemm_call* c, const tln_options& o, void* stream_) {
+  return gather_gemm_one(c->M, c->N, c->s0, c->s1, c->d_w, c->w_is_nk, c->d_bias, c->d_residual, c->ld_res, c->relu,
+                         c->d_out, c->ld_out, c->d_stats, o, stream_);
 }
 
 template <bool W_NK, int NP>
@@ -1244,14 +1240,15 @@ static int launch_multi(const Prep* q, int n, int G, size_t lds, int64_t mt, hip
   return TLN_OK;
 }
 
-extern "C" int tln_gather_gemm_multi(const tln_gemm_call* calls, int n, void* stream_) {
+extern "C" int tln_gather_gemm_multi_opt(const tln_gemm_call* calls, int n, const tln_options* opt, void* stream_) {
   TLN_REQUIRE(calls && n >= 1, "bad multi-gemm arguments");
+  const tln_options& o = tln_opt(opt);
   auto one_by_one = [&]() {
     int rc = TLN_OK;
-    for (int i = 0; i < n && !rc; ++i) rc = run_call(&calls[i], stream_);
+    for (int i = 0; i < n && !rc; ++i) rc = run_call(&calls[i], o, stream_);
     return rc;
   };
-  if (n == 1 || n > TLN_GEMM_MULTI_MAX || g_pair_off) {
+  if (n == 1 || n > TLN_GEMM_MULTI_MAX || o.gemm_pair_off) {
     if (getenv("TLN_MULTI_DEBUG") && n == 1)
       fprintf(stderr, "multi n=1: M=%ld N=%d cin=%d taps=%d\n", (long)calls[0].M, calls[0].N, calls[0].s0->cin, calls[0].s0->taps);
     return one_by_one();
@@ -1262,7 +1259,7 @@ extern "C" int tln_gather_gemm_multi(const tln_gemm_call* calls, int n, void* st
   for (int i = 0; i < n; ++i) {
     const tln_gemm_call& c = calls[i];
     int rc = prepare_gemm(c.M, c.N, c.s0, c.s1, c.d_w, c.w_is_nk, c.d_bias, c.d_residual, c.ld_res, c.relu, c.d_out,
-                          c.ld_out, c.d_stats, q[i]);
+                          c.ld_out, c.d_stats, q[i], o);
     if (rc) return rc;
   }
   // GroupNorm statistics a kernel will not finalise in its own prologue (every product bound for gemm_v2: `all`; else
@@ -1296,7 +1293,7 @@ extern "C" int tln_gather_gemm_multi(const tln_gemm_call* calls, int n, void* st
   };
   // products of one shape class whose rows together reach the large-M kernel's range (the coarse levels of lock-stepped
   // sequences: 4 x 8.9k rows): one gemm_v2 launch, blockIdx.z = product
-  if (g_force_direct == 0 && !g_force_tm && !g_force_tn && !g_force_groups && !g_force_splits) {
+  if (o.gemm_direct == 0 && !o.gemm_tn && !o.gemm_groups && !o.gemm_splits) {
     GemmArgs gs[TLN_GEMM_MULTI_MAX];
     bool vecs[TLN_GEMM_MULTI_MAX];
     bool mixed = false;
@@ -1305,7 +1302,7 @@ extern "C" int tln_gather_gemm_multi(const tln_gemm_call* calls, int n, void* st
       vecs[i] = q[i].vec;
       if (calls[i].w_is_nk != calls[0].w_is_nk) mixed = true;
     }
-    if (!mixed && tln_gemm_v2_multi_ok(gs, n, calls[0].w_is_nk != 0, vecs)) {
+    if (!mixed && tln_gemm_v2_multi_ok(gs, n, calls[0].w_is_nk != 0, vecs, o)) {
       hipStream_t s = (hipStream_t)stream_;
       // as before a single gemm_v2 launch: the GroupNorm scale / shift of the sources, all in ONE launch
       {
@@ -1313,7 +1310,7 @@ extern "C" int tln_gather_gemm_multi(const tln_gemm_call* calls, int n, void* st
         if (rc) return rc;
         for (int i = 0; i < n; ++i) gs[i] = q[i].g;
       }
-      int rc = tln_gemm_v2_launch_multi(gs, n, calls[0].w_is_nk != 0, s);
+      int rc = tln_gemm_v2_launch_multi(gs, n, calls[0].w_is_nk != 0, s, o);
       if (rc) return rc;
       TLN_LAUNCH_CHECK();
       return TLN_OK;
@@ -1348,7 +1345,7 @@ extern "C" int tln_gather_gemm_multi(const tln_gemm_call* calls, int n, void* st
   }
   hipStream_t s = (hipStream_t)stream_;
   // waves per tile from the work of ALL problems (they share the CUs)
-  int G = choose_groups(tiles, q[0].nchunks);
+  int G = choose_groups(tiles, q[0].nchunks, o);
   if (G < 1) G = 1;
   if (G > 12) G = 12;
   if (G > q[0].nchunks) G = q[0].nchunks;
@@ -1371,10 +1368,26 @@ extern "C" int tln_gather_gemm_multi(const tln_gemm_call* calls, int n, void* st
   return TLN_OK;
 }
 
+extern "C" int tln_gather_gemm_multi(const tln_gemm_call* calls, int n, void* stream_) {
+  return tln_gather_gemm_multi_opt(calls, n, nullptr, stream_);
+}
+
 extern "C" int tln_gather_gemm_pair(const tln_gemm_call* a, const tln_gemm_call* b, void* stream_) {
   TLN_REQUIRE(a && b, "null call");
   const tln_gemm_call two[2] = {*a, *b};
-  return tln_gather_gemm_multi(two, 2, stream_);
+  return tln_gather_gemm_multi_opt(two, 2, nullptr, stream_);
+}
+
+extern "C" int tln_gather_gemm_opt(const tln_gemm_call* c, const tln_options* opt, void* stream_) {
+  TLN_REQUIRE(c, "null call");
+  return run_call(c, tln_opt(opt), stream_);
+}
+
+extern "C" int tln_gather_gemm_ex(int64_t M, int N, const tln_gemm_src* s0, const tln_gemm_src* s1, const float* d_w,
+                                  int w_is_nk, const float* d_bias, const float* d_residual, int64_t ld_res, int relu,
+                                  float* d_out, int64_t ld_out, void* d_stats, void* stream_) {
+  return gather_gemm_one(M, N, s0, s1, d_w, w_is_nk, d_bias, d_residual, ld_res, relu, d_out, ld_out, d_stats,
+                         tln_opt(nullptr), stream_);
 }
 
 extern "C" int tln_gather_gemm(int64_t M, int N, const tln_gemm_src* s0, const tln_gemm_src* s1, const float* d_w,

@@ -60,13 +60,14 @@ const int32_t* tln_table_tile_order(const int32_t* table, int64_t rows);
 
 // gemm_v2.hip: the large-M kernel (block tile 128 x N, operands staged by LDS-DMA).  tln_gemm_v2_ok decides from the
 // prepared arguments alone, so every route (operator call, frame program, lock-step group) takes the same kernel.
-bool tln_gemm_v2_ok(const GemmArgs& g, bool w_is_nk, bool vec);
-int tln_gemm_v2_launch(GemmArgs& g, bool w_is_nk, hipStream_t s);
+// (every decision takes the caller's tln_options explicitly: there is no file-scope switch)
+bool tln_gemm_v2_ok(const GemmArgs& g, bool w_is_nk, bool vec, const tln_options& o);
+int tln_gemm_v2_launch(GemmArgs& g, bool w_is_nk, hipStream_t s, const tln_options& o);
 // n products of one shape class whose rows TOGETHER make a large M (lock-stepped sequences on a coarse level): one launch
-bool tln_gemm_v2_multi_ok(const GemmArgs* g, int n, bool w_is_nk, const bool* vec);
-int tln_gemm_v2_launch_multi(GemmArgs* g, int n, bool w_is_nk, hipStream_t s);
+bool tln_gemm_v2_multi_ok(const GemmArgs* g, int n, bool w_is_nk, const bool* vec, const tln_options& o);
+int tln_gemm_v2_launch_multi(GemmArgs* g, int n, bool w_is_nk, hipStream_t s, const tln_options& o);
 // the GRU cell as one two-source product with the gates in its epilogue (large V, C a multiple of 64)
-bool tln_gemm_v2_gru_ok(int64_t V, int64_t Vh, int C);
+bool tln_gemm_v2_gru_ok(int64_t V, int64_t Vh, int C, const tln_options& o);
 int tln_gemm_v2_launch_gru(const float* d_x, const float* d_h, int64_t Vh, int64_t V, int C, const float* d_w_ih,
                            const float* d_w_hh, const float* d_b_ih, const float* d_b_hh, float* d_out, hipStream_t s);
 int tln_gemm_v2_launch_gru_multi(int n, const float* const* d_x, const float* const* d_h, const int64_t* Vh, const int64_t* V,

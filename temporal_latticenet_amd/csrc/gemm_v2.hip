@@ -32,8 +32,12 @@
 #include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x8 __attribute__((ext_vector_type(8)));
 
 #define V2_STAGES 3
+#ifndef V2_FOLD
+#define V2_FOLD 1   // split accumulation (see v2_body); 0: one chain over all of K (measurement builds)
+#endif
 
 // GRU = true (only <4,2,1,3, W_NK, !PRO>, N = 3C, C a multiple of 64): the whole GRU cell (K9) as ONE product with two
 // sources: the K loop runs over the C channels of x (weights W_ih, g.W) and then over the C channels of h (W_hh, g.W2;
@@ -232,6 +236,28 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
+  // Split accumulation (round 4).  One fp32 accumulation chain over all of K = taps * cin (1728 steps for 192 -> 192 x 9)
+  // carries ~sqrt(K / K_block) times the rounding noise of a blocked sum: measured against a float64 evaluation of the
+  // whole model (tools/parity64.py) the logits were 1.55 x as far from the truth as the fp32 CPU
+  // restatement's (whose GEMMs are K-blocked), 1.08 x with the K range in three partial sums, 0.82 x in nine.  So the
+  // accumulators are folded into `tot` whenever the chunk sequence crosses into another GROUP OF TAPS (V2_TAPS_PER_FOLD
+  // logical taps, ~192-256 k values) and restart from zero.  The groups are defined on the logical tap ids, not on the
+  // executed chunk count: a tap this block skips contributes an exact zero to its group's partial sum, so the result
+  // stays independent of the row order / tap skipping, as before.
+  // Only the [K,N]-weight instantiations fold: those are the 9-tap products (convolutions, coarsen, finefy); the [N,K]
+  // ones are 1 x 1 linears and GRU projections (K <= 2 x 256: a short chain) and keep their registers.
+  constexpr bool FOLD = !GRU && !W_NK && V2_FOLD;
+  f32x16 tot[FOLD ? TM : 1][FOLD ? TN : 1];
+  if constexpr (FOLD) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tot[i][j][r] = 0.0f;
+  }
+  const int fold_taps = s.cin >= 192 ? 1 : (s.cin >= 96 ? 2 : 3);   // taps per partial sum: 192..256 k values (uniform)
+
   const int arow0 = wm * 32 * TM + l31;       // this lane's A row of tile 0 inside the block
   const int bcol0 = wn * 32 * TN + l31;       // this lane's B column of tile 0 inside the block
 
@@ -371,6 +397,30 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
     constexpr int st = decltype(stage)::value;
     constexpr int stn = st == STAGES - 1 ? 0 : st + 1;
     const int ti = t / cpt;
+    if constexpr (FOLD) {
+      // first chunk of a tap whose group differs from the previous present tap's: fold (uniform branch, once per group)
+      if (t > 0 && t == ti * cpt) {
+        const int ga = __builtin_amdgcn_readfirstlane(Taps[ti]) / fold_taps, gb = __builtin_amdgcn_readfirstlane(Taps[1 + ti]) / fold_taps;
+        if (ga != gb) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              tot[i][j] += acc[i][j];
+              // (zeroed as eight 64-bit moves: left to the compiler it is sixteen 32-bit ones, and beside an fp32 MFMA
+              //  every vector instruction costs the matrix pipe ~3 cycles)
+              f64x8 z;
+#pragma unroll
+              for (int q = 0; q < 8; ++q) {
+                double d;
+                asm volatile("v_mov_b64_e32 %0, 0" : "=v"(d));
+                z[q] = d;
+              }
+              acc[i][j] = __builtin_bit_cast(f32x16, z);
+            }
+        }
+      }
+    }
     const unsigned gs_c0 = gs_lane + 8u * (unsigned)((t - ti * cpt) << 5);
     const int tn = t + 1 < nchunks ? t + 1 : nchunks - 1;
     const unsigned gs_c0n = gs_lane + 8u * (unsigned)((tn - (tn / cpt) * cpt) << 5);
@@ -461,6 +511,14 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
   }
 #endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the repeated DMAs of the last two rounds
+  if constexpr (FOLD) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = tot[i][j][r] + acc[i][j][r];
+  }
 
   // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).  The residual is loaded for a whole
   // 32x32 tile at once from clamped (always valid) addresses: a per-element "load or not" makes the compiler branch
@@ -555,8 +613,20 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
 #endif
 }
 
+// Waves per SIMD a tile must keep for the workgroups per CU its LDS footprint allows (two-stage rings): the 128 x 64 tile
+// three workgroups of eight waves (6 per SIMD: 80 registers), the 64-row tile three of four waves (3 per SIMD: 168).
+// Given to the compiler as the second launch bound: with the split accumulation's second accumulator set it would
+// otherwise settle a few registers above those steps and lose a workgroup per CU.
+template <int WM, int WN, int TM, int TN, int STAGES>
+constexpr int v2_min_waves() {
+  if (STAGES == 2 && WM == 4 && WN == 2 && TM == 1 && TN == 1) return 6;
+  if (STAGES == 2 && WM == 4 && WN == 2 && TM == 1 && TN == 2) return 4;
+  if (STAGES == 2 && WM == 2 && WN == 2 && TM == 1 && TN == 2) return 3;
+  return 1;
+}
+
 template <int WM, int WN, int TM, int TN, bool W_NK, bool PRO, int STAGES = V2_STAGES>
-__global__ void __launch_bounds__(64 * WM * WN) k_gather_gemm_v2(const GemmArgs g) {
+__global__ void __launch_bounds__(64 * WM * WN, (v2_min_waves<WM, WN, TM, TN, STAGES>())) k_gather_gemm_v2(const GemmArgs g) {
   v2_body<WM, WN, TM, TN, W_NK, PRO, false, STAGES>(g);
 }
 
@@ -576,7 +646,7 @@ __global__ void __launch_bounds__(512) k_gather_gemm_v2_gru_multi(const GemmArgs
 // several products of one shape class in one launch (blockIdx.z = product): the coarse levels of lock-stepped
 // sequences, whose rows only together fill the chip with 128-row tiles
 template <int WM, int WN, int TM, int TN, bool W_NK, bool PRO, int STAGES = V2_STAGES>
-__global__ void __launch_bounds__(64 * WM * WN) k_gather_gemm_v2_multi(const GemmArgsN<TLN_GEMM_MULTI_MAX> gg) {
+__global__ void __launch_bounds__(64 * WM * WN, (v2_min_waves<WM, WN, TM, TN, STAGES>())) k_gather_gemm_v2_multi(const GemmArgsN<TLN_GEMM_MULTI_MAX> gg) {
   const GemmArgs& g = gg.a[blockIdx.z];
   if ((int64_t)blockIdx.x * (32 * TM * WM) >= g.M) return;   // (the grid is sized for the longest product)
   v2_body<WM, WN, TM, TN, W_NK, PRO, false, STAGES>(g);
@@ -588,11 +658,10 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gather_gemm_v2_multi(const Gem
 // below: gemm.hip's kernels.  Measured at M = 8.9k (level 1 of the headline lattice) with 64x64, 32x128, 64x128 block
 // tiles of this kernel: 49-65 us against 52 us for the direct kernel on 128 -> 128 — too few chunks per block to pay
 // for the ring's fill and the per-chunk barrier, and 1.1 tiles per SIMD leave no tile shape that balances.
-static int64_t g_v2_min_m = getenv("TLN_V2_MIN_M") ? atoll(getenv("TLN_V2_MIN_M")) : 12288;
-static int g_v2_off = 0;
-extern "C" void tln_gemm_v2_config(int off, int64_t min_m) {
-  g_v2_off = off;
-  if (min_m > 0) g_v2_min_m = min_m;
+// smallest M that takes this kernel: tln_options.v2_min_m, or the default (12288; env TLN_V2_MIN_M read once)
+static int64_t v2_min_m(const tln_options& o) {
+  static const int64_t def = getenv("TLN_V2_MIN_M") ? atoll(getenv("TLN_V2_MIN_M")) : 12288;
+  return o.v2_min_m > 0 ? o.v2_min_m : def;
 }
 
 // the kernel addresses a source row and a weight row as a 32-bit byte offset into a buffer (the range check of the
@@ -604,8 +673,8 @@ static bool v2_bytes_ok(const GemmArgs& g) {
   return s.src_rows * s.ld * 4 < lim && ((int64_t)s.taps * s.cin + g.N) * g.ldw * 4 < lim && g.M * g.ld_out * 4 < lim;
 }
 
-bool tln_gemm_v2_ok(const GemmArgs& g, bool w_is_nk, bool vec) {
-  if ((g_v2_off & 1) || !vec || g.nsrc != 1 || g.M < g_v2_min_m) return false;
+bool tln_gemm_v2_ok(const GemmArgs& g, bool w_is_nk, bool vec, const tln_options& o) {
+  if ((o.v2_off & 1) || !vec || g.nsrc != 1 || g.M < v2_min_m(o)) return false;
   const SrcDev& s = g.s[0];
   if (s.cin % 32 != 0 || s.cin > 1024 || s.pad != 0.f) return false;
   if (!(s.taps == 1 || s.taps == TLN_TAPS)) return false;
@@ -620,11 +689,11 @@ bool tln_gemm_v2_ok(const GemmArgs& g, bool w_is_nk, bool vec) {
   return n == 64 || n == 96 || n % 128 == 0 || n % 192 == 0;
 }
 
-// the row order of a product over a tap table (lattice.hip), unless switched off (TLN_V2_PERM_OFF, tln_gemm_v2_config bit 2)
-static const int32_t* v2_perm_of(const GemmArgs& g) {
+// the row order of a product over a tap table (lattice.hip), unless switched off (TLN_V2_PERM_OFF, tln_options.v2_off bit 2)
+static const int32_t* v2_perm_of(const GemmArgs& g, const tln_options& o) {
   static const bool off = getenv("TLN_V2_PERM_OFF") != nullptr;
   const SrcDev& s = g.s[0];
-  if (off || (g_v2_off & 4) || s.table == nullptr || s.taps != TLN_TAPS) return nullptr;
+  if (off || (o.v2_off & 4) || s.table == nullptr || s.taps != TLN_TAPS) return nullptr;
   return tln_table_perm(s.table, g.M);
 }
 
@@ -649,7 +718,7 @@ static size_t v2_lds_bytes(int cin) {
 }
 
 template <int WM, int WN, int TM, int TN, bool W_NK, bool PRO, int STAGES = V2_STAGES>
-static int launch_v2(GemmArgs& g, hipStream_t s) {
+static int launch_v2(GemmArgs& g, hipStream_t s, const tln_options& o) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
   const size_t lds = v2_lds_bytes<WM, WN, TM, TN, STAGES>(g.s[0].cin);
   TLN_REQUIRE(lds <= 160 * 1024, "gemm v2: LDS %zu B", lds);
@@ -658,36 +727,36 @@ static int launch_v2(GemmArgs& g, hipStream_t s) {
   TLN_HIP(tln_set_max_lds(attr, reinterpret_cast<const void*>(kern), (int)lds));
   dim3 grid((unsigned)tln_cdiv(g.M, BM), (unsigned)tln_cdiv(g.N, BN), 1);
   g.splits = 1;
-  g.s[0].perm = v2_perm_of(g);
+  g.s[0].perm = v2_perm_of(g, o);
   g.s[0].order = g.s[0].perm ? tln_table_tile_order(g.s[0].table, g.M) : nullptr;
   hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, s, g);
   return TLN_OK;
 }
 
 template <bool W_NK, bool PRO>
-static int dispatch_v2(GemmArgs& g, hipStream_t s) {
+static int dispatch_v2(GemmArgs& g, hipStream_t s, const tln_options& o) {
   const int n = g.N;
   // eight waves per block (two per SIMD: one issues MFMAs while the other waits for LDS or the barrier) measured 3-8 %
   // faster than four waves of twice the tile on every shape of the workload (TLN_V2_WAVES=4 brings those back)
   static const int waves = getenv("TLN_V2_WAVES") ? atoi(getenv("TLN_V2_WAVES")) : 8;
   if (waves == 8) {
     if (n % 192 == 0)   // 128 x 192, 8 waves of 32 x 96
-      return (v2_two_stage() & 4) ? launch_v2<4, 2, 1, 3, W_NK, PRO, 2>(g, s) : launch_v2<4, 2, 1, 3, W_NK, PRO>(g, s);
+      return (v2_two_stage() & 4) ? launch_v2<4, 2, 1, 3, W_NK, PRO, 2>(g, s, o) : launch_v2<4, 2, 1, 3, W_NK, PRO>(g, s, o);
     if (n % 128 == 0) {   // 128 x 128, 8 waves of 32 x 64
-      return (v2_two_stage() & 1) ? launch_v2<4, 2, 1, 2, W_NK, PRO, 2>(g, s) : launch_v2<4, 2, 1, 2, W_NK, PRO>(g, s);
+      return (v2_two_stage() & 1) ? launch_v2<4, 2, 1, 2, W_NK, PRO, 2>(g, s, o) : launch_v2<4, 2, 1, 2, W_NK, PRO>(g, s, o);
     }
     if (n == 64)
-      return (v2_two_stage() & 2) ? launch_v2<4, 2, 1, 1, W_NK, PRO, 2>(g, s) : launch_v2<4, 2, 1, 1, W_NK, PRO>(g, s);   // 128 x 64, 8 waves of 32 x 32 (also with the
+      return (v2_two_stage() & 2) ? launch_v2<4, 2, 1, 1, W_NK, PRO, 2>(g, s, o) : launch_v2<4, 2, 1, 1, W_NK, PRO>(g, s, o);   // 128 x 64, 8 waves of 32 x 32 (also with the
                                                                           // GroupNorm prologue, which both column waves then apply: 37 against 38.6 us on 64 -> 64 x 9)
   }
-  if (n % 192 == 0) return launch_v2<2, 2, 2, 3, W_NK, PRO>(g, s);   // 128 x 192, waves 64 x 96
-  if (n % 128 == 0) return launch_v2<2, 2, 2, 2, W_NK, PRO>(g, s);   // 128 x 128, waves 64 x 64
-  if (n == 96) return launch_v2<4, 1, 1, 3, W_NK, PRO>(g, s);        // 128 x 96, waves 32 x 96
-  return (v2_two_stage() & 2) ? launch_v2<4, 1, 1, 2, W_NK, PRO, 2>(g, s) : launch_v2<4, 1, 1, 2, W_NK, PRO>(g, s);   // 128 x 64, waves 32 x 64
+  if (n % 192 == 0) return launch_v2<2, 2, 2, 3, W_NK, PRO>(g, s, o);   // 128 x 192, waves 64 x 96
+  if (n % 128 == 0) return launch_v2<2, 2, 2, 2, W_NK, PRO>(g, s, o);   // 128 x 128, waves 64 x 64
+  if (n == 96) return launch_v2<4, 1, 1, 3, W_NK, PRO>(g, s, o);        // 128 x 96, waves 32 x 96
+  return (v2_two_stage() & 2) ? launch_v2<4, 1, 1, 2, W_NK, PRO, 2>(g, s, o) : launch_v2<4, 1, 1, 2, W_NK, PRO>(g, s, o);   // 128 x 64, waves 32 x 64
 }
 
-static bool v2_shape_ok(const GemmArgs& g, bool vec) {
-  if ((g_v2_off & 1) || !vec || g.nsrc != 1) return false;
+static bool v2_shape_ok(const GemmArgs& g, bool vec, const tln_options& o) {
+  if ((o.v2_off & 1) || !vec || g.nsrc != 1) return false;
   const SrcDev& s = g.s[0];
   if (s.cin % 32 != 0 || s.cin > 1024 || s.pad != 0.f) return false;
   if (!(s.taps == 1 || s.taps == TLN_TAPS)) return false;
@@ -700,12 +769,12 @@ static bool v2_shape_ok(const GemmArgs& g, bool vec) {
   return n == 64 || n == 96 || n % 128 == 0 || n % 192 == 0;
 }
 
-bool tln_gemm_v2_multi_ok(const GemmArgs* g, int n, bool w_is_nk, const bool* vec) {
+bool tln_gemm_v2_multi_ok(const GemmArgs* g, int n, bool w_is_nk, const bool* vec, const tln_options& o) {
   static const bool off = getenv("TLN_V2_MULTI_OFF") != nullptr;
   if (off || n < 2 || n > TLN_GEMM_MULTI_MAX) return false;
   int64_t total = 0;
   for (int i = 0; i < n; ++i) {
-    if (!v2_shape_ok(g[i], vec[i]) || g[i].M < 1024) return false;
+    if (!v2_shape_ok(g[i], vec[i], o) || g[i].M < 1024) return false;
     const SrcDev &a = g[i].s[0], &b = g[0].s[0];
     if (g[i].N != g[0].N || a.cin != b.cin || a.taps != b.taps || (a.table != nullptr) != (b.table != nullptr) ||
         ((a.scale != nullptr || a.gn_part != nullptr) != (b.scale != nullptr || b.gn_part != nullptr)))
@@ -714,7 +783,7 @@ bool tln_gemm_v2_multi_ok(const GemmArgs* g, int n, bool w_is_nk, const bool* ve
   }
   (void)w_is_nk;
   static const int64_t multi_min = getenv("TLN_V2_MULTI_MIN_M") ? atoll(getenv("TLN_V2_MULTI_MIN_M")) : 0;
-  return total >= (multi_min > 0 ? multi_min : g_v2_min_m);
+  return total >= (multi_min > 0 ? multi_min : v2_min_m(o));
 }
 
 static int v2_cu_count() {
@@ -731,7 +800,7 @@ static int v2_cu_count() {
 }
 
 template <int WM, int WN, int TM, int TN, bool W_NK, bool PRO, int STAGES = V2_STAGES>
-static int launch_v2_multi(GemmArgs* g, int n, hipStream_t s) {
+static int launch_v2_multi(GemmArgs* g, int n, hipStream_t s, const tln_options& o) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
   const size_t lds = v2_lds_bytes<WM, WN, TM, TN, STAGES>(g[0].s[0].cin);
   TLN_REQUIRE(lds <= 160 * 1024, "gemm v2: LDS %zu B", lds);
@@ -743,7 +812,7 @@ static int launch_v2_multi(GemmArgs* g, int n, hipStream_t s) {
   for (int i = 0; i < TLN_GEMM_MULTI_MAX; ++i) {
     gg.a[i] = g[i < n ? i : 0];
     gg.a[i].splits = 1;
-    gg.a[i].s[0].perm = v2_perm_of(gg.a[i]);
+    gg.a[i].s[0].perm = v2_perm_of(gg.a[i], o);
     gg.a[i].s[0].order = gg.a[i].s[0].perm ? tln_table_tile_order(gg.a[i].s[0].table, gg.a[i].M) : nullptr;
     if (i < n && g[i].M > mmax) mmax = g[i].M;
   }
@@ -753,10 +822,10 @@ static int launch_v2_multi(GemmArgs* g, int n, hipStream_t s) {
 }
 
 template <bool W_NK, bool PRO>
-static int dispatch_v2_multi(GemmArgs* g, int n, hipStream_t s) {
+static int dispatch_v2_multi(GemmArgs* g, int n, hipStream_t s, const tln_options& o) {
   const int nn = g[0].N;
   if (nn % 192 == 0)
-    return (v2_two_stage() & 4) ? launch_v2_multi<4, 2, 1, 3, W_NK, PRO, 2>(g, n, s) : launch_v2_multi<4, 2, 1, 3, W_NK, PRO>(g, n, s);
+    return (v2_two_stage() & 4) ? launch_v2_multi<4, 2, 1, 3, W_NK, PRO, 2>(g, n, s, o) : launch_v2_multi<4, 2, 1, 3, W_NK, PRO>(g, n, s, o);
   if (nn % 128 == 0) {
     // Tile height against the quantisation of the launch: two workgroups of this tile share a CU, and a CU's time is
     // (workgroups it gets) x (rows per workgroup).  The lock-stepped level-1 products have 52k-72k rows together — 407 to
@@ -776,39 +845,39 @@ static int dispatch_v2_multi(GemmArgs* g, int n, hipStream_t s) {
       const double t128 = (double)tln_cdiv(w128 * cb, v2_cu_count()) * 1.0;
       const double t96 = (double)tln_cdiv(w96 * cb, v2_cu_count()) * 0.78;   // 0.75 of the rows + the fixed cost per workgroup
       if ((v2_two_stage() & 1) && (env == 1 || (env != 0 && t96 < t128)))
-        return launch_v2_multi<3, 2, 1, 2, W_NK, PRO, 2>(g, n, s);
+        return launch_v2_multi<3, 2, 1, 2, W_NK, PRO, 2>(g, n, s, o);
       // 64-row tiles of four waves (2 x 2, the same 32 x 64 per wave, three workgroups per CU): half the quantum of a
       // CU's time.  Where the 128-row count lands just above a multiple of the CU count (532 tiles: "3 per CU" for 2.08)
       // the launch takes 5 half-rounds instead of 3 whole ones.  MEASURED (4 streams x 8): the replay of a group's
       // products alone 113.4 -> 114.9 TFLOP/s by this model, the timed mode unchanged (1452 either way: the other streams
-      // fill the idle CUs of a last round already).  On by the model (TLN_V2_BM64 / tln_gemm_v2_config bits 8, 16: 1 /
+      // fill the idle CUs of a last round already).  On by the model (TLN_V2_BM64 / tln_options.v2_off bits 8, 16: 1 /
       // bit 8 always, 0 / bit 16 never)
       static const int env64 = getenv("TLN_V2_BM64") ? atoi(getenv("TLN_V2_BM64")) : -1;
-      const int mode64 = (g_v2_off & 8) ? 1 : ((g_v2_off & 16) ? 0 : env64);
+      const int mode64 = (o.v2_off & 8) ? 1 : ((o.v2_off & 16) ? 0 : env64);
       int64_t w64 = 0;
       for (int i = 0; i < n; ++i) w64 += tln_cdiv(g[i].M, 64);
       const double t64 = (double)tln_cdiv(w64 * cb, v2_cu_count()) * 0.53;
       if ((v2_two_stage() & 1) && (mode64 == 1 || (mode64 != 0 && t64 < t128)))
-        return launch_v2_multi<2, 2, 1, 2, W_NK, PRO, 2>(g, n, s);
+        return launch_v2_multi<2, 2, 1, 2, W_NK, PRO, 2>(g, n, s, o);
     }
-    return (v2_two_stage() & 1) ? launch_v2_multi<4, 2, 1, 2, W_NK, PRO, 2>(g, n, s) : launch_v2_multi<4, 2, 1, 2, W_NK, PRO>(g, n, s);
+    return (v2_two_stage() & 1) ? launch_v2_multi<4, 2, 1, 2, W_NK, PRO, 2>(g, n, s, o) : launch_v2_multi<4, 2, 1, 2, W_NK, PRO>(g, n, s, o);
   }
   if (nn == 64)
-    return (v2_two_stage() & 2) ? launch_v2_multi<4, 2, 1, 1, W_NK, PRO, 2>(g, n, s) : launch_v2_multi<4, 2, 1, 1, W_NK, PRO>(g, n, s);
-  if (nn == 96) return launch_v2_multi<4, 1, 1, 3, W_NK, PRO>(g, n, s);
-  return (v2_two_stage() & 2) ? launch_v2_multi<4, 1, 1, 2, W_NK, PRO, 2>(g, n, s) : launch_v2_multi<4, 1, 1, 2, W_NK, PRO>(g, n, s);
+    return (v2_two_stage() & 2) ? launch_v2_multi<4, 2, 1, 1, W_NK, PRO, 2>(g, n, s, o) : launch_v2_multi<4, 2, 1, 1, W_NK, PRO>(g, n, s, o);
+  if (nn == 96) return launch_v2_multi<4, 1, 1, 3, W_NK, PRO>(g, n, s, o);
+  return (v2_two_stage() & 2) ? launch_v2_multi<4, 1, 1, 2, W_NK, PRO, 2>(g, n, s, o) : launch_v2_multi<4, 1, 1, 2, W_NK, PRO>(g, n, s, o);
 }
 
-int tln_gemm_v2_launch_multi(GemmArgs* g, int n, bool w_is_nk, hipStream_t s) {
+int tln_gemm_v2_launch_multi(GemmArgs* g, int n, bool w_is_nk, hipStream_t s, const tln_options& o) {
   const bool pro = g[0].s[0].scale != nullptr;
-  if (w_is_nk) return pro ? dispatch_v2_multi<true, true>(g, n, s) : dispatch_v2_multi<true, false>(g, n, s);
-  return pro ? dispatch_v2_multi<false, true>(g, n, s) : dispatch_v2_multi<false, false>(g, n, s);
+  if (w_is_nk) return pro ? dispatch_v2_multi<true, true>(g, n, s, o) : dispatch_v2_multi<true, false>(g, n, s, o);
+  return pro ? dispatch_v2_multi<false, true>(g, n, s, o) : dispatch_v2_multi<false, false>(g, n, s, o);
 }
 
 // h' = GRUCell(x, pad(h)) as one two-source product with the cell in its epilogue (see v2_body)
-bool tln_gemm_v2_gru_ok(int64_t V, int64_t Vh, int C) {
+bool tln_gemm_v2_gru_ok(int64_t V, int64_t Vh, int C, const tln_options& o) {
   static const bool off = getenv("TLN_GRU_FUSED_OFF") != nullptr;
-  return !off && !(g_v2_off & 1) && V >= g_v2_min_m && V * C * 4 < (1ll << 31) - 4096 && Vh >= 1 && Vh <= V && C % 64 == 0 && C <= 1024;
+  return !off && !(o.v2_off & 1) && V >= v2_min_m(o) && V * C * 4 < (1ll << 31) - 4096 && Vh >= 1 && Vh <= V && C % 64 == 0 && C <= 1024;
 }
 static void v2_gru_args(GemmArgs& g, const float* d_x, const float* d_h, int64_t Vh, int64_t V, int C, const float* d_w_ih,
                         const float* d_w_hh, const float* d_b_ih, const float* d_b_hh, float* d_out) {
@@ -884,8 +953,8 @@ int tln_gemm_v2_launch_gru_multi(int n, const float* const* d_x, const float* co
   return TLN_OK;
 }
 
-int tln_gemm_v2_launch(GemmArgs& g, bool w_is_nk, hipStream_t s) {
+int tln_gemm_v2_launch(GemmArgs& g, bool w_is_nk, hipStream_t s, const tln_options& o) {
   const bool pro = g.s[0].scale != nullptr;
-  if (w_is_nk) return pro ? dispatch_v2<true, true>(g, s) : dispatch_v2<true, false>(g, s);
-  return pro ? dispatch_v2<false, true>(g, s) : dispatch_v2<false, false>(g, s);
+  if (w_is_nk) return pro ? dispatch_v2<true, true>(g, s, o) : dispatch_v2<true, false>(g, s, o);
+  return pro ? dispatch_v2<false, true>(g, s, o) : dispatch_v2<false, false>(g, s, o);
 }

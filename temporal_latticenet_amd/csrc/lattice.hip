@@ -63,6 +63,11 @@ struct __attribute__((aligned(16))) TlnSlot {
 // (the row record is a uint4: barycentric weight bits, row id, packed key lo / hi)
 
 struct tln_lattice {
+  tln_options opt = [] {   // kernel-selection options of this handle's distributes / pools (tln_lattice_set_options)
+    tln_options d;
+    tln_options_init(&d);
+    return d;
+  }();
   int pos_dim = 3, level = 0;
   int64_t capacity = 0, nslots = 0;
   double sigmas[3] = {1, 1, 1};
@@ -83,6 +88,7 @@ struct tln_lattice {
   int32_t* f2c = nullptr;
   // row orders of the three tap tables (rows with equal sets of present taps next to each other: perm section below)
   int32_t *perm_nbr = nullptr, *perm_c2f = nullptr, *perm_f2c = nullptr;
+  int64_t table_cap_nbr = 0, table_cap_c2f = 0, table_cap_f2c = 0;   // rows the three tables were allocated for
   int32_t *phist_nbr = nullptr, *phist_c2f = nullptr, *phist_f2c = nullptr;
   int64_t embedded_fine = 0;
   // tln_lattice_prepare_levels_begin without its _finish yet: coarse counters are in flight (root level only)
@@ -2160,25 +2166,21 @@ static void publish_counts(tln_lattice* l) {
   l->occupied = l->h_ctr[CTR_OCCUPIED];
 }
 
-// which K1: the partitioned kernels (default) or the per-row-atomic ones (TLN_K1_LEGACY=1 / tln_distribute_config; also
-// taken for val_dim > 1 and for frames beyond 4M rows)
-static int g_k1_legacy = -1;
-static bool k1_partitioned() {
-  if (g_k1_legacy < 0) {
+// which K1: the partitioned kernels (default) or the per-row-atomic ones (tln_options.k1_legacy of the handle, or env
+// TLN_K1_LEGACY=1 read once; also taken for val_dim > 1 and for frames beyond 4M rows)
+static bool k1_partitioned(const tln_lattice* l) {
+  static const bool env_legacy = [] {
     const char* e = getenv("TLN_K1_LEGACY");
-    g_k1_legacy = (e && e[0] == '1') ? 1 : 0;
-  }
-  return g_k1_legacy == 0;
+    return e && e[0] == '1';
+  }();
+  return !env_legacy && !l->opt.k1_legacy;
 }
-extern "C" int tln_distribute_config(int legacy) {
-  g_k1_legacy = legacy ? 1 : 0;
-  return TLN_OK;
-}
-// rows per bucket the partitioned kernels aim at (0 = default 512; a test / measurement hook: large values provoke a
-// bucket whose distinct keys overflow its LDS table, i.e. the fallback to the per-row-atomic kernels)
-static int g_bk_rows = 0;
-extern "C" int tln_distribute_bucket_rows(int rows) {
-  g_bk_rows = rows;
+const tln_options& tln_lat_options(const tln_lattice* l) { return l->opt; }
+extern "C" int tln_lattice_set_options(tln_lattice_t* l, const tln_options* opt) {
+  TLN_REQUIRE(l, "null lattice");
+  tln_options d;
+  tln_options_init(&d);
+  l->opt = opt ? *opt : d;
   return TLN_OK;
 }
 
@@ -2205,7 +2207,7 @@ static int distribute_prepare(tln_lattice* l, int64_t n, hipStream_t s) {
 }
 
 static bool bk_eligible(const tln_lattice* l, int64_t n, int val_dim) {
-  return k1_partitioned() && val_dim <= 1 && 4 * n <= (int64_t)TLN_BK_MAXB * TLN_BK_ROWS;
+  return k1_partitioned(l) && val_dim <= 1 && 4 * n <= (int64_t)TLN_BK_MAXB * TLN_BK_ROWS;
 }
 
 // the bucket geometry of a frame and everything its four kernels address; *split_t = threads of its split blocks
@@ -2214,7 +2216,7 @@ static int bk_fill_job(tln_lattice* l, const float* d_positions, const float* d_
   const int64_t rows = 4 * n;
   static const int env_rows = getenv("TLN_BK_ROWS") ? atoi(getenv("TLN_BK_ROWS")) : 0;   // measurement overrides
   static const int env_ppb = getenv("TLN_BK_PPB") ? atoi(getenv("TLN_BK_PPB")) : 0;
-  const int want_rows = g_bk_rows > 0 ? g_bk_rows : env_rows;
+  const int want_rows = l->opt.k1_bucket_rows > 0 ? l->opt.k1_bucket_rows : env_rows;
   const int bucket_rows = want_rows >= 128 && want_rows <= 65536 ? want_rows : TLN_BK_ROWS;
   int B = TLN_BK_MINB;
   while ((int64_t)B * bucket_rows < rows && B < l->bk_maxb) B <<= 1;
@@ -2851,15 +2853,16 @@ static int build_perms(const PermWant* w, int n, hipStream_t s) {
   return TLN_OK;
 }
 
-static int ensure_table(int32_t** p, int64_t capacity) {
+static int ensure_table(int32_t** p, int64_t capacity, int64_t* cap_out) {
   if (*p) return TLN_OK;
   TLN_HIP(hipMalloc(p, capacity * TLN_TAPS * sizeof(int32_t)));
+  *cap_out = capacity;
   return TLN_OK;
 }
 
 extern "C" int tln_neighbour_table(tln_lattice_t* l, const int32_t** d_table_out, void* stream_) {
   TLN_REQUIRE(l && d_table_out, "null argument");
-  int rc = ensure_table(&l->nbr, l->capacity);
+  int rc = ensure_table(&l->nbr, l->capacity, &l->table_cap_nbr);
   if (rc) return rc;
   if (l->nbr_gen != l->gen && l->nr_vertices > 0) {
     const int64_t total = l->nr_vertices * TLN_TAPS;
@@ -2959,7 +2962,7 @@ extern "C" int tln_coarse_to_fine_table(tln_lattice_t* c, const int32_t** d_tabl
     if (rc) return rc;
   }
   tln_lattice* f = c->parent;
-  int rc = ensure_table(&c->c2f, c->capacity);
+  int rc = ensure_table(&c->c2f, c->capacity, &c->table_cap_c2f);
   if (rc) return rc;
   if ((c->c2f_gen_c != c->gen || c->c2f_gen_f != f->gen) && c->nr_vertices > 0) {
     const int64_t total = c->nr_vertices * TLN_TAPS;
@@ -2983,7 +2986,7 @@ extern "C" int tln_fine_to_coarse_table(tln_lattice_t* c, const int32_t** d_tabl
     if (rc) return rc;
   }
   tln_lattice* f = c->parent;
-  int rc = ensure_table(&c->f2c, f->capacity);
+  int rc = ensure_table(&c->f2c, f->capacity, &c->table_cap_f2c);
   if (rc) return rc;
   if ((c->f2c_gen_c != c->gen || c->f2c_gen_f != f->gen) && f->nr_vertices > 0) {
     const int64_t total = f->nr_vertices * TLN_TAPS;
@@ -3141,7 +3144,7 @@ static int prepare_levels_begin_multi(tln_lattice* const* ll, int n, int nr_coar
     l0->levels_wait = i ? first->levels_event : nullptr;
     l0->levels_pending = nr_coarse_levels > 0 ? nr_coarse_levels : -1;   // -1: nothing to wait for, tables only
     if (l0->nr_vertices > 0) {
-      int rc = ensure_table(&l0->nbr, l0->capacity);
+      int rc = ensure_table(&l0->nbr, l0->capacity, &l0->table_cap_nbr);
       if (rc) return rc;
       if (l0->nbr_gen != l0->gen) {
         rc = add_table(tb, l0->vkeys, l0->nr_vertices, l0, 0, l0->nbr,
@@ -3178,7 +3181,7 @@ static int prepare_levels_finish_multi(tln_lattice* const* ll, int n, hipStream_
     }
     for (tln_lattice* p = l0; p; p = p->coarse) {
       if (p->nr_vertices <= 0) continue;
-      int rc = ensure_table(&p->nbr, p->capacity);
+      int rc = ensure_table(&p->nbr, p->capacity, &p->table_cap_nbr);
       if (rc) return rc;
       if (p->nbr_gen != p->gen) {
         rc = add_table(tb, p->vkeys, p->nr_vertices, p, 0, p->nbr,
@@ -3188,9 +3191,9 @@ static int prepare_levels_finish_multi(tln_lattice* const* ll, int n, hipStream_
       }
       if (p->parent && p->parent->nr_vertices > 0) {
         tln_lattice* f = p->parent;
-        rc = ensure_table(&p->c2f, p->capacity);
+        rc = ensure_table(&p->c2f, p->capacity, &p->table_cap_c2f);
         if (rc) return rc;
-        rc = ensure_table(&p->f2c, f->capacity);
+        rc = ensure_table(&p->f2c, f->capacity, &p->table_cap_f2c);
         if (rc) return rc;
         if (p->c2f_gen_c != p->gen || p->c2f_gen_f != f->gen) {
           rc = add_table(tb, p->vkeys, p->nr_vertices, f, 1, p->c2f,
@@ -3248,3 +3251,44 @@ extern "C" int tln_lattice_prepare_levels(tln_lattice_t* l0, int nr_coarse_level
 
 // the coarse level of `l` as it stands (NULL if none yet); no side effects
 extern "C" tln_lattice_t* tln_lattice_coarse_level(tln_lattice_t* l) { return l ? l->coarse : nullptr; }
+
+// Device memory this handle owns, by purpose, over the whole level stack ("~2 GB per resident sequence,
+// unexplained").  Computed from the sizes the allocations below were made with (every array here is sized by the
+// level's capacity, slot count or row capacity).  out: [0] hash tables + per-vertex arrays, [1] per-row workspaces of the
+// distribute (records, bins, sort scratch), [2] the pool's packed accumulators, [3] neighbour / cross-level tables and
+// their row orders, [4] total.
+static void lattice_memory_one(const tln_lattice* l, int64_t* out) {
+  const int64_t cap = l->capacity, ns = l->nslots, rc = l->rows_cap;
+  int64_t a = ns * (int64_t)sizeof(TlnSlot) + cap * 16 + (cap + 2) * 4 + cap * 12 + CTR_COUNT * 4;
+  if (l->slot_cnt) a += ns * 4;
+  if (l->vslot) a += cap * 16;   // vslot, vcnt, vstart, vstamp
+  int64_t b = 0;
+  if (rc > 0) {
+    b += 5 * rc * 4 + (rc / TLN_SCAN_BLOCK + 2) * 4 + (rc / 256 + 2) * 48 + (int64_t)l->sort_temp_bytes;
+    if (l->bin_rec) b += rc * 4 + rc * (int64_t)sizeof(TlnBinRec) + l->rec_cap * 16 +
+                         (int64_t)TLN_BK_SPLIT_BLOCKS * (l->bk_maxb + 1) * 4 + rc * 4 + (int64_t)l->bk_maxb * 4 + (rc / 128 + 8) * 4;
+  }
+  const int64_t c = l->pool_packed_elems * 8;
+  int64_t d = 0;
+  auto table = [&](const int32_t* t, int64_t rows_cap_t, const int32_t* perm) {
+    if (t) d += rows_cap_t * TLN_TAPS * 4;
+    if (perm) {
+      const int64_t pc = rows_cap_t < TLN_PERM_MAX_ROWS ? rows_cap_t : TLN_PERM_MAX_ROWS;
+      d += (pc + pc / TLN_TILE_ROWS + 8) * 4 + (pc / TLN_PERM_CHUNK + 2) * 256 * 4;
+    }
+  };
+  table(l->nbr, l->table_cap_nbr, l->perm_nbr);
+  table(l->c2f, l->table_cap_c2f, l->perm_c2f);
+  table(l->f2c, l->table_cap_f2c, l->perm_f2c);
+  out[0] += a;
+  out[1] += b;
+  out[2] += c;
+  out[3] += d;
+}
+extern "C" int tln_lattice_memory(const tln_lattice_t* l, int64_t* out) {
+  TLN_REQUIRE(l && out, "null argument");
+  for (int i = 0; i < 5; ++i) out[i] = 0;
+  for (const tln_lattice* q = l; q; q = q->coarse) lattice_memory_one(q, out);
+  out[4] = out[0] + out[1] + out[2] + out[3];
+  return TLN_OK;
+}

@@ -746,33 +746,30 @@ static int launch_pool(tln_lattice* l, const float* d_dist, int64_t rows, int co
 
 #define TLN_POOL_DEFAULT_MODE 0
 // which kernel pools the 4-16-32-64 MLP from the bins: the all-VALU k_pool_bins (default) or k_pool_bins_mfma
-// (TLN_POOL_MFMA=1 / tln_pool_config(1)).  Bitwise equal results; the MFMA variant measured no faster.
-static int g_pool_mfma = -1;
-static int pool_mode() {   // 0: all-VALU k_pool_bins, 1: legacy.hip's matrix-core variant, 2: k_pool_bins_mx
-  if (g_pool_mfma < 0) {
+// (TLN_POOL_MFMA=1 / tln_options.pool_mode = 1).  Bitwise equal results; the MFMA variant measured no faster.
+// (tln_options.pool_mode of the lattice handle, tln_lattice_set_options; -1 = env TLN_POOL_MFMA, read once, else 0)
+static int pool_mode(const tln_lattice* l) {   // 0: all-VALU k_pool_bins, 1: legacy.hip's matrix-core variant, 2: k_pool_bins_mx
+  static const int env_mode = [] {
     const char* e = getenv("TLN_POOL_MFMA");
-    g_pool_mfma = e ? atoi(e) : TLN_POOL_DEFAULT_MODE;
-    if (g_pool_mfma < 0 || g_pool_mfma > 2) g_pool_mfma = TLN_POOL_DEFAULT_MODE;
-  }
-  return g_pool_mfma;
-}
-extern "C" int tln_pool_config(int mode) {
-  g_pool_mfma = (mode < 0 || mode > 2) ? TLN_POOL_DEFAULT_MODE : mode;
-  return TLN_OK;
+    const int m = e ? atoi(e) : TLN_POOL_DEFAULT_MODE;
+    return (m < 0 || m > 2) ? TLN_POOL_DEFAULT_MODE : m;
+  }();
+  const int m = tln_lat_options(l).pool_mode;
+  return (m < 0 || m > 2) ? env_mode : m;
 }
 
 // the bins route for 1..TLN_POOL_MAXJOBS frames that share the MLP: *taken = false when the shape has no bins kernel
 static int pool_bins_jobs(PoolJobs& jobs, int n, int nr_layers, const float* const* d_w, const float* const* d_b,
-                          const int* dims, int min_points, bool* taken, hipStream_t s) {
+                          const int* dims, int min_points, bool* taken, int mode, hipStream_t s) {
   const int cin = dims[0], cout = dims[nr_layers];
   int rc = TLN_OK;
   for (int i = n; i < TLN_POOL_MAXJOBS; ++i) jobs.j[i] = jobs.j[0];   // (never indexed: the grids have n rows)
 #define POOLB_CASE(CI, A, B, CO) rc = launch_pool_bins<CI, A, B, CO>(jobs, n, d_w, d_b, min_points, s)
   *taken = true;
   const bool shape_wide = nr_layers == 3 && dims[1] == 16 && dims[2] == 32 && dims[3] == 64 && (cin == 4 || cin == 3);
-  const bool wide = n == 1 && shape_wide && pool_mode() == 1;
+  const bool wide = n == 1 && shape_wide && mode == 1;
   const PoolJob& j0 = jobs.j[0];
-  if (shape_wide && pool_mode() == 2) {
+  if (shape_wide && mode == 2) {
     // matrix cores + the max in accumulator layout: a wave strides over chunks (weights stay in its registers)
     int64_t rmax = 0;
     for (int i = 0; i < n; ++i)
@@ -825,7 +822,7 @@ extern "C" int tln_pointnet_pool_ex(tln_lattice_t* l, const float* d_distributed
     PoolJobs jobs;
     jobs.j[0] = PoolJob{bn, rows, packed, d_out, d_argrow, nv};
     bool taken = false;
-    rc = pool_bins_jobs(jobs, 1, nr_layers, d_w, d_b, dims, min_points, &taken, s);
+    rc = pool_bins_jobs(jobs, 1, nr_layers, d_w, d_b, dims, min_points, &taken, pool_mode(l), s);
     if (taken) return rc;
   }
   TLN_REQUIRE(d_distributed, "the pool needs the distributed rows (or the bins of this frame's distribute)");
@@ -882,7 +879,7 @@ extern "C" int tln_pointnet_pool_multi(const tln_pool_call* c, int n, int dist_c
   }
   if (batch) {
     bool taken = false;
-    int rc = pool_bins_jobs(jobs, n, nr_layers, d_w, d_b, dims, min_points, &taken, s);
+    int rc = pool_bins_jobs(jobs, n, nr_layers, d_w, d_b, dims, min_points, &taken, pool_mode(c[0].l), s);
     if (taken) return rc;
   }
   for (int i = 0; i < n; ++i) {

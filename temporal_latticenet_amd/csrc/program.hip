@@ -48,15 +48,14 @@ __global__ void __launch_bounds__(256) k_copy_rows_multi(const CopyJobs jobs, in
   *reinterpret_cast<float4*>(J.dst + r * J.ld_dst + c) = v;
 }
 
-// group mode: bit k set = ops of kind k (TLN_OP_*) are NOT batched over the group but launched per program, as before
-// round 3 (test / measurement switch; env TLN_GROUP_BATCH_OFF at load, tln_program_group_config at run time).  Bit 0:
-// the K1 / coarse-level batches of tln_program_begin_frame_group and the table batch of tln_program_run_group.
-static int g_group_off = getenv("TLN_GROUP_BATCH_OFF") ? atoi(getenv("TLN_GROUP_BATCH_OFF")) : 0;
-extern "C" int tln_program_group_config(int off_mask) {
-  g_group_off = off_mask;
-  return TLN_OK;
+// group mode: bit k of tln_options.group_off_mask set = ops of kind k (TLN_OP_*) are NOT batched over the group but
+// launched per program, as before round 3 (test / measurement switch; env TLN_GROUP_BATCH_OFF, read once, is OR-ed in).
+// Bit 0: the K1 / coarse-level batches of tln_program_begin_frame_group and the table batch of tln_program_run_group.
+// A group follows its first program's options.
+static inline bool group_batches(const tln_options& o, int kind) {
+  static const int env_off = getenv("TLN_GROUP_BATCH_OFF") ? atoi(getenv("TLN_GROUP_BATCH_OFF")) : 0;
+  return (((o.group_off_mask | env_off) >> kind) & 1) == 0;
 }
-static inline bool group_batches(int kind) { return ((g_group_off >> kind) & 1) == 0; }
 
 namespace {
 
@@ -182,6 +181,7 @@ struct tln_program {
   std::vector<SlotRt> rt;
   bool capture = false;
   std::vector<GemmCall> calls;
+  tln_options opt = tln_opt(nullptr);   // kernel-selection options of everything this program issues (tln_program_set_options)
   // stage timing (bench.py roofline_scatter): HIP events on the launch stream around K1 (every kernel of the
   // distribute), K2 (the PointNet pool) and K8 (the slice kernels of the last frame)
   bool timing = false;
@@ -406,9 +406,12 @@ int walk(tln_program* p, bool dry, int early, float* d_out, int64_t out_rows, in
           stop_here = true;
           break;
         }
-        rc = tln_gather_gemm_ex(M, o.n, &a[0], o.s1.slot >= 0 ? &a[1] : nullptr, o.w, o.w_is_nk, o.bias, res, ld_res,
-                                o.relu, fptr(o.out) + o.out_col, so.cols,
-                                o.stats_out >= 0 ? p->rt[o.stats_out].ptr : nullptr, s);
+        {
+          const tln_gemm_call call{M, o.n, &a[0], o.s1.slot >= 0 ? &a[1] : nullptr, o.w, o.w_is_nk, o.bias, res, ld_res,
+                                   o.relu, fptr(o.out) + o.out_col, so.cols,
+                                   o.stats_out >= 0 ? p->rt[o.stats_out].ptr : nullptr};
+          rc = tln_gather_gemm_opt(&call, &p->opt, s);
+        }
         if (rc) return rc;
         if (p->capture && M > 0) {
           GemmCall c{M, o.n, {a[0], a[1]}, o.s1.slot >= 0, o.w, o.w_is_nk, o.bias, res, ld_res, o.relu,
@@ -421,7 +424,7 @@ int walk(tln_program* p, bool dry, int early, float* d_out, int64_t out_rows, in
       case TLN_OP_GN_PARTIALS: {
         if (dry) break;
         const tln_slot& ss = p->slots[o.s0.slot];
-        if (p->defer && group_batches(TLN_OP_GN_PARTIALS)) {
+        if (p->defer && group_batches(p->opt, TLN_OP_GN_PARTIALS)) {
           p->pend_gn = tln_gn_partials_call{fptr(o.s0.slot), p->rt[o.s0.slot].rows, p->rt[o.stats_out].ptr};
           p->has_pending = true;
           p->pend_kind = TLN_OP_GN_PARTIALS;
@@ -441,7 +444,7 @@ int walk(tln_program* p, bool dry, int early, float* d_out, int64_t out_rows, in
         const float* w[4] = {o.p[0], o.p[1], o.p[2], o.p[3]};
         const float* b[4] = {o.p[4], o.p[5], o.p[6], o.p[7]};
         int dims[6] = {o.i[1], o.i[2], o.i[3], o.i[4], o.i[5], 0};
-        if (p->defer && group_batches(TLN_OP_POOL)) {
+        if (p->defer && group_batches(p->opt, TLN_OP_POOL)) {
           p->pend_pool_out = fptr(o.out);
           p->has_pending = true;
           p->pend_kind = TLN_OP_POOL;
@@ -463,7 +466,7 @@ int walk(tln_program* p, bool dry, int early, float* d_out, int64_t out_rows, in
         const int Cn = p->slots[o.out].cols;
         want_scratch(0, (size_t)p->rt[o.out].rows_b * 6 * Cn * sizeof(float));
         if (dry) break;
-        if (p->defer && !p->capture && group_batches(TLN_OP_GRU)) {
+        if (p->defer && !p->capture && group_batches(p->opt, TLN_OP_GRU)) {
           p->pend_gru = tln_gru_call{fptr(o.s0.slot), fptr(o.s1.slot), Vr, p->rt[o.s1.slot].rows, fptr(o.out),
                                      reinterpret_cast<float*>(scratch[0]), Vr * 6 * Cn};
           p->has_pending = true;
@@ -472,8 +475,8 @@ int walk(tln_program* p, bool dry, int early, float* d_out, int64_t out_rows, in
           stop_here = true;
           break;
         }
-        rc = tln_gru_cell(fptr(o.s0.slot), fptr(o.s1.slot), Vr, p->rt[o.s1.slot].rows, Cn, o.p[0], o.p[1], o.p[2], o.p[3],
-                          fptr(o.out), reinterpret_cast<float*>(scratch[0]), Vr * 6 * Cn, s);
+        rc = tln_gru_cell_opt(fptr(o.s0.slot), fptr(o.s1.slot), Vr, p->rt[o.s1.slot].rows, Cn, o.p[0], o.p[1], o.p[2], o.p[3],
+                              fptr(o.out), reinterpret_cast<float*>(scratch[0]), Vr * 6 * Cn, &p->opt, s);
         if (rc) return rc;
         if (p->capture && Vr > 0) {   // the cell's two products x @ W_ih^T, h @ W_hh^T as tln_gru_cell issues them
           float* gi = reinterpret_cast<float*>(scratch[0]);
@@ -503,7 +506,7 @@ int walk(tln_program* p, bool dry, int early, float* d_out, int64_t out_rows, in
         TLN_REQUIRE(p->levels[o.s0.level], "op %d: level %d does not exist", oi, o.s0.level);
         rc = tln_neighbour_table(p->levels[o.s0.level], &tp, s);
         if (rc) return rc;
-        if (p->defer && group_batches(TLN_OP_AFLOW)) {
+        if (p->defer && group_batches(p->opt, TLN_OP_AFLOW)) {
           p->pend_aflow = tln_aflow_call{fptr(o.s0.slot), fptr(o.s1.slot), Vr, p->rt[o.s1.slot].rows, tp, fptr(o.out),
                                          reinterpret_cast<float*>(scratch[0]), reinterpret_cast<int32_t*>(scratch[1])};
           p->has_pending = true;
@@ -547,7 +550,7 @@ int walk(tln_program* p, bool dry, int early, float* d_out, int64_t out_rows, in
       case TLN_OP_SLICE_DEFORM: {
         if (dry) break;
         TLN_REQUIRE(p->idx_valid, "op %d: the frame was begun without its vertex indices", oi);
-        if (p->defer && group_batches(TLN_OP_SLICE_DEFORM)) {
+        if (p->defer && group_batches(p->opt, TLN_OP_SLICE_DEFORM)) {
           const int ncls = p->slots[o.s1.slot].cols;
           p->pend_slice = tln_slice_call{fptr(o.s0.slot), fptr(o.s1.slot), p->rt[o.s1.slot].rows, p->d_idx, p->d_w, p->N,
                                          fptr(o.out), ncls <= 64 ? p->aux_out : nullptr};
@@ -611,7 +614,7 @@ int walk(tln_program* p, bool dry, int early, float* d_out, int64_t out_rows, in
           float* dp = fptr(o.out) + o.out_col;
           const bool vec = ss.cols % 4 == 0 && so.cols % 4 == 0 && o.out_col % 4 == 0 &&
                            (reinterpret_cast<uintptr_t>(sp) & 15) == 0 && (reinterpret_cast<uintptr_t>(dp) & 15) == 0;
-          if (vec && p->defer && group_batches(TLN_OP_COPY)) {
+          if (vec && p->defer && group_batches(p->opt, TLN_OP_COPY)) {
             p->pend_copy.src = sp;
             p->pend_copy.ld_src = ss.cols;
             p->pend_copy.dst = dp;
@@ -854,7 +857,7 @@ extern "C" int tln_program_begin_frame_group(tln_program_t* const* pp, tln_latti
                                              int need_indices, int64_t* v_out, void* stream_) {
   TLN_REQUIRE(pp && ll && d_positions && n && v_out && count >= 1 && count <= 8 && val_dim >= 0, "bad frame group");
   hipStream_t s = (hipStream_t)stream_;
-  if (!group_batches(0)) {   // every sequence by itself: all first halves, then all second halves
+  if (!group_batches(pp[0]->opt, 0)) {   // every sequence by itself: all first halves, then all second halves
     for (int k = 0; k < count; ++k) {
       int rc = tln_program_begin_frame_start(pp[k], ll[k], d_positions[k], d_values ? d_values[k] : nullptr, n[k], val_dim,
                                              reset_hashmap, subtract_mean, s);
@@ -1141,7 +1144,7 @@ int launch_pending_gemms(tln_program* const* pp, int n, hipStream_t s) {
       calls[m++] = tln_gemm_call{c.M, c.N, &c.a[0], c.two ? &c.a[1] : nullptr, c.w, c.w_is_nk, c.bias, c.res, c.ld_res,
                                  c.relu, c.out, c.ld_out, c.stats};
     }
-  int rc = m ? tln_gather_gemm_multi(calls, m, s) : TLN_OK;
+  int rc = m ? tln_gather_gemm_multi_opt(calls, m, &pp[0]->opt, s) : TLN_OK;
   for (int k = 0; k < n; ++k) {
     tln_program* p = pp[k];
     if (p->has_pending && p->capture && p->pending.M > 0) p->calls.push_back(p->pending);
@@ -1205,7 +1208,7 @@ int launch_pending(tln_program* const* pp, int n, hipStream_t s) {
       case TLN_OP_GRU: {
         tln_gru_call c[kMaxGroup];
         for (int k = 0; k < cnt; ++k) c[k] = q[b + k]->pend_gru;
-        rc = tln_gru_cell_multi(c, cnt, p0->slots[o.out].cols, o.p[0], o.p[1], o.p[2], o.p[3], s);
+        rc = tln_gru_cell_multi_opt(c, cnt, p0->slots[o.out].cols, o.p[0], o.p[1], o.p[2], o.p[3], &p0->opt, s);
         break;
       }
       case TLN_OP_AFLOW: {
@@ -1330,7 +1333,7 @@ extern "C" int tln_program_run_group(tln_program_t* const* pp, int n, int early,
     tln_lattice_t* lats[kMaxGroup];
     for (int k = 0; k < n; ++k) lats[k] = pp[k]->lat;
     int rc2 = TLN_OK;
-    if (group_batches(0)) rc2 = tln_lattice_prepare_levels_finish_multi(lats, n, s);
+    if (group_batches(pp[0]->opt, 0)) rc2 = tln_lattice_prepare_levels_finish_multi(lats, n, s);
     else
       for (int k = 0; k < n && !rc2; ++k) rc2 = tln_lattice_prepare_levels_finish(lats[k], s);
     if (rc == TLN_OK) rc = rc2;
@@ -1401,6 +1404,33 @@ extern "C" int tln_program_capture_gemms(tln_program_t* p, int enable) {
   return TLN_OK;
 }
 
+static int replay_one(const GemmCall& c, const tln_options& o, hipStream_t s) {
+  const tln_gemm_call call{c.M, c.N, &c.a[0], c.two ? &c.a[1] : nullptr, c.w, c.w_is_nk, c.bias, c.res, c.ld_res,
+                           c.relu, c.out, c.ld_out, c.stats};
+  return tln_gather_gemm_opt(&call, &o, s);
+}
+
+// Device memory the program owns: [0] the arena of the frame's temporaries (capacity), [1] its high-water mark of the
+// last frame, [2] the K1 output buffer (indices | weights | distributed rows when wanted), [3] the hidden-state buffers
+// (two per fusion module), [4] total of 0, 2, 3.
+extern "C" int tln_program_memory(const tln_program_t* p, int64_t* out) {
+  TLN_REQUIRE(p && out, "null argument");
+  out[0] = (int64_t)p->arena.bytes;
+  out[1] = (int64_t)p->alloc.high;
+  out[2] = (int64_t)p->k1.bytes;
+  out[3] = 0;
+  for (int st = 0; st < TLN_MAX_STATES; ++st)
+    for (int k = 0; k < 2; ++k) out[3] += (int64_t)p->state_buf[st][k].bytes;
+  out[4] = out[0] + out[2] + out[3];
+  return TLN_OK;
+}
+
+extern "C" int tln_program_set_options(tln_program_t* p, const tln_options* opt) {
+  TLN_REQUIRE(p, "null program");
+  p->opt = tln_opt(opt);
+  return TLN_OK;
+}
+
 extern "C" int tln_program_replay_gemms(tln_program_t* p, int reps, double* ms_total, int64_t* launches, double* flops,
                                         double* bytes, void* stream_) {
   TLN_REQUIRE(p && reps > 0 && ms_total && launches && flops && bytes, "bad replay arguments");
@@ -1415,8 +1445,7 @@ extern "C" int tln_program_replay_gemms(tln_program_t* p, int reps, double* ms_t
   TLN_HIP(hipEventCreate(&e1));
   auto launch_all = [&]() -> int {
     for (const GemmCall& c : p->calls) {
-      int rc = tln_gather_gemm_ex(c.M, c.N, &c.a[0], c.two ? &c.a[1] : nullptr, c.w, c.w_is_nk, c.bias, c.res, c.ld_res,
-                                  c.relu, c.out, c.ld_out, c.stats, s);
+      int rc = replay_one(c, p->opt, s);
       if (rc) return rc;
     }
     return TLN_OK;
@@ -1435,9 +1464,7 @@ extern "C" int tln_program_replay_gemms(tln_program_t* p, int reps, double* ms_t
     int idx = 0;
     for (const GemmCall& c : p->calls) {
       TLN_HIP(hipEventRecord(e0, s));
-      for (int r = 0; r < 20; ++r)
-        tln_gather_gemm_ex(c.M, c.N, &c.a[0], c.two ? &c.a[1] : nullptr, c.w, c.w_is_nk, c.bias, c.res, c.ld_res, c.relu,
-                           c.out, c.ld_out, c.stats, s);
+      for (int r = 0; r < 20; ++r) replay_one(c, p->opt, s);
       TLN_HIP(hipEventRecord(e1, s));
       TLN_HIP(hipEventSynchronize(e1));
       float ms = 0.f;
@@ -1449,17 +1476,15 @@ extern "C" int tln_program_replay_gemms(tln_program_t* p, int reps, double* ms_t
       if (atoi(getenv("TLN_GEMM_DUMP")) >= 2) {  // the direct kernel over its waves-per-tile choices
         fprintf(stderr, " | G:");
         for (int G = 1; G <= 12; ++G) {
-          tln_gemm_force_groups(G);
+          tln_options og = p->opt;
+          og.gemm_groups = G;
           TLN_HIP(hipEventRecord(e0, s));
-          for (int r = 0; r < 20; ++r)
-            tln_gather_gemm_ex(c.M, c.N, &c.a[0], c.two ? &c.a[1] : nullptr, c.w, c.w_is_nk, c.bias, c.res, c.ld_res,
-                               c.relu, c.out, c.ld_out, c.stats, s);
+          for (int r = 0; r < 20; ++r) replay_one(c, og, s);
           TLN_HIP(hipEventRecord(e1, s));
           TLN_HIP(hipEventSynchronize(e1));
           TLN_HIP(hipEventElapsedTime(&ms, e0, e1));
           fprintf(stderr, " %d:%.1f", G, ms * 50.0);
         }
-        tln_gemm_force_groups(0);
       }
       fprintf(stderr, "\n");
     }
@@ -1506,7 +1531,7 @@ extern "C" int tln_program_replay_gemms_group(tln_program_t* const* pp, int n, i
         calls[k] = tln_gemm_call{c.M, c.N, &c.a[0], c.two ? &c.a[1] : nullptr, c.w, c.w_is_nk, c.bias, c.res, c.ld_res,
                                  c.relu, c.out, c.ld_out, c.stats};
       }
-      int rc = tln_gather_gemm_multi(calls, n, s);
+      int rc = tln_gather_gemm_multi_opt(calls, n, &pp[0]->opt, s);
       if (rc) return rc;
     }
     return TLN_OK;
@@ -1536,7 +1561,7 @@ extern "C" int tln_program_replay_gemms_group(tln_program_t* const* pp, int n, i
         if (c.M > mmax) mmax = c.M;
       }
       TLN_HIP(hipEventRecord(e0, s));
-      for (int r = 0; r < 10; ++r) tln_gather_gemm_multi(calls, n, s);
+      for (int r = 0; r < 10; ++r) tln_gather_gemm_multi_opt(calls, n, &pp[0]->opt, s);
       TLN_HIP(hipEventRecord(e1, s));
       TLN_HIP(hipEventSynchronize(e1));
       float ms = 0.f;
@@ -1567,7 +1592,6 @@ extern "C" int tln_program_replay_gemms_group(tln_program_t* const* pp, int n, i
 // What the matrix cores execute for the captured products of one frame of n lock-stepped programs (n = 1: one sequence
 // alone): every gather-GEMM kernel counts its 32 x 32 x 32 steps (gemm_v2 after skipping the K chunks of absent taps, all
 // kernels including the rows and columns a tile pads) into a device counter during ONE extra pass of the launches.
-extern "C" void tln_gemm_debug_stamps(void* d_buf);
 extern "C" int tln_program_replay_executed(tln_program_t* const* pp, int n, double* flops_executed, void* stream_) {
   TLN_REQUIRE(pp && n >= 1 && n <= 8 && flops_executed, "bad replay arguments");
   hipStream_t s = (hipStream_t)stream_;
@@ -1579,7 +1603,8 @@ extern "C" int tln_program_replay_executed(tln_program_t* const* pp, int n, doub
   TLN_HIP(hipMalloc(&d_cnt, 16 * sizeof(unsigned long long)));
   int rc = TLN_OK;
   if (hipMemsetAsync(d_cnt, 0, 16 * sizeof(unsigned long long), s) != hipSuccess) rc = TLN_E_HIP;
-  tln_gemm_debug_stamps(d_cnt);
+  tln_options oc = pp[0]->opt;
+  oc.gemm_stamps = d_cnt;
   for (size_t i = 0; i < nc && !rc; ++i) {
     tln_gemm_call calls[8];
     for (int k = 0; k < n; ++k) {
@@ -1587,9 +1612,8 @@ extern "C" int tln_program_replay_executed(tln_program_t* const* pp, int n, doub
       calls[k] = tln_gemm_call{c.M, c.N, &c.a[0], c.two ? &c.a[1] : nullptr, c.w, c.w_is_nk, c.bias, c.res, c.ld_res,
                                c.relu, c.out, c.ld_out, c.stats};
     }
-    rc = tln_gather_gemm_multi(calls, n, s);
+    rc = tln_gather_gemm_multi_opt(calls, n, &oc, s);
   }
-  tln_gemm_debug_stamps(nullptr);
   unsigned long long h[16] = {0};
   if (!rc && (hipStreamSynchronize(s) != hipSuccess ||
               hipMemcpy(h, d_cnt, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess))

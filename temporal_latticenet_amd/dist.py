@@ -76,8 +76,13 @@ class HandoffError(RuntimeError):
 
 _MAGIC = 0x544C4E48            # "TLNH"
 _HDR = 8                       # magic, message number on this (src -> dst) channel, slot id, ndim, 4 extents
-_sent, _received = {}, {}      # (group id, peer) -> messages so far on that channel
+_sent, _received = {}, {}      # (ranks of the group, peer) -> messages completed so far on that channel
 HANDOFF_TIMEOUT_S = float(os.environ.get("TLN_HANDOFF_TIMEOUT_S", "120"))
+# Steady state: a hidden state travels as ONE message, its payload — the receiver knows the shape (rows = vertex count of
+# the state's level before the frame, known from the key exchange; columns from the program).  TLN_HANDOFF_DEBUG=1 (and
+# every hand-off whose shape the receiver cannot know: the operator-level hook route) puts the numbered header in front
+# again: RCCL matches messages by order alone, the header is what turns a mis-ordered walk into an error.
+HANDOFF_DEBUG = os.environ.get("TLN_HANDOFF_DEBUG", "0") not in ("", "0")
 
 
 def reset_handoff_counters():
@@ -85,48 +90,81 @@ def reset_handoff_counters():
     _received.clear()
 
 
-def _wait(work, what, timeout_s):
+def _channel(group, peer):
+    """key of a (group, peer) channel that survives the group object: its global ranks (id() of a collected group can be
+    reused by the next one)"""
+    try:
+        ranks = tuple(dist.get_process_group_ranks(group if group is not None else dist.group.WORLD))
+    except Exception:
+        ranks = ("world",)
+    return ranks, peer
+
+
+def _is_nccl(group):
+    try:
+        return dist.get_backend(group) == "nccl"
+    except Exception:
+        return False
+
+
+def _wait(work, what, timeout_s, group=None):
+    """gloo: block the host until the message is through, at most timeout_s (HandoffError instead of a hang).
+    nccl (RCCL): `wait()` only makes the CURRENT STREAM wait for the transfer — the host runs ahead, which is what lets
+    rank g start its next sequence while rank g+1 still works on this one (a host-side wait would serialise the
+    pipeline); there is no host timeout on that path, a peer that never arrives is the launcher's to time out."""
     import datetime
+    if _is_nccl(group):
+        work.wait()
+        return
     try:
         ok = work.wait(datetime.timedelta(seconds=timeout_s)) if timeout_s and timeout_s > 0 else work.wait()
-    except RuntimeError as e:                                   # gloo / nccl raise on timeout
+    except RuntimeError as e:                                   # gloo raises on timeout
         raise HandoffError("%s: %s" % (what, e)) from e
     if ok is False:
         raise HandoffError("%s: timed out after %.0f s" % (what, timeout_s))
 
 
-def send_tensor(t, dst, tag=0, group=None, timeout_s=None):
-    """header + payload.  The header carries the shape (hidden states grow from frame to frame, so the receiver cannot
-    know V_s), a per-channel MESSAGE NUMBER and the SLOT id the sender believes it is serving: the RCCL backend ignores
-    tags, messages between two ranks are matched by order alone, so a receiver that walked its fusion slots differently
-    would silently take the wrong state — it now sees a header it did not expect and raises HandoffError."""
-    key = (id(group), dst)
+def send_tensor(t, dst, tag=0, group=None, timeout_s=None, header=True):
+    """[header +] payload.  The header carries the shape (for receivers that cannot know it), a per-channel MESSAGE NUMBER
+    and the SLOT id the sender believes it is serving: the RCCL backend ignores tags, messages between two ranks are
+    matched by order alone, so a receiver that walked its fusion slots differently would silently take the wrong state —
+    with the header it sees a message it did not expect and raises HandoffError.  header=False (both sides must agree,
+    see HANDOFF_DEBUG): the payload alone."""
+    key = _channel(group, dst)
     seq = _sent.get(key, 0)
-    _sent[key] = seq + 1
-    hdr = torch.tensor([_MAGIC, seq, int(tag), t.dim()] + list(t.shape) + [0] * (4 - t.dim()), dtype=torch.int64,
-                       device=t.device)
     tmo = HANDOFF_TIMEOUT_S if timeout_s is None else timeout_s
-    _wait(dist.isend(hdr, dst, group=group, tag=tag), "send of header %d (slot %d) to rank %d" % (seq, tag, dst), tmo)
+    if header or HANDOFF_DEBUG:
+        hdr = torch.tensor([_MAGIC, seq, int(tag), t.dim()] + list(t.shape) + [0] * (4 - t.dim()), dtype=torch.int64,
+                           device=t.device)
+        _wait(dist.isend(hdr, dst, group=group, tag=tag), "send of header %d (slot %d) to rank %d" % (seq, tag, dst), tmo, group)
     if t.numel():
         _wait(dist.isend(t.contiguous(), dst, group=group, tag=tag),
-              "send of payload %d (slot %d) to rank %d" % (seq, tag, dst), tmo)
+              "send of payload %d (slot %d) to rank %d" % (seq, tag, dst), tmo, group)
+    _sent[key] = seq + 1          # (counted once the message is through)
 
 
-def recv_tensor(src, device, dtype=torch.float32, tag=0, group=None, timeout_s=None):
-    key = (id(group), src)
+def recv_tensor(src, device, dtype=torch.float32, tag=0, group=None, timeout_s=None, shape=None):
+    """shape=None: the message starts with the numbered header (checked; one host synchronisation to read it).
+    shape given: the payload alone, straight into a tensor of that shape — no header, no host synchronisation (unless
+    HANDOFF_DEBUG asks both sides for the header; it must then agree with `shape`)."""
+    key = _channel(group, src)
     seq = _received.get(key, 0)
-    _received[key] = seq + 1
     tmo = HANDOFF_TIMEOUT_S if timeout_s is None else timeout_s
-    hdr = torch.zeros(_HDR, dtype=torch.int64, device=device)
-    _wait(dist.irecv(hdr, src, group=group, tag=tag), "receive of header %d (slot %d) from rank %d" % (seq, tag, src), tmo)
-    h = hdr.tolist()
-    if h[0] != _MAGIC or h[1] != seq or h[2] != int(tag) or not 0 <= h[3] <= 4:
-        raise HandoffError("hand-off out of step: expected message %d for slot %d from rank %d, got magic %#x message %d "
-                           "slot %d ndim %d" % (seq, tag, src, h[0], h[1], h[2], h[3]))
-    shape = h[4:4 + h[3]]
-    t = torch.empty(shape, dtype=dtype, device=device)
+    if shape is None or HANDOFF_DEBUG:
+        hdr = torch.zeros(_HDR, dtype=torch.int64, device=device)
+        _wait(dist.irecv(hdr, src, group=group, tag=tag), "receive of header %d (slot %d) from rank %d" % (seq, tag, src), tmo, group)
+        h = hdr.tolist()
+        if h[0] != _MAGIC or h[1] != seq or h[2] != int(tag) or not 0 <= h[3] <= 4:
+            raise HandoffError("hand-off out of step: expected message %d for slot %d from rank %d, got magic %#x message %d "
+                               "slot %d ndim %d" % (seq, tag, src, h[0], h[1], h[2], h[3]))
+        got = h[4:4 + h[3]]
+        if shape is not None and list(shape) != got:
+            raise HandoffError("hand-off out of step: slot %d from rank %d has shape %s, expected %s" % (tag, src, got, list(shape)))
+        shape = got
+    t = torch.empty(tuple(shape), dtype=dtype, device=device)
     if t.numel():
-        _wait(dist.irecv(t, src, group=group, tag=tag), "receive of payload %d (slot %d) from rank %d" % (seq, tag, src), tmo)
+        _wait(dist.irecv(t, src, group=group, tag=tag), "receive of payload %d (slot %d) from rank %d" % (seq, tag, src), tmo, group)
+    _received[key] = seq + 1
     return t
 
 
@@ -235,18 +273,27 @@ class FrameShardRunner:
             self._hooks.append(mod.register_forward_pre_hook(self._make_pre(slot)))
             self._hooks.append(mod.register_forward_hook(self._make_post(slot)))
 
+    _shapes = None     # program route: {state id: (rows, cols)} of the states about to arrive (known before they do)
+
     def _recv_state(self, sid):
         """hidden state `sid` from the owner of the previous frame (None: it has none yet).  The transport: ranks of a
-        process group here; pipeline.FramePipeline overrides both ends with in-process queues + stream events"""
+        process group here; pipeline.FramePipeline overrides both ends with in-process queues + stream events.
+        On the program route the shape is known (rows = vertex count of the state's level before this frame, from the key
+        exchange; columns from the program): the payload arrives alone, no header, no host synchronisation."""
         dev = "cpu" if self.via_host else "cuda"
-        h = recv_tensor(self.plan.prev_rank, dev, tag=sid, group=self.group)
-        return h.to("cuda") if h.numel() else None
+        shape = self._shapes.get(sid) if self._shapes else None
+        h = recv_tensor(self.plan.prev_rank, dev, tag=sid, group=self.group, shape=shape)
+        return h.to("cuda", non_blocking=True) if h.numel() else None
 
     def _send_state(self, sid, t):
-        """hidden state `sid` (a device tensor, or None) to the owner of the next frame"""
+        """hidden state `sid` (a device tensor, or None) to the owner of the next frame; header-less exactly when the
+        receiver knows the shape (program route on both sides: decided by the same flag on every rank)"""
         if t is None:
             t = torch.zeros(0, device="cuda")
-        send_tensor(t.cpu() if self.via_host else t, self.plan.next_rank, tag=sid, group=self.group)
+        send_tensor(t.cpu() if self.via_host else t, self.plan.next_rank, tag=sid, group=self.group,
+                    header=not (self._headerless and t.numel() > 0))
+
+    _headerless = False
 
     def _make_pre(self, slot):
         def pre(mod, args):
@@ -336,8 +383,21 @@ class FrameShardRunner:
                 lvl = lvl.coarsen()
                 expect.append(lvl.nr_lattice_vertices())
 
-        raw, lat = prog.run_frame_sharded(lat, pos, val, f == 0, early, self._recv_state if recv_now else None,
-                                          self._send_state if send_now else None, expect)
+        # every state of a frame > 0 exists on the sender's side and has the row count of its level before this frame:
+        # the messages of the program route need no header (both sides take this branch: same model, same flag)
+        self._headerless = True
+        self._shapes = None
+        if recv_now:
+            self._shapes = {}
+            for sid in range(prog.nr_states):
+                fr, lw, lvl = prog.state_ops(sid)
+                self._shapes[sid] = (int(expect[lvl]), int(prog.state_cols(sid)))
+        try:
+            raw, lat = prog.run_frame_sharded(lat, pos, val, f == 0, early, self._recv_state if recv_now else None,
+                                              self._send_state if send_now else None, expect)
+        finally:
+            self._shapes = None
+            self._headerless = False
         model.first_sequence = False
         model._program_active = True
         if early and prog.stop_shape is not None:

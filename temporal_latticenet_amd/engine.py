@@ -352,6 +352,9 @@ class FrameProgram:
         self.uses_dropout = builder.uses_dropout
         self._keep = builder.keep
         self.n_ops, self.n_slots, self.n_states = len(builder.ops), len(builder.slots), builder.n_states
+        self.nr_states = self.n_states
+        # columns of every hidden state (what a frame-sharded receiver needs to know a state's shape before it arrives)
+        self._state_cols = {state: cols for rows, cols, kind, state in builder.slots if kind == SLOT_STATE_NEW}
         self.fused_logsm = bool(getattr(builder, "fused_logsm", False))
         self.last_logsm = None
         slots = (_lib.Slot * len(builder.slots))()
@@ -388,6 +391,23 @@ class FrameProgram:
     def reset(self):
         _lib.check(_lib.lib().tln_program_reset(self._h), "tln_program_reset")
 
+    def memory_bytes(self):
+        """device memory of the program (tln_program_memory): arena capacity / high-water mark, K1 buffer, hidden states"""
+        out = (C.c_int64 * 5)()
+        _lib.check(_lib.lib().tln_program_memory(self._h, out), "tln_program_memory")
+        return dict(zip(("arena", "arena_high_water", "k1_buffer", "hidden_states", "total"), (int(x) for x in out)))
+
+    def apply_options(self, *lattices):
+        """hands the kernel-selection options in force on this host thread (options.py; none = the library's defaults) to
+        this program's handle and to the lattices of the frame: the library itself keeps no process-wide switch"""
+        from . import options as O
+        g = O.generation()
+        if getattr(self, "_opt_gen", 0) != g:
+            _lib.check(_lib.lib().tln_program_set_options(self._h, O.current_ref()), "tln_program_set_options")
+            self._opt_gen = g
+        for ls in lattices:
+            ls.apply_options()
+
     def _rows(self, code, n):
         return n if code == ROWS_POINTS else (4 * n if code == ROWS_POINT_ROWS else int(self._v[code]))
 
@@ -401,6 +421,7 @@ class FrameProgram:
             values = values.contiguous().float()
             val_dim = values.shape[1]
         lib, s = _lib.lib(), stream_ptr()
+        self.apply_options(ls)
         _lib.check(lib.tln_program_begin_frame(self._h, ls._h, positions.data_ptr(),
                                                values.data_ptr() if values is not None else None, n, val_dim,
                                                1 if reset_hashmap else 0, 1 if self.subtract_mean else 0, self._v, s),
@@ -434,6 +455,7 @@ class FrameProgram:
         else:
             values = values.contiguous().float()
             val_dim = values.shape[1]
+        self.apply_options(ls)
         _lib.check(_lib.lib().tln_program_begin_frame_start(self._h, ls._h, positions.data_ptr(),
                                                             values.data_ptr() if values is not None else None, n,
                                                             val_dim, 1 if reset_hashmap else 0,
@@ -466,6 +488,8 @@ class FrameProgram:
             vals = [v_.contiguous().float() for v_ in values]
             val_dim = vals[0].shape[1]
             assert all(v_.shape[1] == val_dim for v_ in vals)
+        for p_, ls_ in zip(progs, lattices):
+            p_.apply_options(ls_)
         hs = (C.c_void_p * n)(*[p._h for p in progs])
         lh = (C.c_void_p * n)(*[ls._h for ls in lattices])
         pp = (C.c_void_p * n)(*[x.data_ptr() for x in pos])
@@ -522,6 +546,7 @@ class FrameProgram:
         """(ms, launches, flops, algorithmic bytes) of the last frame's gather-GEMM launches replayed `reps` times
         back to back between two HIP events on the current stream"""
         ms, n, fl, by = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
+        self.apply_options()
         _lib.check(_lib.lib().tln_program_replay_gemms(self._h, reps, C.byref(ms), C.byref(n), C.byref(fl),
                                                        C.byref(by), stream_ptr()), "tln_program_replay_gemms")
         return ms.value, n.value, fl.value, by.value
@@ -530,6 +555,8 @@ class FrameProgram:
     def replay_gemms_group(programs, reps=5):
         """the same for the programs of a lock-step group (models.forward_group): product i of every program through
         one tln_gather_gemm_multi call, as the group issued it; launches = products"""
+        for p_ in programs:
+            p_.apply_options()
         hs = (C.c_void_p * len(programs))(*[p._h for p in programs])
         ms, n, fl, by = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
         _lib.check(_lib.lib().tln_program_replay_gemms_group(hs, len(programs), reps, C.byref(ms), C.byref(n), C.byref(fl),
@@ -540,6 +567,8 @@ class FrameProgram:
     def replay_executed(programs):
         """flops the matrix cores execute for the last frame's products of these 1..8 lock-stepped programs (one extra
         pass of the launches with the kernels' step counters on: tln_program_replay_executed)"""
+        for p_ in programs:
+            p_.apply_options()
         hs = (C.c_void_p * len(programs))(*[p._h for p in programs])
         fl = C.c_double()
         _lib.check(_lib.lib().tln_program_replay_executed(hs, len(programs), C.byref(fl), stream_ptr()),
@@ -547,6 +576,9 @@ class FrameProgram:
         return fl.value
 
     # ---- the frame in segments (frame-sharded multi-GPU, dist.FrameShardRunner) -----------------------------------
+    def state_cols(self, sid):
+        return self._state_cols[sid]
+
     def state_ops(self, sid):
         """(first op that reads stored state `sid`, last op that writes the new one, lattice level of the state)"""
         fr, lw, lvl = C.c_int(), C.c_int(), C.c_int()
@@ -568,6 +600,7 @@ class FrameProgram:
             values = values.contiguous().float()
             val_dim = values.shape[1]
         lib, s = _lib.lib(), stream_ptr()
+        self.apply_options(ls)
         _lib.check(lib.tln_program_begin_frame(self._h, ls._h, positions.data_ptr(),
                                                values.data_ptr() if values is not None else None, n, val_dim,
                                                1 if reset_hashmap else 0, 1 if self.subtract_mean else 0, self._v, s),

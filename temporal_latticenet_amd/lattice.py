@@ -113,6 +113,21 @@ class Lattice:
         except Exception:
             pass
 
+    def memory_bytes(self):
+        """device memory of the whole level stack by purpose (tln_lattice_memory)"""
+        out = (C.c_int64 * 5)()
+        _lib.check(_lib.lib().tln_lattice_memory(self._h, out), "tln_lattice_memory")
+        return dict(zip(("structure", "row_workspaces", "pool_accumulators", "tables", "total"), (int(x) for x in out)))
+
+    def apply_options(self):
+        """hands the kernel-selection options in force on this host thread (options.py; none = the library's defaults) to
+        the native handle (K1 variant / bucket size, pool kernel): the library keeps no process-wide switch"""
+        from . import options as O
+        g = O.generation()
+        if getattr(self, "_opt_gen", 0) != g:
+            _lib.check(_lib.lib().tln_lattice_set_options(self._h, O.current_ref()), "tln_lattice_set_options")
+            self._opt_gen = g
+
     # ---- the API the reference uses -----------------------------------------------------
     def set_values(self, t):
         self._values = t            # aliasing, not copying (lm:284 then lm:290)
@@ -261,6 +276,7 @@ class Lattice:
         indices = torch.empty((4 * n,), dtype=torch.int32, device="cuda")
         weights = torch.empty((4 * n,), dtype=torch.float32, device="cuda")
         from . import ops as _ops
+        self.apply_options()
         with _ops._timed("distribute", n=n):
             rc = _lib.lib().tln_distribute(self._h, _ptr(positions), _ptr(values), n, val_dim,
                                            1 if subtract_mean else 0, _ptr(distributed), _ptr(indices),
@@ -285,6 +301,8 @@ class Lattice:
         if reset_hashmap:
             hs = (C.c_void_p * n)(*[l._h for l in lattices])
             _lib.check(_lib.lib().tln_lattice_clear_multi(hs, n, stream_ptr()), "tln_lattice_clear_multi")
+        for l in lattices:
+            l.apply_options()
         calls = (_lib.DistributeCall * n)()
         outs = []
         for k, (l, p, v) in enumerate(zip(lattices, pos, vals)):

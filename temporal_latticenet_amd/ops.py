@@ -5,6 +5,7 @@ import ctypes as C
 import torch
 
 from . import _lib
+from . import options as _options
 from .lattice import Lattice, stream_ptr, _ptr
 
 __all__ = ["gemm_src", "gather_gemm", "groupnorm_stats", "affine_act", "pointnet_pool", "gru_cell", "aflow",
@@ -117,20 +118,30 @@ def gather_gemm(M, weight, s0, s1=None, w_is_nk=False, bias=None, residual=None,
         d.d_gamma, d.d_beta = norm.weight.data_ptr(), norm.bias.data_ptr()
         d.d_scale_shift = keep.data_ptr() if keep is not None else None
         with _timed("gather_gemm", M=M, N=N, K=K, taps=s0[0].taps, cin=s0[0].cin, res=residual is not None):
-            rc = _lib.lib().tln_gn_gather_gemm(C.byref(d), M, N, C.byref(s0[0]),
-                                               C.byref(s1[0]) if s1 is not None else None, _ptr(weight),
-                                               1 if w_is_nk else 0, _ptr(bias), _ptr(residual),
-                                               residual.stride(0) if residual is not None else 0, 1 if relu else 0,
-                                               _ptr(out), out.stride(0), _ptr(st), stream_ptr())
+            rc = _lib.lib().tln_gn_gather_gemm_opt(C.byref(d), M, N, C.byref(s0[0]),
+                                                   C.byref(s1[0]) if s1 is not None else None, _ptr(weight),
+                                                   1 if w_is_nk else 0, _ptr(bias), _ptr(residual),
+                                                   residual.stride(0) if residual is not None else 0, 1 if relu else 0,
+                                                   _ptr(out), out.stride(0), _ptr(st), _options.current_ref(),
+                                                   stream_ptr())
         _lib.check(rc, "tln_gn_gather_gemm")
         if st is not None:
             out._tln_stats = st
         return out
     with _timed("gather_gemm", M=M, N=N, K=K, taps=s0[0].taps, cin=s0[0].cin, res=residual is not None):
-        rc = _lib.lib().tln_gather_gemm_ex(M, N, C.byref(s0[0]), C.byref(s1[0]) if s1 is not None else None,
-                                           _ptr(weight), 1 if w_is_nk else 0, _ptr(bias), _ptr(residual),
-                                           residual.stride(0) if residual is not None else 0, 1 if relu else 0,
-                                           _ptr(out), out.stride(0), _ptr(st), stream_ptr())
+        opt = _options.current_ref()
+        if opt is None:
+            rc = _lib.lib().tln_gather_gemm_ex(M, N, C.byref(s0[0]), C.byref(s1[0]) if s1 is not None else None,
+                                               _ptr(weight), 1 if w_is_nk else 0, _ptr(bias), _ptr(residual),
+                                               residual.stride(0) if residual is not None else 0, 1 if relu else 0,
+                                               _ptr(out), out.stride(0), _ptr(st), stream_ptr())
+        else:       # the same product under the kernel-selection options in force on this host thread (options.py)
+            call = _lib.GemmCall()
+            call.M, call.N, call.s0, call.s1 = M, N, C.pointer(s0[0]), (C.pointer(s1[0]) if s1 is not None else None)
+            call.d_w, call.w_is_nk, call.d_bias, call.d_residual = _ptr(weight), 1 if w_is_nk else 0, _ptr(bias), _ptr(residual)
+            call.ld_res, call.relu = residual.stride(0) if residual is not None else 0, 1 if relu else 0
+            call.d_out, call.ld_out, call.d_stats = _ptr(out), out.stride(0), _ptr(st)
+            rc = _lib.lib().tln_gather_gemm_opt(C.byref(call), opt, stream_ptr())
     _lib.check(rc, "tln_gather_gemm")
     if st is not None:
         out._tln_stats = st
@@ -190,6 +201,7 @@ def pointnet_pool(lattice: Lattice, distributed, indices, weights, biases, min_p
     barr = (C.c_void_p * max(nl, 1))(*[b.data_ptr() for b in bs])
     darr = (C.c_int * (nl + 1))(*dims)
     argrow = torch.empty((V, dims[-1]), dtype=torch.int32, device="cuda") if want_argrow else None
+    lattice.apply_options()
     with _timed("pointnet_pool", rows=rows, V=V, cout=dims[-1]):
         rc = _lib.lib().tln_pointnet_pool_ex(lattice._h, _ptr(distributed), rows, cols, nl, warr, barr, darr,
                                              int(min_points), _ptr(out), _ptr(argrow), stream_ptr())
@@ -203,9 +215,9 @@ def gru_cell(x, h, w_ih, w_hh, b_ih, b_hh):
     V, Cn = x.shape
     out = torch.empty_like(x)
     ws = torch.empty((V * 6 * Cn,), dtype=torch.float32, device="cuda")
-    _lib.check(_lib.lib().tln_gru_cell(_ptr(x), _ptr(h), V, h.shape[0], Cn, _ptr(_f32c(w_ih)), _ptr(_f32c(w_hh)),
-                                       _ptr(_f32c(b_ih)), _ptr(_f32c(b_hh)), _ptr(out), _ptr(ws), ws.numel(),
-                                       stream_ptr()), "tln_gru_cell")
+    _lib.check(_lib.lib().tln_gru_cell_opt(_ptr(x), _ptr(h), V, h.shape[0], Cn, _ptr(_f32c(w_ih)), _ptr(_f32c(w_hh)),
+                                           _ptr(_f32c(b_ih)), _ptr(_f32c(b_hh)), _ptr(out), _ptr(ws), ws.numel(),
+                                           _options.current_ref(), stream_ptr()), "tln_gru_cell")
     return out
 
 

@@ -186,9 +186,10 @@ class FramePipeline:
             job = self._jobs[g].get()
             if job is None:
                 return
-            seq, frame = job
+            seq, frame, opt, gen = job
             try:
-                with torch.no_grad(), torch.cuda.stream(self.streams[g]):
+                from . import options as O
+                with torch.no_grad(), torch.cuda.stream(self.streams[g]), O.inherit(opt, gen):
                     out = self.slots[g].run(seq, frame)
                 self._done.put((g, seq, out, None))
             except BaseException as e:          # reported by run(); the other slots time out on their queues
@@ -203,12 +204,13 @@ class FramePipeline:
         start.record(cur)
         for s in self.streams:
             s.wait_event(start)                       # the inputs were produced on the caller's stream
+        from . import options as O
         self._gen += 1
         gen = self._gen
         for i, sq in enumerate(sequences):
             assert len(sq) == T, "a sequence of %d frames on a pipeline of %d slots" % (len(sq), T)
             for g in range(T):
-                self._jobs[g].put(((gen, i), sq[g]))
+                self._jobs[g].put(((gen, i), sq[g], O.current(), O.generation()))
         outs = [None] * len(sequences)
         err = None
         for _ in range(T * len(sequences)):

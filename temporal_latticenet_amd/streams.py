@@ -93,7 +93,10 @@ class SequenceStreams:
             job = self._jobs[i].get()
             if job is None:
                 return
-            self._done.put((i,) + self._work(i, *job))
+            from . import options as O
+            opt, gen, batch, keep = job
+            with O.inherit(opt, gen):        # the kernel-selection options of the thread that called run()
+                self._done.put((i,) + self._work(i, batch, keep))
 
     def _fetch(self, i, grp, t):
         """frame t of the sequences of a lock-step group: device tensors as they are; host tensors (pinned) start their
@@ -168,8 +171,9 @@ class SequenceStreams:
         cur = torch.cuda.current_stream()
         for s in self.streams:           # inputs prepared on the caller's stream are ready for every worker
             s.wait_stream(cur)
+        from . import options as O
         for i in range(1, n):
-            self._jobs[i].put((batches[i], keep_outputs))
+            self._jobs[i].put((O.current(), O.generation(), batches[i], keep_outputs))
         results, errors = [None] * n, [None] * n
         results[0], errors[0] = self._work(0, batches[0], keep_outputs)
         for _ in range(1, n):

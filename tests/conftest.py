@@ -31,6 +31,8 @@ def _seeded():
     torch.manual_seed(20240607)
     np.random.seed(20240607)
     yield
+    from temporal_latticenet_amd import options
+    options.reset()      # kernel-selection options a failed test left pushed on this host thread
 
 
 

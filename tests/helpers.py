@@ -64,24 +64,35 @@ def oracle_pair(model, contents, **kw):
     return oracle_from_model(model, contents, **kw), oracle_from_model(model, contents, dtype=torch.float64, **kw)
 
 
+MAX_SLACK = 1.25   # the worst of ~3 M elements is an extreme-value statistic: two evaluations with the SAME noise level differ
+                   # in it by this much from draw to draw (tools/parity64.py: 0.8-1.4 between HIP and o32 over the BASELINE cases)
+RMS_SLACK = 1.15   # the noise LEVEL itself: rms of (x - o64) over all elements
+
+
 def check_logits(got, want32, want64, what, rel_tol=NORTH_STAR_TOL, abs_ceiling=None):
-    """The 1e-4 bar settled with a float64 reference.  Three numbers are recorded per comparison —
-    |HIP - o64|, |o32 - o64|, |HIP - o32| (max-abs over all points and classes) — and asserted:
-      * |HIP - o64| <= max(1e-4, |o32 - o64|): the HIP path is within the north star's absolute 1e-4 of the float64
-        truth, or at least no further from it than the fp32 CPU restatement of the same algorithm is (at |logit| ~ 30-100
-        an fp32 evaluation of ~60 layers, whatever its summation order, carries more than 1e-4 of rounding noise);
+    """The 1e-4 bar settled with a float64 reference.  Recorded per comparison: the max-abs and the rms
+    of HIP - o64, o32 - o64 (and max-abs HIP - o32).  Asserted:
+      * max|HIP - o64| <= max(1e-4, 1.25 x max|o32 - o64|): the HIP path is within the north star's absolute 1e-4 of the
+        float64 truth, or — where an fp32 evaluation of ~60 layers cannot be, at |logit| ~ 30-100 — no further from it
+        than the fp32 CPU restatement of the same algorithm is (up to the draw-to-draw spread of a maximum);
+      * rms(HIP - o64) <= 1.15 x rms(o32 - o64): the NOISE LEVEL of the HIP path is that of the fp32 CPU restatement (round
+        3's kernels: 1.55 x, one accumulation chain over all of K in gemm_v2; round 4 folds per tap group: 1.0-1.08 x);
       * |HIP - o32| <= 1e-4 * max(1, max|logit|): the relative reading of earlier rounds, kept so the records stay
         comparable; `abs_ceiling` (when given) bounds the absolute error as a regression tripwire."""
     import torch
     got = got.detach().cpu()
     assert got.shape == want32.shape == want64.shape, (got.shape, want32.shape, want64.shape)
     scale = max(1.0, float(want64.abs().max()))
-    e_h64 = float((got.double() - want64).abs().max())
-    e_3264 = float((want32.double() - want64).abs().max())
+    d_h, d_o = got.double() - want64, want32.double() - want64
+    e_h64, e_3264 = float(d_h.abs().max()), float(d_o.abs().max())
+    r_h64, r_3264 = float(d_h.pow(2).mean().sqrt()), float(d_o.pow(2).mean().sqrt())
     e_h32 = float((got - want32).abs().max())
-    parity_log(what, e_h32, scale, tuple(got.shape), hip_vs_o64=e_h64, o32_vs_o64=e_3264, hip_vs_o32=e_h32)
-    assert e_h64 <= max(NORTH_STAR_TOL, e_3264), \
-        "%s: |HIP - o64| = %.3e exceeds max(1e-4, |o32 - o64| = %.3e) (max|logit| %.1f)" % (what, e_h64, e_3264, scale)
+    parity_log(what, e_h32, scale, tuple(got.shape), hip_vs_o64=e_h64, o32_vs_o64=e_3264, hip_vs_o32=e_h32,
+               hip_vs_o64_rms=r_h64, o32_vs_o64_rms=r_3264)
+    assert e_h64 <= max(NORTH_STAR_TOL, MAX_SLACK * e_3264), \
+        "%s: |HIP - o64| = %.3e exceeds max(1e-4, %.2f x |o32 - o64| = %.3e) (max|logit| %.1f)" % (what, e_h64, MAX_SLACK, e_3264, scale)
+    assert r_h64 <= RMS_SLACK * r_3264 + 1e-9, \
+        "%s: rms(HIP - o64) = %.3e exceeds %.2f x rms(o32 - o64) = %.3e" % (what, r_h64, RMS_SLACK, r_3264)
     assert e_h32 <= rel_tol * scale, "%s: |HIP - o32| = %.3e (scale %.2f)" % (what, e_h32, scale)
     if abs_ceiling is not None:
         assert e_h32 <= abs_ceiling, "%s: max abs err %.3e exceeds the recorded absolute level" % (what, e_h32)

@@ -30,14 +30,14 @@ def _free_port():
     return p
 
 
-def _spawn(fn, *args):
+def _spawn(fn, *args, world=WORLD):
     port = _free_port()
-    mp.spawn(_entry, args=(fn, port) + args, nprocs=WORLD, join=True)
+    mp.spawn(_entry, args=(fn, port, world) + args, nprocs=world, join=True)
 
 
-def _entry(rank, fn, port, *args):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(WORLD))
-    torch.set_num_threads(2)
+def _entry(rank, fn, port, world, *args):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2 if world <= 2 else 1)
     D.init_from_env("gloo")
     try:
         fn(rank, *args)
@@ -87,8 +87,9 @@ def _handoff_out_of_step(rank):
     dist.barrier()
     # the sender serves slot 5, the receiver waits for slot 6 (same tag on the wire, as RCCL would deliver it)
     if rank == 0:
-        hdr = torch.tensor([D._MAGIC, D._sent[(id(None), 1)], 5, 1, 2, 0, 0, 0], dtype=torch.int64)
-        D._sent[(id(None), 1)] += 1
+        ch = D._channel(None, 1)
+        hdr = torch.tensor([D._MAGIC, D._sent[ch], 5, 1, 2, 0, 0, 0], dtype=torch.int64)
+        D._sent[ch] += 1
         dist.send(hdr, 1, tag=6)
     else:
         with pytest.raises(D.HandoffError, match="out of step"):
@@ -100,6 +101,18 @@ def _handoff_out_of_step(rank):
     else:
         with pytest.raises(D.HandoffError, match="expected message"):
             D.recv_tensor(0, "cpu", tag=7)
+    dist.barrier()
+    # steady state of the frame-sharded program route: the receiver knows the shape, the payload travels alone (one message
+    # per state, no header to read back on the host) -- and the message counters still advance in step
+    if rank == 0:
+        before = D._sent[D._channel(None, 1)]
+        D.send_tensor(torch.full((5, 3), 2.0), 1, tag=9, header=False)
+        assert D._sent[D._channel(None, 1)] == before + 1
+        D.send_tensor(torch.full((2, 3), 4.0), 1, tag=10)                 # with header, shape checked against the expectation
+    else:
+        got = D.recv_tensor(0, "cpu", tag=9, shape=(5, 3))
+        assert tuple(got.shape) == (5, 3) and float(got.sum()) == 30.0
+        assert tuple(D.recv_tensor(0, "cpu", tag=10).shape) == (2, 3)
     dist.barrier()
     # nobody sends: the receiver gives up instead of hanging the pipeline (last: gloo tears the pair down on a timeout)
     if rank == 1:
@@ -181,10 +194,10 @@ def _make_oracle():
 SLOTS = ["early", "middle", "bottle", "late"]
 
 
-def _frame_sharding(rank):
+def _frame_sharding(rank, WORLD=WORLD):
     seq = make_sequence(1500, WORLD, seed=17)
     plan = D.FrameShardPlan(WORLD, rank, WORLD)
-    assert plan.frames == [rank] and plan.group_ranks == [0, 1]
+    assert plan.frames == [rank] and plan.group_ranks == list(range(WORLD))
     pos, val = seq[rank]
     # 1. first-touch-ordered keys of my frame alone
     scratch = P.VertexTable(3, 1 << 14)
@@ -221,3 +234,9 @@ def _frame_sharding(rank):
 
 def test_frame_sharding_equals_sequential_semantics():
     _spawn(_frame_sharding)
+
+
+def test_frame_sharding_over_four_ranks():
+    """BASELINE config 4's cut: a 4-frame sequence, one frame per rank (key all-gather over the four, hidden states handed
+    from rank g to g + 1 three times): numbering and last-frame scores bit-identical to the sequential run"""
+    _spawn(_frame_sharding, 4, world=4)

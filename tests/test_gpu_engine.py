@@ -6,6 +6,7 @@ import pytest
 import torch
 
 from tests.helpers import build_model, make_config, make_lattice, oracle_from_model, randomize_parameters
+from temporal_latticenet_amd import options as O
 from temporal_latticenet_amd.synthetic import make_sequence
 
 pytestmark = pytest.mark.gpu
@@ -167,11 +168,11 @@ def test_lockstep_pair_equals_the_solo_frames(gpu, rnn, seq_learning, frames):
     # the bitwise half of the statement needs the same kernel on both routes: products that share a launch may take the
     # large-M kernel where each alone takes the direct one (their rows are counted together), so that kernel stays off
     # here; tests/test_gpu_fullsize.py runs the lock-step route with it against the oracle
-    lib.tln_gemm_v2_config(1, 0)
+    O.push(v2_off=1)
     want = [_run(model, contents, s, gpu)[0] for s in seqs]
     try:
         for off in (1, 0, 0):
-            lib.tln_gemm_pair_disable(off)
+            O.set(gemm_pair_off=off)
             lats = [make_lattice(contents), make_lattice(contents)]
             with torch.no_grad():
                 for t in range(frames):
@@ -192,8 +193,7 @@ def test_lockstep_pair_equals_the_solo_frames(gpu, rnn, seq_learning, frames):
             for m in models:
                 m.reset_sequence()
     finally:
-        lib.tln_gemm_pair_disable(0)
-        lib.tln_gemm_v2_config(0, 0)
+        O.pop()
 
 
 def test_slice_head_writes_log_softmax(gpu):

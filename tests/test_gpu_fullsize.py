@@ -11,6 +11,7 @@ import torch
 
 from oracle import ops as O
 from tests.helpers import build_model, make_config, make_lattice, oracle_from_model, oracle_pair, randomize_parameters
+from temporal_latticenet_amd import options as OPT
 from temporal_latticenet_amd.synthetic import make_sequence
 
 pytestmark = pytest.mark.gpu
@@ -179,11 +180,8 @@ def test_the_timed_configuration_matches_the_oracle(gpu):
             for t, (p, v) in enumerate(seq):
                 want, want64 = _both(oracle, oracle64, p.cpu().numpy(), v.cpu().numpy(), early_return=(t != T - 1))
             _check(got[i][j], want, "timed configuration 4 streams x 8: stream %d position %d vs oracle" % (i, j), want64)
-            lib.tln_gemm_v2_config(0, 1)
-            try:
+            with OPT.options(v2_min_m=1):
                 same, _ = alone(seq)
-            finally:
-                lib.tln_gemm_v2_config(0, 12288)
             assert torch.equal(got[i][j], same), "stream %d position %d: the shared launches changed a bit" % (i, j)
         # (4) other positions, same bits
         rot = pool.run([[seqs[per * i + (j + 3) % per] for j in range(per)] for i in range(S)], keep_outputs=True)

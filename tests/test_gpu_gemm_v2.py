@@ -26,11 +26,11 @@ def lattice(gpu):
 
 @pytest.fixture
 def v2_forced():
-    from temporal_latticenet_amd import _lib
-    lib = _lib.lib()
-    lib.tln_gemm_v2_config(0, 1)
-    yield lib
-    lib.tln_gemm_v2_config(0, 12288)
+    """every product of the test on the large-M kernel (kernel-selection options of this host thread, options.py)"""
+    from temporal_latticenet_amd import options as OPT
+    OPT.push(v2_min_m=1)
+    yield OPT
+    OPT.pop()
 
 
 # (cin, cout, taps, weights as [N,K], GroupNorm+ReLU prologue, bias, residual, relu)
@@ -92,11 +92,8 @@ def test_v2_matches_oracle_and_the_other_kernels(gpu, lattice, v2_forced, cin, c
     np.testing.assert_allclose(st[:, :, 0].sum(0).numpy(), got.sum(0).numpy(), rtol=1e-10, atol=1e-7)
     np.testing.assert_allclose(st[:, :, 1].sum(0).numpy(), (got * got).sum(0).numpy(), rtol=1e-10, atol=1e-7)
     # same product from gemm.hip's kernels (v2 off): equal up to the order of the K summation
-    v2_forced.tln_gemm_v2_config(1, 0)
-    try:
+    with v2_forced.options(v2_off=1):
         other = run()
-    finally:
-        v2_forced.tln_gemm_v2_config(0, 1)
     np.testing.assert_allclose(out.cpu().numpy(), other.cpu().numpy(), rtol=1e-4, atol=5e-5)
 
 
@@ -154,6 +151,7 @@ def test_v2_takes_products_whose_rows_only_together_are_large(gpu, lattice, cin,
     same tile: the launch they share must not change a bit)."""
     import ctypes as C
     from temporal_latticenet_amd import _lib, ops
+    from temporal_latticenet_amd import options as OPT
     from temporal_latticenet_amd.lattice import stream_ptr
     lat, table = lattice
     V = lat.nr_lattice_vertices()
@@ -189,15 +187,12 @@ def test_v2_takes_products_whose_rows_only_together_are_large(gpu, lattice, cin,
         first = [o.clone() for o in outs]
         for o in outs:
             o.fill_(float("nan"))
-        lib.tln_gemm_v2_config(8, 12288)
-        try:
-            _lib.check(lib.tln_gather_gemm_multi(calls, nprod, stream_ptr()), "tln_gather_gemm_multi")
+        with OPT.options(v2_off=8):
+            _lib.check(lib.tln_gather_gemm_multi_opt(calls, nprod, OPT.current_ref(), stream_ptr()), "tln_gather_gemm_multi_opt")
             torch.cuda.synchronize()
-        finally:
-            lib.tln_gemm_v2_config(0, 12288)
         for i in range(nprod):
             assert torch.equal(outs[i], first[i]), "64-row tiles, product %d" % i
-    lib.tln_gemm_v2_config(0, 1)                           # the same products one by one through gemm_v2
+    OPT.push(v2_min_m=1)                                   # the same products one by one through gemm_v2
     try:
         for i in range(nprod):
             src, kw, _ = keep[i]
@@ -208,7 +203,7 @@ def test_v2_takes_products_whose_rows_only_together_are_large(gpu, lattice, cin,
             want = a @ (W.t() if nk else W) + bias.cpu()
             np.testing.assert_allclose(outs[i].cpu().numpy(), want.numpy(), rtol=1e-4, atol=5e-5)
     finally:
-        lib.tln_gemm_v2_config(0, 12288)
+        OPT.pop()
 
 
 @pytest.mark.parametrize("cin,cout,pro", [(64, 64, True), (192, 192, False), (128, 64, True)])
@@ -216,7 +211,7 @@ def test_row_order_by_present_taps_changes_no_bit(gpu, lattice, v2_forced, cin, 
     """Every 9-tap product over a tap table walks its rows in the table's row order (rows with the same set of present
     neighbour taps together, lattice.hip) and skips the K chunks of the taps no row of a 128-row block has.  A skipped
     chunk would have added exact zeros, and a row's sum does not depend on which rows share its block: the result is
-    bitwise the one without the row order (tln_gemm_v2_config bit 2), and the GroupNorm partial sums still add up to the
+    bitwise the one without the row order (tln_options.v2_off bit 2), and the GroupNorm partial sums still add up to the
     tensor.  On this lattice a third of the neighbour taps is missing: the fixture also checks that there is something
     to skip."""
     from temporal_latticenet_amd import ops
@@ -238,11 +233,8 @@ def test_row_order_by_present_taps_changes_no_bit(gpu, lattice, v2_forced, cin, 
         return ops.gather_gemm(V, W, s0, stats=True)
 
     with_order = run()
-    v2_forced.tln_gemm_v2_config(4, 0)          # large-M kernel on, row order off
-    try:
+    with v2_forced.options(v2_off=4):           # large-M kernel on, row order off
         plain = run()
-    finally:
-        v2_forced.tln_gemm_v2_config(0, 0)
     assert torch.equal(with_order, plain)
     a, b = with_order._tln_stats.double().sum(0), plain._tln_stats.double().sum(0)
     np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-10, atol=1e-7)

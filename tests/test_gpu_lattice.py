@@ -6,6 +6,7 @@ import torch
 
 from oracle import ops as O
 from oracle import permuto as P
+from temporal_latticenet_amd import options as OPT
 from temporal_latticenet_amd.synthetic import make_sequence
 
 pytestmark = pytest.mark.gpu
@@ -239,16 +240,15 @@ def test_scan_ordered_cloud_and_the_bins(gpu):
 @pytest.fixture
 def k1_legacy():
     """the per-row-atomic K1 kernels for the duration of a test (the partitioned ones are the default)"""
-    from temporal_latticenet_amd import _lib
-    lib = _lib.lib()
-    lib.tln_distribute_config(1)
-    yield lib
-    lib.tln_distribute_config(0)
+    from temporal_latticenet_amd import options as OPT
+    OPT.push(k1_legacy=1)
+    yield OPT
+    OPT.pop()
 
 
 @pytest.mark.parametrize("n,sigma", [(20000, 1.0), (120000, 0.6)])
 def test_legacy_k1_matches_oracle(gpu, k1_legacy, n, sigma):
-    """tln_distribute_config(1): k_distribute_insert + the k_bins_* kernels (also what val_dim > 1 takes)"""
+    """tln_options.k1_legacy = 1: k_distribute_insert + the k_bins_* kernels (also what val_dim > 1 takes)"""
     seq = make_sequence(n, 3, seed=7)
     lat, tab, outs = _run_sequence(gpu, seq, sigma, 1 << 18)
     for d, i, w, od, oi, ow in outs:
@@ -277,7 +277,7 @@ def test_partitioned_and_legacy_k1_agree(gpu, n, sigma, capacity, val_dim):
     Bs = [torch.randn(16, generator=g) * 0.1, torch.randn(32, generator=g) * 0.1, torch.randn(64, generator=g) * 0.1]
     got = {}
     for legacy in (0, 1):
-        lib.tln_distribute_config(legacy)
+        OPT.push(k1_legacy=legacy)
         try:
             lat = Lattice.from_params([sigma] * 3, capacity)
             res = []
@@ -290,7 +290,7 @@ def test_partitioned_and_legacy_k1_agree(gpu, n, sigma, capacity, val_dim):
                 res.append(item)
             got[legacy] = (res, lat.keys().cpu().numpy(), lat.neighbour_table().cpu().numpy())
         finally:
-            lib.tln_distribute_config(0)
+            OPT.pop()
     for a, b in zip(got[0][0], got[1][0]):
         for x, y in zip(a, b):
             assert np.array_equal(x, y)
@@ -329,7 +329,7 @@ def test_batched_distribute_of_eight_lattices_equals_the_single_calls(gpu):
 
 def test_a_bucket_that_overflows_its_table_falls_back_to_the_atomic_kernels(gpu):
     """The partitioned K1 gives every bucket (one workgroup) a 1024-entry LDS table for the distinct keys of a frame.  With
-    the buckets made 64x larger than the default (tln_distribute_bucket_rows) a fine lattice puts thousands of distinct
+    the buckets made 64x larger than the default (tln_options.k1_bucket_rows) a fine lattice puts thousands of distinct
     keys into each: the kernels notice (their own counter, not the "table too full" one), number nothing, and the library
     redoes the frame with the per-row-atomic kernels -- same indices as the oracle, and the sequence goes on append-only.
     Also through the batched first half, and with the per-row indices switched off for a frame."""
@@ -337,7 +337,7 @@ def test_a_bucket_that_overflows_its_table_falls_back_to_the_atomic_kernels(gpu)
     from temporal_latticenet_amd.lattice import Lattice
     lib = _lib.lib()
     seq = make_sequence(60000, 3, seed=411)
-    lib.tln_distribute_bucket_rows(32768)
+    OPT.push(k1_bucket_rows=32768)
     try:
         lat = Lattice.from_params([0.1] * 3, 1 << 19)
         tab = P.VertexTable(3, 1 << 19)
@@ -348,14 +348,14 @@ def test_a_bucket_that_overflows_its_table_falls_back_to_the_atomic_kernels(gpu)
             assert lat.nr_lattice_vertices() == tab.nr_vertices > 50000
             assert np.array_equal(i.cpu().numpy(), oi) and np.array_equal(w.cpu().numpy(), ow)
             np.testing.assert_allclose(d.cpu().numpy(), od, rtol=0, atol=2e-5)
-        lib.tln_distribute_bucket_rows(0)            # the third frame on the default geometry: no fallback, same numbering
+        OPT.set(k1_bucket_rows=0)                    # the third frame on the default geometry: no fallback, same numbering
         pos, val = seq[2]
         d, i, w = lat.distribute(torch.from_numpy(pos).to(gpu), torch.from_numpy(val).to(gpu), reset_hashmap=False)
         od, oi, ow = O.distribute(tab, pos, val, [0.1] * 3)
         assert lat.bucket_fallbacks() == 2 and np.array_equal(i.cpu().numpy(), oi)
         assert np.array_equal(lat.keys().cpu().numpy(), tab.keys)
         # batched first halves, two lattices, both overflowing
-        lib.tln_distribute_bucket_rows(32768)
+        OPT.set(k1_bucket_rows=32768)
         lats = [Lattice.from_params([0.1] * 3, 1 << 19) for _ in range(2)]
         outs = Lattice.distribute_batch(lats, [torch.from_numpy(seq[k][0]).to(gpu) for k in range(2)],
                                         [torch.from_numpy(seq[k][1]).to(gpu) for k in range(2)])
@@ -364,4 +364,4 @@ def test_a_bucket_that_overflows_its_table_falls_back_to_the_atomic_kernels(gpu)
             od, oi, ow = O.distribute(t2, seq[k][0], seq[k][1], [0.1] * 3)
             assert lats[k].bucket_fallbacks() == 1 and np.array_equal(i.cpu().numpy(), oi)
     finally:
-        lib.tln_distribute_bucket_rows(0)
+        OPT.pop()

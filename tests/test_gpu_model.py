@@ -5,6 +5,7 @@ import pytest
 import torch
 
 from tests.helpers import build_model, make_config, make_lattice, oracle_from_model, randomize_parameters
+from temporal_latticenet_amd import options as OPT
 from temporal_latticenet_amd.synthetic import make_sequence
 
 pytestmark = pytest.mark.gpu
@@ -215,7 +216,7 @@ def test_executed_flops_of_a_frame_are_counted_by_the_kernels(gpu):
     assert prog is not None
     shares = {}
     for name, force in (("default", 0), ("small-M kernels only", 1)):
-        _lib.lib().tln_gemm_force_direct(force)
+        OPT.push(gemm_direct=force)
         try:
             prog.capture_gemms(True)
             lat = make_lattice(contents)
@@ -227,7 +228,7 @@ def test_executed_flops_of_a_frame_are_counted_by_the_kernels(gpu):
             prog.capture_gemms(False)
             model.reset_sequence()
         finally:
-            _lib.lib().tln_gemm_force_direct(0)
+            OPT.pop()
         assert n > 20 and fl > 0 and again[2] == fl
         shares[name] = ex / fl
     print("executed / algorithmic flops:", shares)

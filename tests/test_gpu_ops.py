@@ -6,6 +6,7 @@ import torch.nn.functional as F
 
 from oracle import ops as O
 from oracle import permuto as P
+from temporal_latticenet_amd import options as OPT
 from temporal_latticenet_amd.synthetic import make_sequence
 
 pytestmark = pytest.mark.gpu
@@ -86,12 +87,12 @@ def test_gemm_all_tiles_with_prologue_epilogue(gpu, tm, tn):
     W = torch.randn(9 * cin, cout, generator=g) / np.sqrt(9 * cin)
     res = torch.randn(V, cout, generator=g)
     scale, shift = ops.groupnorm_stats(lv.to(gpu), 32, gamma.to(gpu), beta.to(gpu))
-    _lib.lib().tln_gemm_force_tiles(tm, tn)
+    OPT.push(gemm_tn=tn)
     try:
         s0 = ops.gemm_src(lv.to(gpu), lat.neighbour_table_ptr(), 9, scale=scale, shift=shift, relu=True)
         out = ops.gather_gemm(V, W.to(gpu), s0, residual=res.to(gpu), relu=False)
     finally:
-        _lib.lib().tln_gemm_force_tiles(0, 0)
+        OPT.pop()
     act = torch.relu(O.group_norm(lv, gamma, beta))
     want = O.conv(act, P.neighbour_table(tab), W) + res
     np.testing.assert_allclose(out.cpu().numpy(), want.numpy(), rtol=1e-4, atol=5e-5)
@@ -111,16 +112,14 @@ def test_gemm_split_k_is_exact_and_reproducible(gpu, splits, wm, groups):
     b = torch.randn(cout, generator=g)
     res = torch.randn(V, cout, generator=g)
     lib = _lib.lib()
-    lib.tln_gemm_force_splits(splits, wm)
-    lib.tln_gemm_force_groups(groups)
+    OPT.push(gemm_splits=splits, gemm_wm=wm, gemm_groups=groups)
     try:
         outs = []
         for _ in range(3):
             s0 = ops.gemm_src(lv.to(gpu), lat.neighbour_table_ptr(), 9)
             outs.append(ops.gather_gemm(V, W.to(gpu), s0, bias=b.to(gpu), residual=res.to(gpu), relu=True, stats=True))
     finally:
-        lib.tln_gemm_force_splits(0, 0)
-        lib.tln_gemm_force_groups(0)
+        OPT.pop()
     want = torch.relu(O.conv(lv, P.neighbour_table(tab), W, b) + res)
     np.testing.assert_allclose(outs[0].cpu().numpy(), want.numpy(), rtol=1e-4, atol=3e-5)
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2]), "bitwise reproducible"
@@ -339,17 +338,10 @@ def test_direct_and_tiled_gemm_agree_on_random_shapes(gpu):
             return ops.gather_gemm(M, W, s0, s1, w_is_nk=nk, bias=bias, residual=res, relu=relu, stats=True,
                                    gn=(xs, norm, True) if use_gn else None)
 
-        lib.tln_gemm_force_direct(1)
-        lib.tln_gemm_force_groups(groups)
-        try:
+        with OPT.options(gemm_direct=1, gemm_groups=groups):
             a = call()
-        finally:
-            lib.tln_gemm_force_groups(0)
-        lib.tln_gemm_force_direct(-1)
-        try:
+        with OPT.options(gemm_direct=-1):
             b = call()
-        finally:
-            lib.tln_gemm_force_direct(0)
         scale = max(1.0, float(b.abs().max()))
         err = float((a - b).abs().max())
         assert err <= 2e-5 * scale, "case %d (cin %d, N %d, taps %d, M %d, two %s, nk %s, groups %d): %.3e" % (
@@ -360,7 +352,7 @@ def test_direct_and_tiled_gemm_agree_on_random_shapes(gpu):
 
 @pytest.mark.parametrize("cin", [4, 3])
 def test_pool_on_the_matrix_cores_is_bitwise_the_fma_chain(gpu, cin):
-    """tln_pool_config(1): layers 2 and 3 of the 16-32-64 PointNet MLP as v_mfma_f32_32x32x2_f32 products.  The MFMA adds
+    """tln_options.pool_mode = 1 / 2: layers 2 and 3 of the 16-32-64 PointNet MLP as v_mfma_f32_32x32x2_f32 products.  The MFMA adds
     its k terms as one ascending chain of fp32 fmas, so the pooled tensor (values, arg-max rows' barycentric weights,
     min_points mask) equals the all-VALU kernel's and the oracle's bit for bit — on two frames, the second one with
     vertices that have no rows, rows without a vertex (capacity overflow) and runs crossing 64-row chunks."""
@@ -375,7 +367,7 @@ def test_pool_on_the_matrix_cores_is_bitwise_the_fma_chain(gpu, cin):
     Bs = [torch.randn(16, generator=g) * 0.1, torch.randn(32, generator=g) * 0.1, torch.randn(64, generator=g) * 0.1]
     got = {}
     for mfma in (2, 1, 0):      # 2: k_pool_bins_mx (max in accumulator layout), 1: legacy.hip's LDS-tile variant, 0: all-VALU
-        lib.tln_pool_config(mfma)
+        OPT.push(pool_mode=mfma)
         try:
             lat = Lattice.from_params([0.7] * 3, 9000)
             tab = P.VertexTable(3, 9000)
@@ -390,7 +382,7 @@ def test_pool_on_the_matrix_cores_is_bitwise_the_fma_chain(gpu, cin):
                         assert np.array_equal(outs[-1], want.numpy()), "frame %d, pool mode %d" % (t, mfma)
             got[mfma] = outs
         finally:
-            lib.tln_pool_config(0)
+            OPT.pop()
     assert (oi < 0).sum() > 0, "the fixture is meant to overflow on the second frame"
     for a, b, c in zip(got[0], got[1], got[2]):
         assert np.array_equal(a, b) and np.array_equal(a, c)

@@ -4,6 +4,7 @@ import pytest
 import torch
 
 from tests.helpers import build_model, make_config, make_lattice, randomize_parameters
+from temporal_latticenet_amd import options as O
 from temporal_latticenet_amd.streams import SequenceStreams
 from temporal_latticenet_amd.synthetic import make_sequence
 
@@ -58,14 +59,14 @@ def test_lockstep_pairs_match_the_single_sequence_results(gpu):
     randomize_parameters(model, seed=19)
     # (the bitwise half needs the same kernel on both routes: products sharing a launch may take the large-M kernel
     # where each alone takes the direct one — their rows are counted together —, so that kernel stays off here)
-    _lib.lib().tln_gemm_v2_config(1, 0)
+    O.push(v2_off=1)
     want = [_alone(model, contents, s) for s in seqs]
     pool = SequenceStreams(model, lambda: build_model(contents).eval(), lambda: make_lattice(contents), seqs[0], S, pairs=True)
     assert len(pool.models) == 2 * S and len(pool) == S
     lib = _lib.lib()
     try:
         for off in (1, 0):
-            lib.tln_gemm_pair_disable(off)
+            O.set(gemm_pair_off=off)
             # stream 0: a pair and an odd one out (solo route); stream 1: a pair
             got = pool.run([[seqs[0], seqs[1], seqs[4]], [seqs[2], seqs[3]]], keep_outputs=True)
             flat = got[0][:2] + got[1] + got[0][2:]
@@ -77,8 +78,7 @@ def test_lockstep_pairs_match_the_single_sequence_results(gpu):
                     err = float((g - w).abs().max())
                     assert err <= 2e-4 * max(1.0, float(w.abs().max())), "sequence %d: %.3e" % (k, err)
     finally:
-        lib.tln_gemm_pair_disable(0)
-        lib.tln_gemm_v2_config(0, 0)
+        O.pop()
         pool.close()
 
 
@@ -94,14 +94,14 @@ def test_lockstep_groups_of_three_and_four(gpu, group):
     model = build_model(contents).eval()
     _alone(model, contents, seqs[0])
     randomize_parameters(model, seed=29)
-    _lib.lib().tln_gemm_v2_config(1, 0)   # (as in the pairs test above)
+    O.push(v2_off=1)   # (as in the pairs test above)
     want = [_alone(model, contents, s) for s in seqs]
     pool = SequenceStreams(model, lambda: build_model(contents).eval(), lambda: make_lattice(contents), seqs[0], S, pairs=group)
     assert len(pool.models) == group * S
     lib = _lib.lib()
     try:
         for off in (1, 0):
-            lib.tln_gemm_pair_disable(off)
+            O.set(gemm_pair_off=off)
             got = pool.run([seqs[:group] + seqs[2 * group:], seqs[group:2 * group]], keep_outputs=True)
             flat = got[0][:group] + got[1] + got[0][group:]
             for k, (g, w) in enumerate(zip(flat, want)):
@@ -111,6 +111,5 @@ def test_lockstep_groups_of_three_and_four(gpu, group):
                     err = float((g - w).abs().max())
                     assert err <= 2e-4 * max(1.0, float(w.abs().max())), "sequence %d: %.3e" % (k, err)
     finally:
-        lib.tln_gemm_pair_disable(0)
-        lib.tln_gemm_v2_config(0, 0)
+        O.pop()
         pool.close()

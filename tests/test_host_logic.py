@@ -110,6 +110,77 @@ def test_c_abi_library_exports_every_declared_symbol():
     assert _lib.lib().tln_version() >= 1            # no device needed
 
 
+def test_the_library_exports_no_process_wide_switch():
+    """"no global state except explicit handles".  Until round 3 the kernel-selection switches were setters
+    on file-scope variables (tln_*_config, tln_gemm_force_*), racy under the host threads of streams.py; they are fields of
+    tln_options now, stored in a handle or passed with a call.  No such setter is exported, declared or bound, and the
+    kernel sources keep no mutable file-scope switch."""
+    import subprocess
+    from temporal_latticenet_amd import _lib
+    gone = ["tln_distribute_config", "tln_distribute_bucket_rows", "tln_pool_config", "tln_gemm_force_tiles",
+            "tln_gemm_force_groups", "tln_gemm_force_splits", "tln_gemm_force_direct", "tln_gemm_v2_config",
+            "tln_gemm_pair_disable", "tln_gemm_debug_stamps", "tln_program_group_config"]
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    declared = _declared_symbols()
+    for name in gone:
+        assert not hasattr(lib, name), "%s is still exported" % name
+        assert name not in declared and name not in _lib.exported_symbols()
+    nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True)
+    if nm.returncode == 0:
+        exported = re.findall(r"\b(tln_[a-z0-9_]+)$", nm.stdout, flags=re.M)
+        bad = [e for e in exported if re.search(r"_config$|_force_|_disable$", e)]
+        assert not bad, bad
+    for want in ("tln_options_init", "tln_lattice_set_options", "tln_program_set_options", "tln_gather_gemm_opt",
+                 "tln_gather_gemm_multi_opt", "tln_gru_cell_opt"):
+        assert hasattr(lib, want), want
+    # no mutable switch at file scope in the kernel sources (immutable `static const` defaults read from the environment
+    # once and mutexes are not switches)
+    csrc = os.path.join(ROOT, "temporal_latticenet_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith(".hip"):
+            for ln in open(os.path.join(csrc, f)):
+                m = re.match(r"^static\s+(?!const\b|constexpr\b|inline\b|thread_local\b)[A-Za-z_0-9:<> \*]+\s+(g_[a-z0-9_]+)\s*(=|;)", ln)
+                assert not (m and "mutex" not in ln), "%s: mutable file-scope variable %s" % (f, ln.strip())
+    # the defaults as tln_options_init writes them
+    o = _lib.Options()
+    _lib.lib().tln_options_init(ctypes.byref(o))
+    assert o.pool_mode == -1 and all(getattr(o, n) in (0, None) for n, _ in _lib.Options._fields_ if n != "pool_mode")
+
+
+def test_host_side_options_context():
+    """temporal_latticenet_amd/options.py: one struct per host thread, nested blocks, explicit push / set / pop, worker
+    threads inherit what run() captured"""
+    import threading
+    from temporal_latticenet_amd import options as O
+    O.reset()
+    assert O.current() is None and O.current_ref() is None and O.generation() == 0
+    with O.options(v2_min_m=1) as a:
+        g1 = O.generation()
+        assert a.v2_min_m == 1 and a.pool_mode == -1 and g1 > 0
+        with O.options(gemm_direct=-1) as b:
+            assert b.v2_min_m == 1 and b.gemm_direct == -1 and O.generation() != g1
+        assert O.current() is a and O.generation() == g1
+        seen = {}
+
+        def worker(opt, gen):
+            seen["before"] = O.current()
+            with O.inherit(opt, gen):
+                seen["inside"] = (O.current().v2_min_m, O.generation())
+            seen["after"] = O.current()
+
+        t = threading.Thread(target=worker, args=(O.current(), O.generation()))
+        t.start()
+        t.join()
+        assert seen == {"before": None, "inside": (1, g1), "after": None}
+        O.set(gemm_pair_off=1)
+        assert O.current().gemm_pair_off == 1 and O.current().v2_min_m == 1 and O.generation() != g1
+    assert O.current() is None
+    with pytest.raises(TypeError):
+        O.push(no_such_field=1)
+    with pytest.raises(RuntimeError):
+        O.set(v2_off=1)
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     from temporal_latticenet_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)
@@ -153,7 +224,7 @@ def test_ctypes_mirrors_match_the_header_layout(tmp_path):
         pytest.skip("no gcc")
     pairs = {"tln_gemm_src": _lib.GemmSrc, "tln_gemm_call": _lib.GemmCall, "tln_slot": _lib.Slot,
              "tln_op_src": _lib.OpSrc, "tln_op": _lib.Op, "tln_gn_desc": _lib.GnDesc,
-             "tln_distribute_call": _lib.DistributeCall}
+             "tln_distribute_call": _lib.DistributeCall, "tln_options": _lib.Options}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "tln.h"', 'int main(void) {']
     for cname, cls in pairs.items():
         lines.append('  printf("%s size %%zu\\n", sizeof(%s));' % (cname, cname))

@@ -6,6 +6,9 @@ import os
 import sys
 
 import torch
+from temporal_latticenet_amd import options as OPT  # noqa: E402
+
+OPT.push()   # kernel-selection options of this host thread (tln_options; the library has no process-wide switch)
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from temporal_latticenet_amd import _lib, ops                      # noqa: E402
@@ -38,8 +41,8 @@ def main():
         res = {}
         for rnd in range(3):
             for sp, wm, g in variants:
-                lib.tln_gemm_force_splits(sp, wm)
-                lib.tln_gemm_force_groups(g)
+                OPT.set(gemm_splits=sp, gemm_wm=wm)
+                OPT.set(gemm_groups=g)
                 src = ops.gemm_src(x, tbl, taps)
                 out = torch.empty(V, cout, device="cuda")
                 for _ in range(3):
@@ -57,8 +60,8 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
                 res.setdefault((sp, wm, g), []).append(e0.elapsed_time(e1) / 20 * 1e3)
-        lib.tln_gemm_force_splits(0, 0)
-        lib.tln_gemm_force_groups(0)
+        OPT.set(gemm_splits=0, gemm_wm=0)
+        OPT.set(gemm_groups=0)
         fl = 2.0 * V * taps * cin * cout
         line = "  ".join("s%dw%dg%d:%5.1f" % (k[0], k[1], k[2], min(v)) for k, v in res.items())
         best = min(res.items(), key=lambda kv: min(kv[1]))

@@ -2,6 +2,9 @@
 """k_gather_gemm in its large-M regime (a fine lattice: sigma 0.05 -> ~170k vertices)."""
 import os, sys
 import torch
+from temporal_latticenet_amd import options as OPT  # noqa: E402
+
+OPT.push()   # kernel-selection options of this host thread (tln_options; the library has no process-wide switch)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from temporal_latticenet_amd import _lib, ops
 from temporal_latticenet_amd.lattice import Lattice
@@ -23,9 +26,9 @@ for cin, cout, taps in [(192, 192, 9), (64, 64, 9), (128, 128, 9), (128, 256, 9)
     for tm, tn in [(0, 0), (1, 1), (2, 1), (1, 2), (2, 2)]:
         if tn == 2 and cout <= 64:
             continue
-        lib.tln_gemm_force_tiles(tm, tn)
+        OPT.set(gemm_tn=tn)
         if (tm, tn) != (0, 0):
-            lib.tln_gemm_force_splits(1, 2)
+            OPT.set(gemm_splits=1, gemm_wm=2)
         src = ops.gemm_src(x, tbl, taps)
         for _ in range(2):
             ops.gather_gemm(V, W, src, out=out)
@@ -36,7 +39,7 @@ for cin, cout, taps in [(192, 192, 9), (64, 64, 9), (128, 128, 9), (128, 256, 9)
         e1.record()
         torch.cuda.synchronize()
         res[(tm, tn)] = e0.elapsed_time(e1) / 5
-        lib.tln_gemm_force_tiles(0, 0)
-        lib.tln_gemm_force_splits(0, 0)
+        OPT.set(gemm_tn=0)
+        OPT.set(gemm_splits=0, gemm_wm=0)
     fl = 2.0 * V * taps * cin * cout
     print("cin=%3d cout=%3d taps=%d | " % (cin, cout, taps) + "  ".join("t%d%d: %6.3f ms %5.1f TF" % (k[0], k[1], v, fl / v / 1e9) for k, v in res.items()))

@@ -2,6 +2,9 @@
 """one heavy shape, direct kernel, G in (1, 2, 4): time per launch (for kernel experiments)"""
 import os, sys
 import torch
+from temporal_latticenet_amd import options as OPT  # noqa: E402
+
+OPT.push()   # kernel-selection options of this host thread (tln_options; the library has no process-wide switch)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from temporal_latticenet_amd import _lib, ops
 from temporal_latticenet_amd.lattice import Lattice
@@ -14,10 +17,10 @@ for t, (p, v) in enumerate(seq):
 V = lat.nr_lattice_vertices()
 x = torch.randn(V, cin, device="cuda"); W = torch.randn(9 * cin, cout, device="cuda"); out = torch.empty(V, cout, device="cuda")
 lib = _lib.lib()
-lib.tln_gemm_force_direct(1)
+OPT.set(gemm_direct=1)
 res = []
 for G in (1, 2, 4, 8, 12):
-    lib.tln_gemm_force_groups(G)
+    OPT.set(gemm_groups=G)
     src = ops.gemm_src(x, lat.neighbour_table_ptr(), 9)
     for _ in range(3):
         ops.gather_gemm(V, W, src, out=out)

@@ -5,6 +5,9 @@ import os
 import sys
 
 import torch
+from temporal_latticenet_amd import options as OPT  # noqa: E402
+
+OPT.push()   # kernel-selection options of this host thread (tln_options; the library has no process-wide switch)
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from temporal_latticenet_amd import _lib, ops                      # noqa: E402
@@ -59,27 +62,27 @@ def main():
         src = ops.gemm_src(x, L.neighbour_table_ptr(), 9)
         fn = lambda: ops.gather_gemm(V, W, src, out=out)
         res = {}
-        lib.tln_gemm_force_direct(0)
+        OPT.set(gemm_direct=0)
         res["auto"] = timed(fn)
-        lib.tln_gemm_force_direct(1)
+        OPT.set(gemm_direct=1)
         for G in (2, 3, 4, 6, 9, 12):
-            lib.tln_gemm_force_groups(G)
+            OPT.set(gemm_groups=G)
             res["d%d" % G] = timed(fn)
-        lib.tln_gemm_force_groups(0)
-        lib.tln_gemm_force_direct(-1)
+        OPT.set(gemm_groups=0)
+        OPT.set(gemm_direct=-1)
         for sp, wm, g in [(1, 1, 4), (1, 1, 2), (1, 2, 4), (1, 2, 2), (2, 1, 2), (2, 2, 2), (2, 2, 4), (4, 2, 2)]:
-            lib.tln_gemm_force_splits(sp, wm)
-            lib.tln_gemm_force_groups(g)
+            OPT.set(gemm_splits=sp, gemm_wm=wm)
+            OPT.set(gemm_groups=g)
             res["t s%dw%dg%d" % (sp, wm, g)] = timed(fn)
         for tm, tn in [(2, 1), (1, 2), (2, 2)]:
-            lib.tln_gemm_force_splits(0, 0)
-            lib.tln_gemm_force_groups(0)
-            lib.tln_gemm_force_tiles(tm, tn)
+            OPT.set(gemm_splits=0, gemm_wm=0)
+            OPT.set(gemm_groups=0)
+            OPT.set(gemm_tn=tn)
             res["t tm%dtn%d" % (tm, tn)] = timed(fn)
-        lib.tln_gemm_force_tiles(0, 0)
-        lib.tln_gemm_force_splits(0, 0)
-        lib.tln_gemm_force_groups(0)
-        lib.tln_gemm_force_direct(0)
+        OPT.set(gemm_tn=0)
+        OPT.set(gemm_splits=0, gemm_wm=0)
+        OPT.set(gemm_groups=0)
+        OPT.set(gemm_direct=0)
         fl = 2.0 * V * 9 * cin * cout
         print("M=%5d cin=%3d cout=%3d | %s" % (V, cin, cout, "  ".join("%s:%.1f" % kv for kv in res.items())), flush=True)
         b = min(res.items(), key=lambda kv: kv[1])

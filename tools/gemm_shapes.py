@@ -5,6 +5,9 @@ import os
 import sys
 
 import torch
+from temporal_latticenet_amd import options as OPT  # noqa: E402
+
+OPT.push()   # kernel-selection options of this host thread (tln_options; the library has no process-wide switch)
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from temporal_latticenet_amd import _lib, ops                      # noqa: E402
@@ -47,11 +50,11 @@ def main():
         for name, tm, tn, g, direct in variants:
             if tn == 2 and cout < 128:
                 continue
-            lib.tln_gemm_v2_config(0 if name.startswith("v2") else 1, 1)
-            lib.tln_gemm_force_tiles(tm, tn)
-            lib.tln_gemm_force_direct(direct)
+            OPT.set(v2_off=0 if name.startswith("v2") else 1, v2_min_m=1)
+            OPT.set(gemm_tn=tn)
+            OPT.set(gemm_direct=direct)
             if tm or tn:
-                lib.tln_gemm_force_splits(1, 2)
+                OPT.set(gemm_splits=1, gemm_wm=2)
             if name.endswith("+gn"):
                 sc, sh = torch.rand(cin, device="cuda") + 0.5, torch.randn(cin, device="cuda")
                 src = ops.gemm_src(x, tbl, taps, scale=sc, shift=sh, relu=True)
@@ -75,10 +78,10 @@ def main():
                 res[name] = e0.elapsed_time(e1) / 10 * 1e3
             except Exception as e:      # a variant the shape cannot take
                 res[name] = float("nan")
-            lib.tln_gemm_force_tiles(0, 0)
-            lib.tln_gemm_force_direct(0)
-            lib.tln_gemm_force_splits(0, 0)
-            lib.tln_gemm_v2_config(0, 12288)
+            OPT.set(gemm_tn=0)
+            OPT.set(gemm_direct=0)
+            OPT.set(gemm_splits=0, gemm_wm=0)
+            OPT.set(v2_off=0, v2_min_m=0)
         fl = 2.0 * V * taps * cin * cout
         print("M=%5d cin=%3d cout=%3d taps=%d | " % (V, cin, cout, taps) +
               "  ".join("%s %6.1f us %5.1f TF" % (k, v, fl / v / 1e6) for k, v in res.items()), flush=True)

@@ -2,6 +2,9 @@
 """Where does one gather-GEMM block spend its cycles?  s_memtime stamps of block (0,0,0)."""
 import ctypes as C, os, sys
 import torch
+from temporal_latticenet_amd import options as OPT  # noqa: E402
+
+OPT.push()   # kernel-selection options of this host thread (tln_options; the library has no process-wide switch)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from temporal_latticenet_amd import _lib, ops
 from temporal_latticenet_amd.lattice import Lattice
@@ -26,9 +29,9 @@ for name, L, cin, cout, taps, use_gn in [("conv 64->64 V0", lat, 64, 64, 9, True
     tbl = L.neighbour_table_ptr() if taps == 9 else None
     for _ in range(3):
         ops.gather_gemm(V, W, ops.gemm_src(prod, tbl, taps), stats=True, gn=(prod, nrm, True) if use_gn else None)
-    lib.tln_gemm_debug_stamps(C.c_void_p(buf.data_ptr()))
+    OPT.set(gemm_stamps=C.c_void_p(buf.data_ptr()))
     ops.gather_gemm(V, W, ops.gemm_src(prod, tbl, taps), stats=True, gn=(prod, nrm, True) if use_gn else None)
-    lib.tln_gemm_debug_stamps(None)
+    OPT.set(gemm_stamps=None)
     torch.cuda.synchronize()
     s = buf.cpu().tolist()
     d = [(s[i + 1] - s[i]) for i in range(4)]

@@ -15,6 +15,9 @@ from temporal_latticenet_amd.streams import share_parameters  # noqa: E402
 from temporal_latticenet_amd.synthetic import make_sequence  # noqa: E402
 from temporal_latticenet_amd.workload import turned  # noqa: E402
 from tests.helpers import randomize_parameters  # noqa: E402
+from temporal_latticenet_amd import options as OPT  # noqa: E402
+
+OPT.push()   # kernel-selection options of this host thread (tln_options; the library has no process-wide switch)
 
 KINDS = {0: "K1/levels/tables", 2: "GN_PARTIALS", 3: "POOL", 4: "GRU", 5: "AFLOW", 8: "COPY", 11: "SLICE_DEFORM"}
 
@@ -48,9 +51,9 @@ def main():
             models[0].reset_sequence()
             return outs
 
-        lib.tln_gemm_v2_config(0, 1)
+        OPT.set(v2_off=0, v2_min_m=1)
         want = [solo(k) for k in range(G)]
-        lib.tln_gemm_v2_config(0, 12288)
+        OPT.set(v2_off=0, v2_min_m=0)
 
         def group():
             lats = [make_lattice(contents) for _ in range(G)]
@@ -66,11 +69,11 @@ def main():
 
         for mask_name, mask in [("all batched", 0)] + [("without " + nm, 1 << k) for k, nm in KINDS.items()] + \
                 [("nothing batched", sum(1 << k for k in KINDS))]:
-            lib.tln_program_group_config(mask)
+            OPT.set(group_off_mask=mask)
             got = group()
             worst = [max(float((got[k][t] - want[k][t]).abs().max()) for k in range(G)) for t in range(T)]
             print("%-28s max |group - solo| per frame: %s" % (mask_name, " ".join("%.3e" % w for w in worst)), flush=True)
-        lib.tln_program_group_config(0)
+        OPT.set(group_off_mask=0)
 
 
 if __name__ == "__main__":

@@ -20,6 +20,9 @@ import torch  # noqa: E402
 
 from tests.helpers import build_model, make_config, make_lattice, oracle_pair, randomize_parameters  # noqa: E402
 from temporal_latticenet_amd.synthetic import make_sequence  # noqa: E402
+from temporal_latticenet_amd import options as OPT  # noqa: E402
+
+OPT.push()   # kernel-selection options of this host thread (tln_options; the library has no process-wide switch)
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "run"
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 120000
@@ -28,9 +31,9 @@ records = []
 for a in sys.argv[3:]:
     if a.startswith("direct"):
         from temporal_latticenet_amd import _lib
-        _lib.lib().tln_gemm_force_direct(1)
+        OPT.set(gemm_direct=1)
         if "=" in a:
-            _lib.lib().tln_gemm_force_groups(int(a.split("=")[1]))
+            OPT.set(gemm_groups=int(a.split("=")[1]))
 for rnn in (("gru", "gru", "aflow", "gru"), ("gru", "gru", "gru", "gru")):
     contents = make_config(rnn_modules=rnn, frames=4, sigma=0.6)
     torch.manual_seed(20240607)          # the modules' default initialisation: the same weights on every run

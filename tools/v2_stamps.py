@@ -5,6 +5,9 @@ sample of blocks adds its loop time, the time it waited for its own DMAs and the
 (s_memtime ticks of 10 ns) to counters behind tln_gemm_debug_stamps."""
 import ctypes as C, os, sys
 import torch
+from temporal_latticenet_amd import options as OPT  # noqa: E402
+
+OPT.push()   # kernel-selection options of this host thread (tln_options; the library has no process-wide switch)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from temporal_latticenet_amd import _lib, ops
 from temporal_latticenet_amd.lattice import Lattice
@@ -34,9 +37,9 @@ for name, cin, cout, taps, use_gn in [("64->64 x9 gn", 64, 64, 9, True), ("128->
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 100
     buf.zero_()
-    lib.tln_gemm_debug_stamps(C.c_void_p(buf.data_ptr()))
+    OPT.set(gemm_stamps=C.c_void_p(buf.data_ptr()))
     run()
-    lib.tln_gemm_debug_stamps(None)
+    OPT.set(gemm_stamps=None)
     torch.cuda.synchronize()
     s = buf.cpu().tolist()
     tot, dma, bar, chunks, waves = s[16:21]
