@@ -68,12 +68,15 @@ def parse():
                          "913 clouds/s at 4 streams x 1, 1160 at 4 x 3, 1220 at 4 x 6 and 4 x 8")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) on the GPU node; gloo for rehearsals")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: all ranks use cuda:0")
-    ap.add_argument("--frames-extra", choices=["gloo", "nccl", "off"], default="gloo",
+    ap.add_argument("--frames-extra", choices=["auto", "gloo", "nccl", "off"], default="auto",
                     help="N > 1, --mode sequences: also time the frame-sharded pipeline and report it as `frames_mode` "
-                         "beside the sequence-sharded `value`.  gloo (default): over a side group with host-staged "
-                         "hand-offs — the path every rehearsal has exercised, so a problem in it cannot cost the run its "
-                         "line; nccl: over RCCL / xGMI as --mode frames does (what the north star asks; not yet run on "
-                         "hardware); off: skip")
+                         "beside the sequence-sharded `value`.  The measurement runs in CHILD processes (one per rank, a "
+                         "process group of their own on another port) that the parents wait for with a time limit: "
+                         "whatever happens in there cannot cost the run its line.  auto (default): RCCL / xGMI first — the "
+                         "transport the north star names — and, if that attempt fails on any rank, host-staged gloo; the "
+                         "line says which transport ran.  nccl / gloo: that transport only; off: skip")
+    ap.add_argument("--frames-child", default=None, help=argparse.SUPPRESS)     # internal: the child of --frames-extra
+    ap.add_argument("--frames-extra-timeout", type=float, default=420.0, help="seconds a parent waits for its child")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-points", type=int, default=120000, help="points per frame of the CPU sample")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="lower bound of CPU work in the sample")
@@ -103,8 +106,135 @@ def gemm_bytes(meta):
     return b
 
 
+def frames_child(args):
+    """The frame-sharded pipeline (BASELINE config 4's cut: rank g owns frame-slot g; per-sequence all-gather of the
+    first-touch-ordered vertex keys, point-to-point hand-off of the fusion modules' hidden states —
+    temporal_latticenet_amd/dist.py) timed in a process group of its own.  Launched by the ranks of the main job as
+    CHILD processes (`--frames-extra`), so that a hang or a failure in here ends with a killed child, not with a lost line.
+    Prints ONE JSON object on rank 0: latency of one sequence alone in the pipeline and the steady-state rate."""
+    import datetime
+    import torch
+    import torch.distributed as dist
+    backend = args.frames_child
+    world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
+    local_rank = 0 if args.same_device else int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    if backend == "gloo":
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")          # rendezvous is on 127.0.0.1
+    kw = {"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}
+    dist.init_process_group(backend, timeout=datetime.timedelta(seconds=120), **kw)
+    from temporal_latticenet_amd import dist as D
+    from temporal_latticenet_amd.configs import build_model, make_config, make_lattice
+    from temporal_latticenet_amd.synthetic import make_sequence
+    via_host = backend != "nccl"
+    dev = None if via_host else "cuda"
+    plan = D.FrameShardPlan(args.frames, rank, world)
+    group = None
+    if plan.nr_groups > 1:
+        for gi in range(plan.nr_groups):                            # (collective: every rank creates every group)
+            gr = dist.new_group(list(range(gi * plan.group_size, (gi + 1) * plan.group_size)))
+            if gi == plan.group:
+                group = gr
+    from temporal_latticenet_amd.configs import suggest_capacity
+    contents = make_config(rnn_modules=tuple(args.rnn.split(",")), frames=args.frames, sigma=args.sigma,
+                           capacity=suggest_capacity(args.points, args.sigma, args.frames), scale_constant=args.scale_constant)
+    quiet = contextlib.redirect_stdout(io.StringIO())
+    with quiet:
+        torch.manual_seed(1234)                                     # the same weights on every rank
+        model = build_model(contents).eval()
+    frames = [(torch.from_numpy(p).cuda(), torch.from_numpy(v).cuda())
+              for p, v in make_sequence(args.points, args.frames, seed=1234 + plan.group)]
+
+    def barrier():
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        with quiet:
+            run_sequence(model, make_lattice(contents), frames)   # creates the lazily built parameters
+        runner = D.FrameShardRunner(model, lambda: make_lattice(contents), plan, group=group, via_host=via_host)
+        mine = {f: frames[f] for f in plan.frames}
+
+        def steps(n):
+            runner.run_stream([mine] * n, on_output=lambda i, out: None)
+
+        steps(max(1, args.warmup))
+        lat = []
+        for _ in range(3):                                          # ONE sequence alone in the pipeline
+            barrier()
+            t_ = time.perf_counter()
+            steps(1)
+            barrier()
+            lat.append(D.max_over_ranks(time.perf_counter() - t_, device=dev))
+        barrier()
+        t0 = time.perf_counter()
+        steps(args.steps)
+        barrier()
+        el = D.max_over_ranks(time.perf_counter() - t0, device=dev)
+        runner.close()
+    if rank == 0:
+        print(json.dumps({
+            "latency_ms_per_sequence": round(min(lat) * 1e3, 3),
+            "steady_state_clouds_per_s": round(plan.nr_groups * args.steps * args.frames / el, 3), "steps": args.steps,
+            "ranks_per_sequence": plan.group_size, "groups": plan.nr_groups,
+            "transport": "RCCL (device tensors over xGMI): all-gather of the vertex keys, ncclSend/Recv of the hidden "
+                         "states, one message per state" if not via_host else
+                         "gloo: vertex keys and hidden states staged through host memory",
+            "backend": backend}), flush=True)
+    dist.destroy_process_group()
+
+
+def run_frames_extra(args, rank, world, barrier, agree):
+    """--frames-extra from the parents' side: every rank starts ONE child (this script with --frames-child <backend>) in
+    a process group of its own (MASTER_PORT + 29 / + 58), waits for it with a time limit and kills it when the limit
+    passes.  The parents only ever talk to each other on their own healthy group (`agree`: a MIN all-reduce of "my child
+    ended with rc 0"), so a failed attempt costs time, never the line.  Returns the dict for `frames_mode`."""
+    import subprocess
+    order = {"auto": ["nccl", "gloo"], "nccl": ["nccl"], "gloo": ["gloo"]}[args.frames_extra]
+    if args.dist_backend != "nccl":
+        order = ["gloo"]                                            # rehearsals (several ranks on one GPU)
+    n_f = max(2, args.steps // 4)
+    tried = []
+    for attempt, backend in enumerate(order):
+        env = dict(os.environ)
+        env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 29 * (attempt + 1))
+        env["TLN_HANDOFF_TIMEOUT_S"] = env.get("TLN_HANDOFF_TIMEOUT_S", "60")
+        cmd = [sys.executable, os.path.abspath(__file__), "--frames-child", backend, "--steps", str(n_f), "--warmup",
+               str(max(1, args.warmup // 2)), "--points", str(args.points), "--frames", str(args.frames), "--sigma",
+               str(args.sigma), "--rnn", args.rnn] + (["--same-device"] if args.same_device else []) + \
+              (["--scale-constant", args.scale_constant] if args.scale_constant else [])
+        barrier()
+        t0 = time.perf_counter()
+        proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        try:
+            out, err = proc.communicate(timeout=args.frames_extra_timeout)
+            ok, why = proc.returncode == 0, "rc %d: %s" % (proc.returncode, err.strip().splitlines()[-1][:300] if err.strip() else "")
+        except subprocess.TimeoutExpired:
+            proc.kill()                                             # (this child, by its handle)
+            out, err = proc.communicate()
+            ok, why = False, "no result after %.0f s (killed)" % args.frames_extra_timeout
+        all_ok = agree(ok)
+        res = None
+        if all_ok and rank == 0:
+            lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+            res = json.loads(lines[-1]) if lines else None
+        if all_ok and (rank != 0 or res is not None):
+            if rank == 0:
+                res["attempts"] = tried + [{"backend": backend, "ok": True, "wall_s": round(time.perf_counter() - t0, 1)}]
+                res["note"] = ("the frames of every sequence sharded over %d ranks (rank g owns frame-slot g), %d group(s), "
+                               "measured by child processes in a process group of their own; latency: one %d-frame sequence "
+                               "alone through the pipeline (best of 3); steady state: sequences back to back, key exchange one "
+                               "sequence ahead.  `value` above is the sequence-sharded rate of the same ranks"
+                               % (res["ranks_per_sequence"], res["groups"], args.frames))
+            return res
+        tried.append({"backend": backend, "ok": False, "rank0": why if not ok else "another rank's child failed"})
+    return {"error": "every transport failed", "attempts": tried}
+
+
 def main():
     args = parse()
+    if args.frames_child:
+        return frames_child(args)
     import torch
     import torch.distributed as dist
 
@@ -128,8 +258,11 @@ def main():
     from temporal_latticenet_amd.synthetic import make_sequence
 
     rnn = tuple(args.rnn.split(","))
-    contents = make_config(rnn_modules=rnn, frames=args.frames, sigma=args.sigma, capacity=1 << 18,
-                           scale_constant=args.scale_constant)
+    # hash_table_capacity from the cloud size and the lattice scale (configs.suggest_capacity: 3 x the expected vertex count;
+    # cfg:71 makes it a hand-set knob), not 1 << 18: every per-vertex array and table of the level stack is sized by it
+    from temporal_latticenet_amd.configs import suggest_capacity
+    contents = make_config(rnn_modules=rnn, frames=args.frames, sigma=args.sigma,
+                           capacity=suggest_capacity(args.points, args.sigma, args.frames), scale_constant=args.scale_constant)
     quiet = contextlib.redirect_stdout(io.StringIO())   # the model prints its layer list like the reference does
     with quiet:
         torch.manual_seed(1234)
@@ -163,10 +296,8 @@ def main():
             runner = D.FrameShardRunner(model, lambda: make_lattice(contents), plan, group=group, via_host=via_host)
             mine = {f: frames[f] for f in plan.frames}
 
-            def run_steps(n):
-                keys = runner.exchange_keys([mine] * n)
-                for i in range(n):
-                    runner.run_sequence(mine, keys[i])
+            def run_steps(n):           # key exchange per sequence, one sequence ahead (dist.FrameShardRunner.run_stream)
+                runner.run_stream([mine] * n, on_output=lambda i, out: None)
 
             def one_sequence_latency():
                 # ONE sequence alone in the pipeline: from the first rank's start to the last rank's end
@@ -227,65 +358,14 @@ def main():
         frames_extra = None
         if not frames_mode and world > 1 and args.frames_extra != "off" and \
                 (args.frames % world == 0 or world % args.frames == 0):
-            def time_frames_extra():
-                plan2 = D.FrameShardPlan(args.frames, rank, world)
-                x_backend = args.frames_extra if args.dist_backend == "nccl" else args.dist_backend
-                x_host = x_backend != "nccl"
-                if x_backend == "gloo" and args.dist_backend != "gloo":
-                    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")      # rendezvous is on 127.0.0.1
-                group2 = None
-                for gi in range(plan2.nr_groups):                           # (collective: every rank creates every group)
-                    # (gloo: a collective of the side group that does not complete raises after 90 s instead of holding the
-                    #  job's line back for the default half hour; the point-to-point hand-offs have their own time-out)
-                    kw2 = {"timeout": datetime.timedelta(seconds=90)} if x_backend == "gloo" else {}
-                    gr = dist.new_group(list(range(gi * plan2.group_size, (gi + 1) * plan2.group_size)), backend=x_backend, **kw2)
-                    if gi == plan2.group:
-                        group2 = gr
-                fr2 = frames if plan2.group == 0 and rank == 0 else \
-                    [(torch.from_numpy(p).cuda(), torch.from_numpy(v).cuda())
-                     for p, v in make_sequence(args.points, args.frames, seed=1234 + plan2.group)]
-                runner2 = D.FrameShardRunner(model, lambda: make_lattice(contents), plan2, group=group2, via_host=x_host)
-                mine2 = {f: fr2[f] for f in plan2.frames}
-                dev = None if via_host else "cuda"                          # (the MAX over ranks on the job's own group)
-
-                def steps2(n):
-                    keys = runner2.exchange_keys([mine2] * n)
-                    for i in range(n):
-                        runner2.run_sequence(mine2, keys[i])
-
-                def latency2():
-                    barrier()
-                    t_ = time.perf_counter()
-                    steps2(1)
-                    barrier()
-                    return D.max_over_ranks(time.perf_counter() - t_, device=dev)
-
-                try:
-                    n_f = max(2, args.steps // 4)
-                    steps2(max(1, args.warmup // 2))
-                    lat2 = min(latency2() for _ in range(3))
-                    barrier()
-                    t0_ = time.perf_counter()
-                    steps2(n_f)
-                    barrier()
-                    el2 = D.max_over_ranks(time.perf_counter() - t0_, device=dev)
-                finally:
-                    runner2.close()
-                return {"latency_ms_per_sequence": round(lat2 * 1e3, 3),
-                        "steady_state_clouds_per_s": round(plan2.nr_groups * n_f * args.frames / el2, 3), "steps": n_f,
-                        "ranks_per_sequence": plan2.group_size, "groups": plan2.nr_groups,
-                        "transport": "RCCL (device tensors over xGMI)" if not x_host else
-                                     "gloo side group: vertex keys and hidden states staged through host memory "
-                                     "(--frames-extra nccl: RCCL)",
-                        "note": "the frames of every sequence sharded over %d ranks (rank g owns frame-slot g: all-gather of "
-                                "the per-frame vertex keys, point-to-point hand-off of the fusion modules' hidden states), "
-                                "%d group(s); latency: one %d-frame sequence alone through the pipeline (best of 3); "
-                                "steady state: sequences back to back.  `value` above is the sequence-sharded rate of the "
-                                "same ranks" % (plan2.group_size, plan2.nr_groups, args.frames)}
+            def agree(ok):
+                t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=None if via_host else "cuda")
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                return bool(int(t.item()))
 
             try:
-                frames_extra = time_frames_extra()
-            except Exception as e:                                          # never at the price of the line
+                frames_extra = run_frames_extra(args, rank, world, barrier, agree)
+            except Exception as e:                      # (the parents' own group is untouched by the children)
                 frames_extra = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
 
         # ---- what the timed region computed, checked: one more step of the same configuration with the outputs kept;
@@ -293,6 +373,21 @@ def main():
         checked, kept0 = None, None
         if not frames_mode and rank == 0:
             checked, kept0 = self_check(pool, per_stream, S, per, model, contents, make_lattice)
+
+        # device memory per resident sequence, by owner (tln_lattice_memory / tln_program_memory)
+        memory = None
+        if not frames_mode and rank == 0:
+            MB = 1.0 / (1 << 20)
+            lats = [l.memory_bytes() for l in pool.lattices]
+            progs = [m._program.memory_bytes() for m in pool.models if getattr(m, "_program", None) is not None]
+            free_b, total_b = torch.cuda.mem_get_info()
+            nseq = max(1, len(lats))
+            memory = {"resident_sequences": len(lats), "hash_table_capacity": pool.lattices[0].capacity(),
+                      "lattice_MB_per_sequence": {k: round(sum(x[k] for x in lats) * MB / nseq, 1) for k in lats[0]},
+                      "program_MB_per_sequence": ({k: round(sum(x[k] for x in progs) * MB / max(1, len(progs)), 1) for k in progs[0]}
+                                                  if progs else None),
+                      "replanned_frames": sum(m._program.replans() for m in pool.models if getattr(m, "_program", None) is not None),
+                      "device_used_MB": round((total_b - free_b) * MB, 1), "torch_reserved_MB": round(torch.cuda.memory_reserved() * MB, 1)}
 
         # vertex counts of the workload (data dependent; printed with every result)
         model.reset_sequence()
@@ -487,6 +582,14 @@ def main():
                             gbps = gs_by[k] / (gs_ms[k] * 1e-3) / 1e9
                             gst[nm] = {"algorithmic_bytes": round(gs_by[k] / gs_n[k]), "us_per_frame": round(gs_ms[k] * 1e3 / gs_n[k], 2),
                                        "GBps": round(gbps, 1), "frac": round(gbps / HBM_PEAK_GBPS, 4), "frames": gs_n[k]}
+                    # HBM-side bytes per frame of those batched launches (the --pmc passes of tools/profile_set.sh taken
+                    # with --streams 1 --pairs 8: profiles/pmc_traffic_group.json)
+                    pmcg = os.path.join(ROOT, "profiles", "pmc_traffic_group.json")
+                    if os.path.exists(pmcg) and default_workload and per == 8:
+                        with open(pmcg) as f:
+                            for nm, v in json.load(f).get("scatter_hbm_bytes_per_frame", {}).items():
+                                if nm in gst:
+                                    gst[nm]["traffic"] = round(v)
                     g_b = sum(gs_by[k] / gs_n[k] for k in range(3) if gs_n[k])
                     g_t = sum(gs_ms[k] / gs_n[k] for k in range(3) if gs_n[k]) * 1e-3
                     scatter["group_mode"] = {
@@ -552,6 +655,7 @@ def main():
                                                               "lattice_gpu.scale_constant = %s" % args.scale_constant)},
             "value_h2d": None if value_h2d is None else round(value_h2d, 3),
             "roofline": roof, "roofline_scatter": scatter, "cpu_baseline": cpu, "checked": checked,
+            "memory": memory,
         }
         if not frames_mode and frames_extra is not None:
             line["frames_mode"] = frames_extra

@@ -591,6 +591,11 @@ int tln_program_set_options(tln_program_t* p, const tln_options* opt);
 /* device memory the program owns, in bytes: out[0] arena of the frame's temporaries (capacity), [1] its high-water mark in
  * the last frame, [2] the K1 output buffer, [3] the hidden-state buffers, [4] total of 0, 2, 3 */
 int tln_program_memory(const tln_program_t* p, int64_t* out /* [5] */);
+/* The arena, the hidden-state buffers and every coarse-level temporary of a frame are planned BEFORE the coarse levels'
+ * vertex counts have reached the host, with a prediction (old count + max(2048, r_i x new level-0 vertices), r = 1, 1/2,
+ * ...) instead of the lattice's hard bound (4^i x new level-0 vertices); a frame whose exact counts exceed the prediction
+ * is planned again with them (same results; the arena may grow with its contents kept).  Number of such frames: */
+int64_t tln_program_replans(const tln_program_t* p);
 /* device pointers of the current frame's K1 outputs ([4N, 3+val_dim+1], [4N], [4N]); valid until the next frame */
 int tln_program_frame_rows(tln_program_t* p, const float** d_distributed, const int32_t** d_indices,
                            const float** d_weights, int64_t* rows, int* cols);

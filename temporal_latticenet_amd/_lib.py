@@ -86,6 +86,7 @@ _PROTOS = {
     "tln_lattice_destroy": (_i, [_vp]),
     "tln_lattice_memory": (_i, [_vp, C.POINTER(_i64)]),
     "tln_program_memory": (_i, [_vp, C.POINTER(_i64)]),
+    "tln_program_replans": (_i64, [_vp]),
     "tln_options_init": (None, [C.POINTER(Options)]),
     "tln_lattice_set_options": (_i, [_vp, C.POINTER(Options)]),
     "tln_program_set_options": (_i, [_vp, C.POINTER(Options)]),

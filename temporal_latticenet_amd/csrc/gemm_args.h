@@ -40,6 +40,7 @@ struct GemmArgs {
   float* slab;      // split-K partial tiles [S][tiles][TM*TN*16][GT]
   int* counters;    // split-K arrival counters [tiles], zero between launches
   int splits;
+  int fold_taps;    // gemm_v2: taps per partial sum of the split accumulation (fills the padding behind `splits`)
   unsigned long long* dbg;  // diagnostic: s_memtime stamps of block (0,0,0) (tools/gemm_stamps.py), else NULL
   // the GRU cell as ONE product (gemm_v2.hip, k_gather_gemm_v2_gru): weights and bias of the second source (h)
   const float* W2;

@@ -134,6 +134,7 @@ struct tln_lattice {
   struct TlnBinRec* bin_rec = nullptr;   // [rows_cap] {position, value | barycentric weight, row id, vertex (-1: none), 0}
   int64_t bins_rows = -1;         // rows of the frame the bins hold (-1: none)
   // ---- partitioned K1 (k_bk_*): the rows of a frame split by key hash into buckets, one workgroup per bucket
+  float4* posv = nullptr;         // [rows_cap / 4] the frame's points as {x, y, z, value} (partitioned K1)
   uint4* rec = nullptr;           // [rec_cap] 16-byte row records {weight, row, key}, grouped by (split block, bucket)
   int64_t rec_cap = 0;
   uint32_t* bk_off = nullptr;     // [bk_maxb + 1][split blocks] first record of a bucket inside a split block's region
@@ -169,8 +170,11 @@ int tln_lat_pool_ws(tln_lattice* l, int64_t elems, unsigned long long** out) {
     }
     l->pool_packed = nullptr;
     l->pool_packed_elems = 0;
-    int64_t want = l->capacity * 64;
-    if (want < elems) want = elems;
+    // sized for what the level holds (+ half again: the lattice grows from frame to frame), not for its capacity: the
+    // capacity is a bound the caller picks generously (cfg:71) and 512 bytes per possible vertex were 128 MB per sequence
+    int64_t want = elems + elems / 2;
+    if (want < (1 << 20)) want = 1 << 20;
+    if (want > l->capacity * 64 && l->capacity * 64 >= elems) want = l->capacity * 64;
     TLN_HIP(hipMalloc(&l->pool_packed, (size_t)want * sizeof(unsigned long long)));
     TLN_HIP(hipMemset(l->pool_packed, 0, (size_t)want * sizeof(unsigned long long)));
     TLN_HIP(hipDeviceSynchronize());
@@ -199,9 +203,10 @@ static int ensure_rows(tln_lattice* l, int64_t rows) {
   while (cap < rows) cap <<= 1;
   void* ptrs[] = {l->row_slot, l->block_cnt, l->sk_in, l->sk_out, l->sv_in, l->sv_out, l->sort_temp, l->pieces,
                   l->row_rank, l->bin_rec, l->rec, l->bk_off, l->first_flag,
-                  l->bucket_rows, l->bits_pre};
+                  l->bucket_rows, l->bits_pre, l->posv};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  l->posv = nullptr;
   l->row_slot = l->block_cnt = l->sk_in = l->sk_out = l->sv_in = l->sv_out = nullptr;
   l->row_rank = nullptr;
   l->bin_rec = nullptr;
@@ -228,6 +233,7 @@ static int ensure_rows(tln_lattice* l, int64_t rows) {
     l->rec_cap = cap + cap / 128 + 4 * TLN_BK_MAX_PPB;
     l->bk_maxb = (int)(cap / 128 < TLN_BK_MINB ? TLN_BK_MINB : (cap / 128 > TLN_BK_MAXB ? TLN_BK_MAXB : cap / 128));
     TLN_HIP(hipMalloc(&l->rec, (size_t)l->rec_cap * sizeof(uint4)));
+    TLN_HIP(hipMalloc(&l->posv, (size_t)(cap / 4 + 1) * sizeof(float4)));
     TLN_HIP(hipMalloc(&l->bk_off, (size_t)TLN_BK_SPLIT_BLOCKS * (l->bk_maxb + 1) * sizeof(uint32_t)));
     TLN_HIP(hipMalloc(&l->first_flag, cap * sizeof(uint32_t)));
     TLN_HIP(hipMemset(l->first_flag, 0, cap * sizeof(uint32_t)));
@@ -402,7 +408,7 @@ extern "C" int tln_lattice_destroy(tln_lattice_t* l) {
                   l->row_slot, l->block_cnt, l->sk_in, l->sk_out, l->sv_in, l->sv_out, l->sort_temp,
                   l->seg_start, l->pool_packed, l->mean, l->pieces, l->slot_cnt, l->vslot, l->vcnt, l->vstart,
                   l->row_rank, l->bin_rec, l->rec, l->bk_off, l->first_flag,
-                  l->bucket_rows, l->bits_pre, l->vstamp};
+                  l->bucket_rows, l->bits_pre, l->vstamp, l->posv};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (l->h_ctr) (void)hipHostFree(l->h_ctr);
@@ -1658,6 +1664,7 @@ __device__ __forceinline__ uint32_t bk_block_scan(uint32_t v, uint32_t* wtmp /* 
 struct BkJob {
   const float* pos;
   const float* val;
+  float4* posv;              // [n] {x, y, z, value}: written by k_bk_split, gathered by k_bk_place (one 16-byte load per row)
   float* weights;
   float* dist;
   uint4* rec;                // 16-byte row records {weight bits, row, key lo, key hi}, grouped by (split block, bucket)
@@ -1721,6 +1728,9 @@ __global__ void __launch_bounds__(1024) k_bk_split(const BkJobs jobs) {
       atomicAdd(&bk_hist[bk_bucket(K, slot_mask, shift)], 1u);
     }
     *reinterpret_cast<float4*>(weights + 4 * p) = make_float4(bary[0], bary[1], bary[2], bary[3]);
+    // the point as ONE 16-byte record for k_bk_place's gather by row id (position 12 B + value 4 B from two arrays were
+    // two cache lines per row, and with eight frames per launch their 15 MB no longer sat in an XCD's L2: PMC FETCH_SIZE)
+    J.posv[p] = make_float4(x, y, z, val_dim ? val[p] : 0.0f);
     if (dist) {   // the [4N, 3 + val_dim + 1] rows (val_dim <= 1 on this path): raw position, value, weight
       const int cols = 3 + val_dim + 1;
       float* d = dist + 4 * p * cols;
@@ -1979,12 +1989,15 @@ __global__ void __launch_bounds__(TLN_BK_THREADS) __attribute__((amdgpu_waves_pe
   unsigned long long (*hsum)[TLN_BK_HT] = reinterpret_cast<unsigned long long (*)[TLN_BK_HT]>(bk_dyn);   // [3][HT] fixed-point position sums; afterwards reused:
   int* hstart = reinterpret_cast<int*>(&hsum[0][0]);   //   [HT] first bin position of the entry's vertex
   int* hv = hstart + TLN_BK_HT;                        //   [HT] vertex of the entry (-1: none)
+  // ... and, behind them, the first BK_STAGE bin records of the bucket: its bin range [bin0, bin0 + R) is contiguous, so
+  // the records are collected here and leave as whole lines (round 3 wrote each 32-byte record where its lane happened
+  // to be: 15 MB of scattered half-lines per frame); a bucket with more rows writes the rest directly
+  constexpr int BK_STAGE = (int)((3 * TLN_BK_HT * sizeof(unsigned long long) - 2 * TLN_BK_HT * sizeof(int)) / sizeof(TlnBinRec));
+  TlnBinRec* bstage = reinterpret_cast<TlnBinRec*>(hv + TLN_BK_HT);
   __shared__ uint32_t wtmp[16];
   __shared__ uint32_t s_tail;
   const int tid = threadIdx.x, b = blockIdx.x;
   const TableRef t = J.t;
-  const float* __restrict__ pos = J.pos;
-  const float* __restrict__ val = J.val_dim ? J.val : nullptr;
   for (int i = tid; i < TLN_BK_HT; i += TLN_BK_THREADS) {
     hk[i] = TLN_KEY_EMPTY;
     hcnt[i] = 0;
@@ -2002,10 +2015,8 @@ __global__ void __launch_bounds__(TLN_BK_THREADS) __attribute__((amdgpu_waves_pe
 #pragma unroll
   for (int k = 0; k < BK_KEEP; ++k)
     if (k < rn.total) kb[k] = *bk_rec_of(rn, k);
-  auto payload = [&](uint32_t row) {
-    const uint32_t p = row >> 2;
-    return make_float4(pos[3 * p], pos[3 * p + 1], pos[3 * p + 2], val ? val[p] : 0.0f);
-  };
+  const float4* __restrict__ posv = J.posv;
+  auto payload = [&](uint32_t row) { return posv[row >> 2]; };   // (x, y, z, value): one 16-byte load
 #pragma unroll
   for (int k = 0; k < BK_KEEP; ++k)
     if (k < rn.total) ka[k] = payload(kb[k].y);
@@ -2124,8 +2135,10 @@ __global__ void __launch_bounds__(TLN_BK_THREADS) __attribute__((amdgpu_waves_pe
     uint32_t dest;
     if (vv >= 0) dest = (uint32_t)hstart[he] + atomicAdd(&hcnt[he], 1u);
     else dest = bin0 + P + atomicAdd(&s_tail, 1u);
-    bin_rec[dest].a = a;   // (both halves of the 32-byte record: one memory transaction, not one per array)
-    bin_rec[dest].m = make_uint4(bb.x, bb.y, (uint32_t)vv, 0u);
+    const uint32_t local = dest - bin0;
+    TlnBinRec* out = local < (uint32_t)BK_STAGE ? bstage + local : bin_rec + dest;
+    out->a = a;   // (both halves of the 32-byte record together)
+    out->m = make_uint4(bb.x, bb.y, (uint32_t)vv, 0u);
     if (indices) indices[bb.y] = vv;   // (NULL: nobody slices this frame — a scattered 4-byte store per row saved)
   };
 #pragma unroll
@@ -2136,6 +2149,13 @@ __global__ void __launch_bounds__(TLN_BK_THREADS) __attribute__((amdgpu_waves_pe
     place_row(payload(bb.y), bb);
   }
   __syncthreads();
+  // the staged records, as consecutive 16-byte pieces: whole lines
+  {
+    const int nst = (int)(R < (uint32_t)BK_STAGE ? R : (uint32_t)BK_STAGE);
+    const uint4* src = reinterpret_cast<const uint4*>(bstage);
+    uint4* dst = reinterpret_cast<uint4*>(bin_rec + bin0);
+    for (int i = tid; i < 2 * nst; i += TLN_BK_THREADS) dst[i] = src[i];
+  }
 }
 
 // accessors for pool.hip: the bins of the last distribute, if they describe (d_distributed, rows)
@@ -2241,6 +2261,7 @@ static int bk_fill_job(tln_lattice* l, const float* d_positions, const float* d_
   J = BkJob{};
   J.pos = d_positions;
   J.val = d_values;
+  J.posv = l->posv;
   J.weights = d_weights;
   J.dist = d_distributed;
   J.rec = l->rec;
@@ -3265,7 +3286,7 @@ static void lattice_memory_one(const tln_lattice* l, int64_t* out) {
   int64_t b = 0;
   if (rc > 0) {
     b += 5 * rc * 4 + (rc / TLN_SCAN_BLOCK + 2) * 4 + (rc / 256 + 2) * 48 + (int64_t)l->sort_temp_bytes;
-    if (l->bin_rec) b += rc * 4 + rc * (int64_t)sizeof(TlnBinRec) + l->rec_cap * 16 +
+    if (l->bin_rec) b += rc * 4 + rc * (int64_t)sizeof(TlnBinRec) + l->rec_cap * 16 + (rc / 4 + 1) * 16 +
                          (int64_t)TLN_BK_SPLIT_BLOCKS * (l->bk_maxb + 1) * 4 + rc * 4 + (int64_t)l->bk_maxb * 4 + (rc / 128 + 8) * 4;
   }
   const int64_t c = l->pool_packed_elems * 8;

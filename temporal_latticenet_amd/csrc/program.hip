@@ -165,7 +165,12 @@ struct tln_program {
   tln_lattice_t* lat = nullptr;
   tln_lattice_t* levels[TLN_MAX_LEVELS] = {nullptr};
   int64_t V[TLN_MAX_LEVELS] = {0};   // exact vertex counts (coarse levels: valid once the pending fetch is finished)
-  int64_t Vb[TLN_MAX_LEVELS] = {0};  // upper bounds, known right after tln_program_begin_frame
+  int64_t Vb[TLN_MAX_LEVELS] = {0};  // what the sizing walk plans with, known right after tln_program_begin_frame: level 0
+                                     // exact; coarse levels a PREDICTION (predict_bounds) capped by the hard bound
+  int64_t Vhard[TLN_MAX_LEVELS] = {0};   // the lattice's hard upper bounds (a fine vertex touches at most 4 coarse ones)
+  int64_t v0_prev = 0;               // level-0 count after the previous frame of this sequence (0: none)
+  double pred_scale = 1.0;           // doubled whenever a prediction was exceeded (replan)
+  int64_t replans = 0;               // frames whose coarse counts exceeded the prediction
   bool exact_known = false;          // V[1..] hold the exact counts
   int split = 0;                     // ops [0, split) only touch level 0: launched before the coarse counts arrive
   int64_t N = 0;
@@ -255,9 +260,14 @@ void for_outputs(const tln_op& o, F f) {
   if (o.stats_out >= 0) f(o.stats_out);
 }
 
-// One walk over the op list.  dry: only the arena bookkeeping (to size the arena); else launch.
-int walk(tln_program* p, bool dry, int early, float* d_out, int64_t out_rows, int out_cols, hipStream_t s,
+// One walk over the op list.  WALK_DRY: only the arena bookkeeping (to size the arena); WALK_RUN: launch; WALK_REPLAY:
+// everything a launching walk does to the bookkeeping (buffers resolved, states marked) but nothing is launched — how
+// replan() re-establishes the state behind ops that have already run after the arena moved.
+enum { WALK_RUN = 0, WALK_DRY = 1, WALK_REPLAY = 2 };
+int walk(tln_program* p, int mode, int early, float* d_out, int64_t out_rows, int out_cols, hipStream_t s,
          int op_begin, int op_end, bool fresh) {
+  const bool dry = mode == WALK_DRY;
+  const bool nolaunch = mode != WALK_RUN;
   if (fresh) {
     p->alloc.reset();
     for (auto& r : p->rt) r = SlotRt();
@@ -357,7 +367,7 @@ int walk(tln_program* p, bool dry, int early, float* d_out, int64_t out_rows, in
         const tln_slot& so = p->slots[o.out];
         const int64_t M = p->rt[o.out].rows;
         if (o.s0.gn_stats >= 0) want_scratch(0, (size_t)2 * p->slots[o.s0.slot].cols * sizeof(float));
-        if (dry) break;
+        if (nolaunch) break;
         tln_gemm_src a[2];
         const tln_op_src* os[2] = {&o.s0, &o.s1};
         for (int k = 0; k < 2; ++k) {
@@ -422,7 +432,7 @@ int walk(tln_program* p, bool dry, int early, float* d_out, int64_t out_rows, in
         break;
       }
       case TLN_OP_GN_PARTIALS: {
-        if (dry) break;
+        if (nolaunch) break;
         const tln_slot& ss = p->slots[o.s0.slot];
         if (p->defer && group_batches(p->opt, TLN_OP_GN_PARTIALS)) {
           p->pend_gn = tln_gn_partials_call{fptr(o.s0.slot), p->rt[o.s0.slot].rows, p->rt[o.stats_out].ptr};
@@ -439,7 +449,7 @@ int walk(tln_program* p, bool dry, int early, float* d_out, int64_t out_rows, in
         break;
       }
       case TLN_OP_POOL: {
-        if (dry) break;
+        if (nolaunch) break;
         const int nl = o.i[0];
         const float* w[4] = {o.p[0], o.p[1], o.p[2], o.p[3]};
         const float* b[4] = {o.p[4], o.p[5], o.p[6], o.p[7]};
@@ -465,7 +475,7 @@ int walk(tln_program* p, bool dry, int early, float* d_out, int64_t out_rows, in
         const int64_t Vr = p->rt[o.out].rows;
         const int Cn = p->slots[o.out].cols;
         want_scratch(0, (size_t)p->rt[o.out].rows_b * 6 * Cn * sizeof(float));
-        if (dry) break;
+        if (nolaunch) break;
         if (p->defer && !p->capture && group_batches(p->opt, TLN_OP_GRU)) {
           p->pend_gru = tln_gru_call{fptr(o.s0.slot), fptr(o.s1.slot), Vr, p->rt[o.s1.slot].rows, fptr(o.out),
                                      reinterpret_cast<float*>(scratch[0]), Vr * 6 * Cn};
@@ -501,7 +511,7 @@ int walk(tln_program* p, bool dry, int early, float* d_out, int64_t out_rows, in
         const int Cn = p->slots[o.out].cols;
         want_scratch(0, (size_t)p->rt[o.out].rows_b * TLN_TAPS * sizeof(float));
         want_scratch(1, (size_t)p->rt[o.out].rows_b * TLN_TAPS * sizeof(int32_t));
-        if (dry) break;
+        if (nolaunch) break;
         const int32_t* tp = nullptr;
         TLN_REQUIRE(p->levels[o.s0.level], "op %d: level %d does not exist", oi, o.s0.level);
         rc = tln_neighbour_table(p->levels[o.s0.level], &tp, s);
@@ -522,7 +532,7 @@ int walk(tln_program* p, bool dry, int early, float* d_out, int64_t out_rows, in
         break;
       }
       case TLN_OP_SLICE_GATHER: {
-        if (dry) break;
+        if (nolaunch) break;
         TLN_REQUIRE(p->idx_valid, "op %d: the frame was begun without its vertex indices", oi);
         if (p->timing && !p->tset[2]) {
           TLN_HIP(hipEventRecord(p->tev[4], s));
@@ -535,7 +545,7 @@ int walk(tln_program* p, bool dry, int early, float* d_out, int64_t out_rows, in
         break;
       }
       case TLN_OP_SLICE: {
-        if (dry) break;
+        if (nolaunch) break;
         TLN_REQUIRE(p->idx_valid, "op %d: the frame was begun without its vertex indices", oi);
         if (p->timing && !p->tset[2]) {
           TLN_HIP(hipEventRecord(p->tev[4], s));
@@ -548,7 +558,7 @@ int walk(tln_program* p, bool dry, int early, float* d_out, int64_t out_rows, in
         break;
       }
       case TLN_OP_SLICE_DEFORM: {
-        if (dry) break;
+        if (nolaunch) break;
         TLN_REQUIRE(p->idx_valid, "op %d: the frame was begun without its vertex indices", oi);
         if (p->defer && group_batches(p->opt, TLN_OP_SLICE_DEFORM)) {
           const int ncls = p->slots[o.s1.slot].cols;
@@ -574,20 +584,20 @@ int walk(tln_program* p, bool dry, int early, float* d_out, int64_t out_rows, in
         break;
       }
       case TLN_OP_LSTM_GATES: {
-        if (dry) break;
+        if (nolaunch) break;
         rc = tln_lstm_gates(fptr(o.s0.slot), p->rt[o.out].rows, p->slots[o.out].cols, fptr(o.out), s);
         if (rc) return rc;
         break;
       }
       case TLN_OP_TEMPORAL_MAX: {
-        if (dry) break;
+        if (nolaunch) break;
         rc = tln_temporal_max(fptr(o.s0.slot), fptr(o.s1.slot), p->rt[o.out].rows, p->rt[o.s1.slot].rows,
                               p->slots[o.out].cols, o.f[0], fptr(o.out), s);
         if (rc) return rc;
         break;
       }
       case TLN_OP_CGA_GATE: {
-        if (dry) break;
+        if (nolaunch) break;
         const int64_t Vr = p->rt[o.out].rows;
         const int Cn = p->slots[o.out].cols;
         TLN_REQUIRE(o.i[0] >= 0 && o.i[0] < p->n_states, "op %d: bad state id", oi);
@@ -597,14 +607,14 @@ int walk(tln_program* p, bool dry, int early, float* d_out, int64_t out_rows, in
         break;
       }
       case TLN_OP_FILL_EMPTY: {
-        if (dry) break;
+        if (nolaunch) break;
         rc = tln_fill_empty_rows(fptr(o.s0.slot), p->rt[o.out].rows, p->slots[o.out].cols, o.i[0], o.f[0], fptr(o.out),
                                  s);
         if (rc) return rc;
         break;
       }
       case TLN_OP_COPY: {
-        if (dry) break;
+        if (nolaunch) break;
         const tln_slot& ss = p->slots[o.s0.slot];
         const tln_slot& so = p->slots[o.out];
         const int64_t rows = p->rt[o.s0.slot].rows;
@@ -643,7 +653,7 @@ int walk(tln_program* p, bool dry, int early, float* d_out, int64_t out_rows, in
       }
       case TLN_OP_ZERO_ROW0: {
         TLN_REQUIRE(p->rt[o.out].live, "op %d: zero-row on an unwritten slot", oi);
-        if (dry) break;
+        if (nolaunch) break;
         if (p->rt[o.out].rows > 0)
           TLN_HIP(hipMemsetAsync(fptr(o.out), 0, (size_t)p->slots[o.out].cols * sizeof(float), s));
         break;
@@ -651,7 +661,7 @@ int walk(tln_program* p, bool dry, int early, float* d_out, int64_t out_rows, in
       case TLN_OP_STOP_IF_EARLY: {
         if (!early) break;
         finished = true;
-        if (dry) break;
+        if (nolaunch) break;
         const tln_slot& ss = p->slots[o.s0.slot];
         const int64_t rows = p->rt[o.s0.slot].rows;
         TLN_REQUIRE(d_out && rows == out_rows && ss.cols == out_cols,
@@ -687,8 +697,59 @@ int walk(tln_program* p, bool dry, int early, float* d_out, int64_t out_rows, in
   return TLN_OK;
 }
 
+// Planning sizes of the coarse levels.  The lattice only knows HARD bounds before its counters arrive (level i: old count
+// + 4^i x the new level-0 vertices; the second coarse level of a first frame: 16 x V0, capped by the capacity) and the
+// arena, the hidden-state buffers and every coarse temporary used to be reserved for them: ~1 GB of arena and 0.5 GB of
+// state buffers per resident sequence for a working set of 0.2 GB (round 3's "2 GB per sequence").  The walk plans with a
+// PREDICTION instead — old count + max(2048, r_i x new level-0 vertices), r = 1, 1/2, 1/4 ... (measured: 0.3-0.45 and
+// 0.1-0.15 on lidar lattices from sigma 0.07 to 1.0), times pred_scale — and replan() repairs the rare frame whose exact
+// counts exceed it.
+void predict_bounds(tln_program* p, const int64_t* hard) {
+  const int64_t v0 = hard[0];
+  const int64_t dv0 = (p->v0_prev > 0 && p->v0_prev <= v0) ? v0 - p->v0_prev : v0;
+  double r = 1.0;
+  p->Vhard[0] = p->Vb[0] = v0;
+  for (int i = 1; i <= p->n_coarse; ++i) {
+    p->Vhard[i] = hard[i];
+    const int64_t old = p->levels[i] ? tln_lattice_nr_vertices(p->levels[i]) : 0;   // (the count before this frame)
+    const double grow = r * p->pred_scale * (double)dv0;
+    int64_t pred = (old > 0 ? old : 0) + (int64_t)(grow < 2048.0 ? 2048.0 : grow);
+    p->Vb[i] = pred < hard[i] ? pred : hard[i];
+    r *= 0.5;
+  }
+}
+
+// exact coarse counts against the hard bounds (an error) and the prediction (true: replan needed)
+int check_counts(tln_program* p, bool* exceeded) {
+  *exceeded = false;
+  for (int i = 1; i <= p->n_coarse; ++i) {
+    p->V[i] = tln_lattice_nr_vertices(p->levels[i]);
+    TLN_REQUIRE(p->V[i] <= p->Vhard[i], "level %d has %lld vertices, more than the bound %lld", i, (long long)p->V[i],
+                (long long)p->Vhard[i]);
+    if (p->V[i] > p->Vb[i]) *exceeded = true;
+  }
+  p->exact_known = true;
+  return TLN_OK;
+}
+
+// The exact coarse counts exceed what the frame was planned with; ops [0, upto) have run.  Plan again with the exact
+// counts (the placements of everything those ops wrote are the same: they were decided before any coarse slot), grow the
+// arena with its contents kept, and re-establish the walk state behind op `upto` without launching anything.
+int replan(tln_program* p, int upto, int early, float* d_out, int64_t out_rows, int out_cols, hipStream_t s) {
+  for (int i = 1; i <= p->n_coarse; ++i) p->Vb[i] = p->V[i];
+  p->pred_scale *= 2.0;
+  ++p->replans;
+  const int n_ops = (int)p->ops.size();
+  int rc = walk(p, WALK_DRY, early, nullptr, out_rows, out_cols, s, 0, n_ops, true);
+  if (rc) return rc;
+  rc = ensure_buf(p->arena, p->alloc.high + kAlign, s, true);
+  if (rc) return rc;
+  return walk(p, WALK_REPLAY, early, d_out, out_rows, out_cols, s, 0, upto, true);
+}
+
 // the frame that wrote a hidden state is over: the new buffer becomes the stored one
 void commit_states(tln_program* p) {
+  p->v0_prev = p->V[0];
   for (int st = 0; st < p->n_states; ++st)
     if (p->w_wrote[st]) {
       p->state_cur[st] = 1 - p->state_cur[st];
@@ -792,6 +853,7 @@ extern "C" int tln_program_reset(tln_program_t* p) {
     p->state_rows[st] = 0;
   }
   p->frame_open = false;
+  p->v0_prev = 0;
   return TLN_OK;
 }
 
@@ -831,6 +893,7 @@ extern "C" int tln_program_begin_frame_start(tln_program_t* p, tln_lattice_t* l,
   if (reset_hashmap) {
     rc = tln_lattice_clear(l, s);
     if (rc) return rc;
+    p->v0_prev = 0;
   }
   p->timing_group = 1;
   if (p->timing) {
@@ -879,6 +942,7 @@ extern "C" int tln_program_begin_frame_group(tln_program_t* const* pp, tln_latti
   if (reset_hashmap) {
     int rc = tln_lattice_clear_multi(ll, count, s);
     if (rc) return rc;
+    for (int k = 0; k < count; ++k) pp[k]->v0_prev = 0;
   }
   tln_program* p0 = pp[0];
   for (int k = 0; k < count; ++k) {
@@ -917,11 +981,11 @@ extern "C" int tln_program_begin_frame_group(tln_program_t* const* pp, tln_latti
     for (int i = 0; i <= p->n_coarse; ++i) {
       TLN_REQUIRE(lv, "level %d does not exist", i);
       p->levels[i] = lv;
-      p->Vb[i] = vb[(size_t)k * TLN_MAX_LEVELS + i];
-      p->V[i] = i == 0 ? p->Vb[0] : -1;
-      v_out[(size_t)k * TLN_MAX_LEVELS + i] = p->Vb[i];
+      p->V[i] = i == 0 ? vb[(size_t)k * TLN_MAX_LEVELS] : -1;
+      v_out[(size_t)k * TLN_MAX_LEVELS + i] = vb[(size_t)k * TLN_MAX_LEVELS + i];
       lv = tln_lattice_coarse_level(lv);
     }
+    predict_bounds(p, vb + (size_t)k * TLN_MAX_LEVELS);
     p->frame_open = true;
   }
   return TLN_OK;
@@ -943,11 +1007,11 @@ extern "C" int tln_program_begin_frame_finish(tln_program_t* p, int64_t* v_out, 
   for (int i = 0; i <= p->n_coarse; ++i) {
     TLN_REQUIRE(lv, "level %d does not exist", i);
     p->levels[i] = lv;
-    p->Vb[i] = vb[i];
     p->V[i] = i == 0 ? vb[0] : -1;
     v_out[i] = vb[i];   // level 0 exact; coarse levels: upper bounds (the exact counts follow in tln_program_run)
     lv = tln_lattice_coarse_level(lv);
   }
+  predict_bounds(p, vb);
   p->frame_open = true;
   return TLN_OK;
 }
@@ -966,24 +1030,21 @@ extern "C" int tln_program_run(tln_program_t* p, int early, float* d_out, int64_
   hipStream_t s = (hipStream_t)stream_;
   const int n_ops = (int)p->ops.size();
   // sizing pass over the whole op list with the upper bounds of the coarse vertex counts
-  int rc = walk(p, true, early, nullptr, out_rows, out_cols, s, 0, n_ops, true);
+  int rc = walk(p, WALK_DRY, early, nullptr, out_rows, out_cols, s, 0, n_ops, true);
   if (rc) return rc;
   rc = ensure_buf(p->arena, p->alloc.high + kAlign, s);
   if (rc) return rc;
   p->calls.clear();
   // level-0 prefix: on the GPU while the coarse counts are still travelling to the host
-  rc = walk(p, false, early, d_out, out_rows, out_cols, s, 0, p->split, true);
+  rc = walk(p, WALK_RUN, early, d_out, out_rows, out_cols, s, 0, p->split, true);
   // the exact coarse counts (waits for the fetch only) and the coarse tables
   int rc2 = tln_lattice_prepare_levels_finish(p->lat, s);
   if (rc == TLN_OK) rc = rc2;
   if (rc == TLN_OK) {
-    for (int i = 1; i <= p->n_coarse; ++i) {
-      p->V[i] = tln_lattice_nr_vertices(p->levels[i]);
-      TLN_REQUIRE(p->V[i] <= p->Vb[i], "level %d has %lld vertices, more than the bound %lld", i, (long long)p->V[i],
-                  (long long)p->Vb[i]);
-    }
-    p->exact_known = true;
-    if (!p->w_finished) rc = walk(p, false, early, d_out, out_rows, out_cols, s, p->split, n_ops, false);
+    bool exceeded = false;
+    rc = check_counts(p, &exceeded);
+    if (rc == TLN_OK && exceeded && !p->w_finished) rc = replan(p, p->split, early, d_out, out_rows, out_cols, s);
+    if (rc == TLN_OK && !p->w_finished) rc = walk(p, WALK_RUN, early, d_out, out_rows, out_cols, s, p->split, n_ops, false);
   }
   if (rc == TLN_OK) commit_states(p);
   p->frame_open = false;
@@ -1049,23 +1110,24 @@ static int seg_walk_to(tln_program* p, int op_end, hipStream_t s) {
   int rc = TLN_OK;
   if (p->seg_cursor < p->split && op_end > p->seg_cursor) {
     const int e = op_end < p->split ? op_end : p->split;
-    rc = walk(p, false, p->seg_early, p->seg_out, p->seg_out_rows, p->seg_out_cols, s, p->seg_cursor, e, false);
+    rc = walk(p, WALK_RUN, p->seg_early, p->seg_out, p->seg_out_rows, p->seg_out_cols, s, p->seg_cursor, e, false);
     if (rc) return rc;
     p->seg_cursor = e;
   }
   if (op_end > p->split && !p->seg_levels_done) {
     rc = tln_lattice_prepare_levels_finish(p->lat, s);
     if (rc) return rc;
-    for (int i = 1; i <= p->n_coarse; ++i) {
-      p->V[i] = tln_lattice_nr_vertices(p->levels[i]);
-      TLN_REQUIRE(p->V[i] <= p->Vb[i], "level %d has %lld vertices, more than the bound %lld", i, (long long)p->V[i],
-                  (long long)p->Vb[i]);
+    bool exceeded = false;
+    rc = check_counts(p, &exceeded);
+    if (rc) return rc;
+    if (exceeded && !p->w_finished) {
+      rc = replan(p, p->seg_cursor, p->seg_early, p->seg_out, p->seg_out_rows, p->seg_out_cols, s);
+      if (rc) return rc;
     }
-    p->exact_known = true;
     p->seg_levels_done = true;
   }
   if (op_end > p->seg_cursor && !p->w_finished) {
-    rc = walk(p, false, p->seg_early, p->seg_out, p->seg_out_rows, p->seg_out_cols, s, p->seg_cursor, op_end, false);
+    rc = walk(p, WALK_RUN, p->seg_early, p->seg_out, p->seg_out_rows, p->seg_out_cols, s, p->seg_cursor, op_end, false);
     if (rc) return rc;
   }
   if (op_end > p->seg_cursor) p->seg_cursor = op_end;
@@ -1077,13 +1139,13 @@ extern "C" int tln_program_run_begin(tln_program_t* p, int early, float* d_out, 
   TLN_REQUIRE(p && p->frame_open && !p->seg_open, "tln_program_run_begin without an open frame");
   hipStream_t s = (hipStream_t)stream_;
   const int n_ops = (int)p->ops.size();
-  int rc = walk(p, true, early, nullptr, out_rows, out_cols, s, 0, n_ops, true);   // sizing (resets the walk state)
+  int rc = walk(p, WALK_DRY, early, nullptr, out_rows, out_cols, s, 0, n_ops, true);   // sizing (resets the walk state)
   if (rc) return rc;
   rc = ensure_buf(p->arena, p->alloc.high + kAlign, s);
   if (rc) return rc;
   p->calls.clear();
   // the launching walk starts from a fresh allocator too: an empty range with fresh = true
-  rc = walk(p, false, early, d_out, out_rows, out_cols, s, 0, 0, true);
+  rc = walk(p, WALK_RUN, early, d_out, out_rows, out_cols, s, 0, 0, true);
   if (rc) return rc;
   p->seg_open = true;
   p->seg_levels_done = p->n_coarse == 0;
@@ -1292,7 +1354,7 @@ int walk_group(tln_program* const* pp, int n, int early, float* const* d_out, co
       p->has_pending = false;
       if (at[k] >= end || (p->w_finished && !(fresh && first))) continue;
       p->defer = true;
-      rc = walk(p, false, early, d_out[k], out_rows[k], out_cols, s, at[k], end, fresh && first);
+      rc = walk(p, WALK_RUN, early, d_out[k], out_rows[k], out_cols, s, at[k], end, fresh && first);
       p->defer = false;
       at[k] = p->w_next;
       any = any || p->has_pending;
@@ -1322,7 +1384,7 @@ extern "C" int tln_program_run_group(tln_program_t* const* pp, int n, int early,
   const int n_ops = (int)pp[0]->ops.size();
   int rc = TLN_OK;
   for (int k = 0; k < n && !rc; ++k) {
-    rc = walk(pp[k], true, early, nullptr, out_rows[k], out_cols, s, 0, n_ops, true);
+    rc = walk(pp[k], WALK_DRY, early, nullptr, out_rows[k], out_cols, s, 0, n_ops, true);
     if (!rc) rc = ensure_buf(pp[k]->arena, pp[k]->alloc.high + kAlign, s);
     pp[k]->calls.clear();
   }
@@ -1341,12 +1403,10 @@ extern "C" int tln_program_run_group(tln_program_t* const* pp, int n, int early,
   for (int k = 0; k < n; ++k) {
     tln_program* p = pp[k];
     if (rc == TLN_OK) {
-      for (int i = 1; i <= p->n_coarse; ++i) {
-        p->V[i] = tln_lattice_nr_vertices(p->levels[i]);
-        TLN_REQUIRE(p->V[i] <= p->Vb[i], "level %d has %lld vertices, more than the bound %lld", i, (long long)p->V[i],
-                    (long long)p->Vb[i]);
-      }
-      p->exact_known = true;
+      bool exceeded = false;
+      rc = check_counts(p, &exceeded);
+      if (rc == TLN_OK && exceeded && !p->w_finished)
+        rc = replan(p, p->split, early, d_out[k], out_rows[k], out_cols, s);
     }
   }
   if (rc == TLN_OK) rc = walk_group(pp, n, early, d_out, out_rows, out_cols, s, pp[0]->split, n_ops, false);
@@ -1424,6 +1484,8 @@ extern "C" int tln_program_memory(const tln_program_t* p, int64_t* out) {
   out[4] = out[0] + out[2] + out[3];
   return TLN_OK;
 }
+// frames whose exact coarse vertex counts exceeded the planning prediction and were planned again (predict_bounds / replan)
+extern "C" int64_t tln_program_replans(const tln_program_t* p) { return p ? p->replans : -1; }
 
 extern "C" int tln_program_set_options(tln_program_t* p, const tln_options* opt) {
   TLN_REQUIRE(p, "null program");

@@ -332,6 +332,49 @@ class FrameShardRunner:
             per_seq.append(allk)
         return per_seq
 
+    # ---- a stream of sequences ------------------------------------------------------------------
+    def run_stream(self, sequences, on_output=None):
+        """sequences: list of {frame index: (positions, values)} (the frames this rank owns).  The key exchange is done
+        PER SEQUENCE and one sequence ahead: the keys of sequence i + 1 are hashed (scratch lattice) and all-gathered
+        before the frames of sequence i are enqueued — on a side stream when the tensors travel over RCCL, so that the
+        collective overlaps sequence i's kernels — instead of one exchange for the whole batch up front (round 3), which
+        put every rank's scratch K1 of the whole batch in front of the first frame.  Returns the outputs of
+        run_sequence per sequence (or hands each to on_output and keeps nothing)."""
+        outs = []
+        if not sequences:
+            return outs
+        side = None
+        if not self.via_host and torch.cuda.is_available():
+            if getattr(self, "_key_stream", None) is None:
+                self._key_stream = torch.cuda.Stream()
+            side = self._key_stream
+
+        def exchange(frames):
+            if side is None:
+                return self.exchange_keys([frames])[0], None
+            cur = torch.cuda.current_stream()
+            side.wait_stream(cur)              # (the frames were produced on the caller's stream)
+            with torch.cuda.stream(side):
+                keys = self.exchange_keys([frames])[0]
+                ev = torch.cuda.Event()
+                ev.record(side)
+            for k in keys:
+                k.record_stream(cur)           # allocated on the side stream, consumed by insert_keys on the caller's
+            return keys, ev
+
+        nxt = exchange(sequences[0])
+        for i, frames in enumerate(sequences):
+            keys, ev = nxt
+            nxt = exchange(sequences[i + 1]) if i + 1 < len(sequences) else None
+            if ev is not None:
+                torch.cuda.current_stream().wait_event(ev)
+            out = self.run_sequence(frames, keys)
+            if on_output is not None:
+                on_output(i, out)
+            else:
+                outs.append(out)
+        return outs
+
     # ---- one sequence ---------------------------------------------------------------------------
     def run_sequence(self, frames, all_keys):
         """frames: {frame index: (positions, values)} of the frames this rank owns.  Returns the model output

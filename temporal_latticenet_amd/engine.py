@@ -397,6 +397,10 @@ class FrameProgram:
         _lib.check(_lib.lib().tln_program_memory(self._h, out), "tln_program_memory")
         return dict(zip(("arena", "arena_high_water", "k1_buffer", "hidden_states", "total"), (int(x) for x in out)))
 
+    def replans(self):
+        """frames whose exact coarse vertex counts exceeded the planning prediction (tln_program_replans)"""
+        return int(_lib.lib().tln_program_replans(self._h))
+
     def apply_options(self, *lattices):
         """hands the kernel-selection options in force on this host thread (options.py; none = the library's defaults) to
         this program's handle and to the lattices of the frame: the library itself keeps no process-wide switch"""

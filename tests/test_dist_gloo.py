@@ -89,8 +89,7 @@ def _handoff_out_of_step(rank):
     if rank == 0:
         ch = D._channel(None, 1)
         hdr = torch.tensor([D._MAGIC, D._sent[ch], 5, 1, 2, 0, 0, 0], dtype=torch.int64)
-        D._sent[ch] += 1
-        dist.send(hdr, 1, tag=6)
+        dist.send(hdr, 1, tag=6)          # (not counted: the receiver rejects it, and counts completed messages only)
     else:
         with pytest.raises(D.HandoffError, match="out of step"):
             D.recv_tensor(0, "cpu", tag=6)

@@ -213,3 +213,88 @@ def test_slice_head_writes_log_softmax(gpu):
     assert logsm.shape == raw.shape == (9000, 26)
     np.testing.assert_allclose(logsm.cpu().numpy(), want.cpu().numpy(), rtol=2e-6, atol=2e-6)
     np.testing.assert_allclose(torch.exp(logsm).sum(1).cpu().numpy(), 1.0, rtol=0, atol=1e-5)
+
+
+def test_a_frame_whose_coarse_levels_outgrow_the_planning_prediction_is_planned_again(gpu):
+    """The frame program sizes its arena and every coarse-level buffer before the coarse levels' vertex counts have reached
+    the host, with a prediction (old count + max(2048, r x new level-0 vertices), program.hip::predict_bounds) instead of
+    the lattice's hard bound (4 / 16 x): ~0.3 GB per resident sequence instead of 1.9.  A cloud of ISOLATED points (every
+    fine vertex far from the next: up to four coarse vertices each) breaks the prediction: the frame is planned again with
+    the exact counts (replan: arena regrown with its contents kept, walk state replayed) and gives the operator route's
+    bits; so does the lock-step group."""
+    from temporal_latticenet_amd.models import forward_group
+    from temporal_latticenet_amd.streams import share_parameters
+    contents = make_config(rnn_modules=("gru", "gru", "aflow", "gru"), frames=2, sigma=0.05, capacity=1 << 17)
+    rng = np.random.default_rng(3)
+    seq = []
+    for t in range(2):              # 6000 points scattered over (60 m)^3: no two share a lattice cell at sigma 0.05
+        pos = (rng.uniform(-30, 30, (6000, 3))).astype(np.float32)
+        seq.append((pos, rng.uniform(0, 1, (6000, 1)).astype(np.float32)))
+    model = build_model(contents).eval()
+    _run(model, contents, seq, gpu)
+    randomize_parameters(model, seed=23)
+    model.use_frame_program = False
+    want, _ = _run(model, contents, seq, gpu)
+    model.use_frame_program = True
+    got, used = _run(model, contents, seq, gpu)
+    assert all(used)
+    prog = model._program
+    assert prog is not None and prog.replans() >= 1, "the fixture was meant to break the prediction"
+    lat = make_lattice(contents)
+    with torch.no_grad():
+        model(lat, torch.from_numpy(seq[0][0]).to(gpu), torch.from_numpy(seq[0][1]).to(gpu), True, False)
+    l1 = lat.coarsen()
+    v0, v1, v2 = lat.nr_lattice_vertices(), l1.nr_lattice_vertices(), l1.coarsen().nr_lattice_vertices()
+    model.reset_sequence()
+    # more coarse vertices than the prediction allows for (old count + max(2048, r x new level-0 vertices), r = 1, 1/2)
+    assert v1 > v0 + 2048 or v2 > v0 // 2 + 2048, (v0, v1, v2)
+    for t in range(2):
+        for j in range(2):
+            if t == 1 and j == 0:       # (the program's slice head writes its own log-softmax: torch's differs in the last bits)
+                assert float((got[t][j] - want[t][j]).abs().max()) < 1e-5
+            else:
+                assert torch.equal(got[t][j], want[t][j]), "frame %d output %d" % (t, j)
+    # the same through a lock-step group of two
+    twin = build_model(contents).eval()
+    _run(twin, contents, seq, gpu)
+    twin = share_parameters(twin, model)
+    before = prog.replans()
+    prog.apply_options()
+    lats = [make_lattice(contents), make_lattice(contents)]
+    with torch.no_grad():
+        for t in range(2):
+            pos = [torch.from_numpy(seq[t][0]).to(gpu)] * 2
+            val = [torch.from_numpy(seq[t][1]).to(gpu)] * 2
+            res = forward_group([model, twin], lats, pos, val, t != 1)
+            for k in range(2):
+                assert torch.equal(res[k][1], want[t][1]), "group member %d frame %d" % (k, t)
+                lats[k] = res[k][2]
+    for m in (model, twin):
+        m.reset_sequence()
+    assert model._program.replans() > before - 1
+
+
+def test_memory_of_a_resident_sequence(gpu):
+    """~2 GB per resident sequence for a working set of 0.15 GB.  With the capacity taken from the cloud size
+    (configs.suggest_capacity), the pool's accumulators sized by the vertices the level holds and the frame planned with
+    predicted coarse counts: <= 0.6 GB per 4 x 120k sequence, by owner (tln_lattice_memory / tln_program_memory)."""
+    contents = make_config(rnn_modules=("gru", "gru", "aflow", "gru"), frames=4, sigma=0.6, capacity="auto")
+    seq = make_sequence(120000, 4, seed=1234)
+    model = build_model(contents).eval()
+    for rep in range(2):            # (the first sequence creates the lazily built parameters on the operator route)
+        lat = make_lattice(contents, nr_points=120000, frames=4)
+        assert lat.capacity() <= 110000
+        with torch.no_grad():
+            for t, (p, v) in enumerate(seq):
+                a, b, lat = model(lat, torch.from_numpy(p).to(gpu), torch.from_numpy(v).to(gpu), t != 3, False)
+        if rep == 0:
+            model.reset_sequence()
+    assert model._program is not None and model._program_active
+    lm, pm = lat.memory_bytes(), model._program.memory_bytes()
+    model.reset_sequence()
+    print("[memory] lattice %s" % {k: round(v / 2 ** 20, 1) for k, v in lm.items()})
+    print("[memory] program %s replans %d" % ({k: round(v / 2 ** 20, 1) for k, v in pm.items()}, model._program.replans()))
+    assert lat.overflow_rows() == 0 and lat.nr_lattice_vertices() > 25000
+    assert model._program.replans() == 0
+    assert lm["total"] + pm["total"] <= 600 * 2 ** 20, (lm, pm)
+    assert pm["arena"] <= 2.0 * pm["arena_high_water"] + 2 ** 24

@@ -54,9 +54,9 @@ plan = D.FrameShardPlan(T, rank, world)
 runner = D.FrameShardRunner(model, lambda: make_lattice(contents), plan, via_host=True, use_program=use_program)
 mine = [{f: s[f] for f in plan.frames} for s in seqs]
 with torch.no_grad():
-    keys = runner.exchange_keys(mine)
-    for i, frames in enumerate(mine):
-        out = runner.run_sequence(frames, keys[i])
+    # the stream of sequences as bench.py drives it: key exchange per sequence, one sequence ahead (run_stream)
+    outs = runner.run_stream(mine)
+    for i, out in enumerate(outs):
         if plan.owns_last_frame():
             assert torch.equal(out[1], want[i]), "frame-sharded logits differ from the sequential run (seq %%d)" %% i
             if os.environ.get("TLN_TEST_ORACLE") == "1":
