@@ -36,8 +36,8 @@ typedef double f64x8 __attribute__((ext_vector_type(8)));
 
 #define V2_STAGES 3
 #ifndef V2_FOLD
-#define V2_FOLD 1   // split accumulation (see v2_body); 0: one chain over all of K (measurement builds)
-#endif
+#define V2_FOLD 7   // split accumulation (see v2_body) per column-tile count of a wave: bit 0 TN = 1, bit 1 TN = 2, bit 2 TN = 3;
+#endif              // 0: one chain over all of K (measurement builds: TLN_EXTRA_FLAGS=-DV2_FOLD=3 ...)
 
 // GRU = true (only <4,2,1,3, W_NK, !PRO>, N = 3C, C a multiple of 64): the whole GRU cell (K9) as ONE product with two
 // sources: the K loop runs over the C channels of x (weights W_ih, g.W) and then over the C channels of h (W_hh, g.W2;
@@ -135,9 +135,16 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
     // the headline workload, at the end of the vertex order) has nothing but zero rows of h: its h chunks — half its K
     // loop — would add exact zeros and are skipped (same bits)
     if (GRU && g.fold_taps && m0 >= (int64_t)g.s[1].src_rows) mask = 1u;   // (fold_taps: the GRU launch's switch for this, host)
-    int n_present = 0;
+    int n_present = 0, prev_group = -1;
     for (int k = 0; k < taps; ++k)
-      if ((mask >> k) & 1u) Taps[1 + n_present++] = k;
+      if ((mask >> k) & 1u) {
+        // [23 + i], i = 1..8 (words 24..31: behind the waves' masks): the accumulators are folded before the i-th present
+        // tap (split accumulation below): its group of g.fold_taps LOGICAL taps differs from the previous present tap's
+        const int grp = k / (g.fold_taps > 0 ? g.fold_taps : 1);
+        if (n_present > 0) Taps[23 + n_present] = grp != prev_group ? 1 : 0;
+        prev_group = grp;
+        Taps[1 + n_present++] = k;
+      }
     Taps[0] = n_present;
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -250,7 +257,7 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
   // stays independent of the row order / tap skipping, as before.
   // Only the [K,N]-weight instantiations fold: those are the 9-tap products (convolutions, coarsen, finefy); the [N,K]
   // ones are 1 x 1 linears and GRU projections (K <= 2 x 256: a short chain) and keep their registers.
-  constexpr bool FOLD = !GRU && !W_NK && V2_FOLD;
+  constexpr bool FOLD = !GRU && !W_NK && ((V2_FOLD >> (TN - 1)) & 1);
   f32x16 tot[FOLD ? TM : 1][FOLD ? TN : 1];
   if constexpr (FOLD) {
 #pragma unroll
@@ -260,7 +267,6 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) tot[i][j][r] = 0.0f;
   }
-  const int fold_taps = g.fold_taps;   // taps per partial sum (host: ~V2_FOLD_K k values; uniform)
 
   const int arow0 = wm * 32 * TM + l31;       // this lane's A row of tile 0 inside the block
   const int bcol0 = wn * 32 * TN + l31;       // this lane's B column of tile 0 inside the block
@@ -384,28 +390,16 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
   const unsigned long long st_begin = __builtin_amdgcn_s_memtime();
   const unsigned long long st_rbegin = __builtin_amdgcn_s_memrealtime();
 #endif
-  // the body of chunk t in ring stage ST (a compile-time constant: every LDS address below is register + immediate)
-  auto chunk = [&](int t, auto stage) {
-    // GRU: the chunks of x come first, then those of h.  The n gate needs gi_n and gh_n apart: at the first chunk of h the
-    // n-gate tile (x's share, complete) moves to the extra tile and starts again from zero for h's share — once per block,
-    // a uniform branch; the K loop itself is the same for both sources
-    if (GRU && t == cpt) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          acc[i][TNA - 1][r] = acc[i][TN - 1][r];
-          acc[i][TN - 1][r] = 0.0f;
-        }
-    }
-    constexpr int st = decltype(stage)::value;
-    constexpr int stn = st == STAGES - 1 ? 0 : st + 1;
-    const int ti = t / cpt;
+  // split accumulation: `tot += acc; acc = 0` in front of the first chunk of a present tap that opens another group of
+  // logical taps (flags in Taps[24 ..], block prologue).  Checked BETWEEN chunk bodies with two scalar counters — inside
+  // the chunk body the check made the compiler emit five bodies instead of three and a division per chunk.
+  int fold_tap = 0, fold_next = cpt;          // the tap the next chunk belongs to, the chunk index where the next tap starts
+  auto fold_check = [&](int t) {
     if constexpr (FOLD) {
-      // first chunk of a tap whose group differs from the previous present tap's: fold (uniform branch, once per group)
-      if (t > 0 && t == ti * cpt) {
-        const int ga = __builtin_amdgcn_readfirstlane(Taps[ti]) / fold_taps, gb = __builtin_amdgcn_readfirstlane(Taps[1 + ti]) / fold_taps;
-        if (ga != gb) {
+      if (t == fold_next) {
+        ++fold_tap;
+        fold_next += cpt;
+        if (__builtin_amdgcn_readfirstlane(Taps[23 + fold_tap])) {
 #pragma unroll
           for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -425,6 +419,24 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
         }
       }
     }
+  };
+  // the body of chunk t in ring stage ST (a compile-time constant: every LDS address below is register + immediate)
+  auto chunk = [&](int t, auto stage) {
+    // GRU: the chunks of x come first, then those of h.  The n gate needs gi_n and gh_n apart: at the first chunk of h the
+    // n-gate tile (x's share, complete) moves to the extra tile and starts again from zero for h's share — once per block,
+    // a uniform branch; the K loop itself is the same for both sources
+    if (GRU && t == cpt) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          acc[i][TNA - 1][r] = acc[i][TN - 1][r];
+          acc[i][TN - 1][r] = 0.0f;
+        }
+    }
+    constexpr int st = decltype(stage)::value;
+    constexpr int stn = st == STAGES - 1 ? 0 : st + 1;
+    const int ti = t / cpt;
     const unsigned gs_c0 = gs_lane + 8u * (unsigned)((t - ti * cpt) << 5);
     const int tn = t + 1 < nchunks ? t + 1 : nchunks - 1;
     const unsigned gs_c0n = gs_lane + 8u * (unsigned)((tn - (tn / cpt) * cpt) << 5);
@@ -495,13 +507,25 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
   // per chunk for it), then the one or two that are left
   {
     int t = 0;
+    const bool cpt_odd = (cpt & 1) != 0;     // (chunks per tap 2, 4, 6, 8 on this workload: a tap starts at an even chunk)
     for (; t + STAGES <= nchunks; t += STAGES) {
+      fold_check(t);
       chunk(t, std::integral_constant<int, 0>{});
+      if (STAGES == 3 || cpt_odd) fold_check(t + 1);
       chunk(t + 1, std::integral_constant<int, 1>{});
-      if constexpr (STAGES == 3) chunk(t + 2, std::integral_constant<int, 2>{});
+      if constexpr (STAGES == 3) {
+        fold_check(t + 2);
+        chunk(t + 2, std::integral_constant<int, 2>{});
+      }
     }
-    if (t < nchunks) chunk(t, std::integral_constant<int, 0>{});
-    if (STAGES == 3 && t + 1 < nchunks) chunk(t + 1, std::integral_constant<int, 1>{});
+    if (t < nchunks) {
+      fold_check(t);
+      chunk(t, std::integral_constant<int, 0>{});
+    }
+    if (STAGES == 3 && t + 1 < nchunks) {
+      fold_check(t + 1);
+      chunk(t + 1, std::integral_constant<int, 1>{});
+    }
   }
 #ifdef TLN_V2_STAMPS
   if (g.dbg && lane == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (blockIdx.x % 37) == 0) {   // a sample of blocks, every wave
