@@ -2016,7 +2016,11 @@ __global__ void __launch_bounds__(TLN_BK_THREADS) __attribute__((amdgpu_waves_pe
   for (int k = 0; k < BK_KEEP; ++k)
     if (k < rn.total) kb[k] = *bk_rec_of(rn, k);
   const float4* __restrict__ posv = J.posv;
+#ifdef TLN_K1_KO_GATHER   // measurement builds only (results wrong): where do k_bk_place's HBM-side bytes come from?
+  auto payload = [&](uint32_t row) { return make_float4(1.f, 2.f, 3.f, (float)(row & 7)); };
+#else
   auto payload = [&](uint32_t row) { return posv[row >> 2]; };   // (x, y, z, value): one 16-byte load
+#endif
 #pragma unroll
   for (int k = 0; k < BK_KEEP; ++k)
     if (k < rn.total) ka[k] = payload(kb[k].y);
@@ -2101,9 +2105,11 @@ __global__ void __launch_bounds__(TLN_BK_THREADS) __attribute__((amdgpu_waves_pe
       // the local mean needs the sums and the vertex only: written here, so that the sums need not live in registers
       // across the scan below (64 VGPRs = four workgroups per CU: the 1024 buckets of a frame in ONE round)
       const double cnt = (double)c[k];
+#ifndef TLN_K1_KO_VERTEX
       mean[3 * v[k]] = tln_unfix20((long long)hsum[0][e], cnt);
       mean[3 * v[k] + 1] = tln_unfix20((long long)hsum[1][e], cnt);
       mean[3 * v[k] + 2] = tln_unfix20((long long)hsum[2][e], cnt);
+#endif
     }
   }
   uint32_t P;
@@ -2117,9 +2123,11 @@ __global__ void __launch_bounds__(TLN_BK_THREADS) __attribute__((amdgpu_waves_pe
     hstart[e] = (int)(bin0 + st);
     if (v[k] >= 0) {
       const int vv = v[k];
+#ifndef TLN_K1_KO_VERTEX
       J.vstart[vv] = (int)(bin0 + st);
       J.vcnt[vv] = (int)c[k];
       J.vstamp[vv] = J.stamp;
+#endif
       st += c[k];
     }
   }
@@ -2139,7 +2147,9 @@ __global__ void __launch_bounds__(TLN_BK_THREADS) __attribute__((amdgpu_waves_pe
     TlnBinRec* out = local < (uint32_t)BK_STAGE ? bstage + local : bin_rec + dest;
     out->a = a;   // (both halves of the 32-byte record together)
     out->m = make_uint4(bb.x, bb.y, (uint32_t)vv, 0u);
+#ifndef TLN_K1_KO_INDICES
     if (indices) indices[bb.y] = vv;   // (NULL: nobody slices this frame — a scattered 4-byte store per row saved)
+#endif
   };
 #pragma unroll
   for (int k = 0; k < BK_KEEP; ++k)
@@ -2154,7 +2164,9 @@ __global__ void __launch_bounds__(TLN_BK_THREADS) __attribute__((amdgpu_waves_pe
     const int nst = (int)(R < (uint32_t)BK_STAGE ? R : (uint32_t)BK_STAGE);
     const uint4* src = reinterpret_cast<const uint4*>(bstage);
     uint4* dst = reinterpret_cast<uint4*>(bin_rec + bin0);
+#ifndef TLN_K1_KO_BINS
     for (int i = tid; i < 2 * nst; i += TLN_BK_THREADS) dst[i] = src[i];
+#endif
   }
 }
 

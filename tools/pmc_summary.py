@@ -12,13 +12,22 @@ import re
 import sys
 
 
-def load(d, counter):
+def load(d, counter, full_only=False):
+    """per kernel [launches, sum of the counter].  full_only (group mode): launches whose grid is less than a quarter of
+    the kernel's largest are left out — the stream pool warms its model replicas on 4096-point slices, one frame per
+    launch, and those must not count as batched launches of eight frames"""
     f = glob.glob("%s/%s/*/*counter_collection.csv" % (d, counter))[0]
+    rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter]
+    name = lambda r: re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "")
+    gmax = {}
+    for r in rows:
+        k = name(r)
+        gmax[k] = max(gmax.get(k, 0), int(r["Grid_Size"]))
     acc = {}
-    for r in csv.DictReader(open(f)):
-        if r["Counter_Name"] != counter:
+    for r in rows:
+        k = name(r)
+        if full_only and int(r["Grid_Size"]) * 4 < gmax[k]:
             continue
-        k = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "")
         a = acc.setdefault(k, [0, 0.0])
         a[0] += 1
         a[1] += float(r["Counter_Value"])
@@ -27,7 +36,8 @@ def load(d, counter):
 
 def main():
     d, out = sys.argv[1], sys.argv[2]
-    fe, wr = load(d, "FETCH_SIZE"), load(d, "WRITE_SIZE")
+    group = len(sys.argv) > 4 and int(sys.argv[4]) > 1
+    fe, wr = load(d, "FETCH_SIZE", group), load(d, "WRITE_SIZE", group)
     rows = []
     for k in sorted(set(fe) | set(wr)):
         n = fe.get(k, wr.get(k))[0]

@@ -27,8 +27,9 @@ rm -rf $O/pmc
 # the same two passes in the mode the timed region launches the stages in: one stream stepping a lock-step group of eight
 # (every K1 / K2 / K8 launch carries eight frames) -> bytes per frame of the batched launches
 mkdir -p $O/pmcg/FETCH_SIZE $O/pmcg/WRITE_SIZE
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmcg/FETCH_SIZE -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --streams 1 --pairs 8 > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmcg/WRITE_SIZE -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --streams 1 --pairs 8 > /dev/null 2>&1
+# (tools/group_run.py: ONLY batched launches — bench.py mixes in its one-sequence replays and checks)
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmcg/FETCH_SIZE -- python3 tools/group_run.py 6 8 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmcg/WRITE_SIZE -- python3 tools/group_run.py 6 8 > /dev/null 2>&1
 python tools/pmc_summary.py $O/pmcg $O/pmc_traffic_group.csv $O/pmc_traffic_group.json 8
 rm -rf $O/pmcg
 head -5 $O/pmc_traffic.csv
