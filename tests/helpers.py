@@ -69,6 +69,16 @@ MAX_SLACK = 1.25   # the worst of ~3 M elements is an extreme-value statistic: t
 RMS_SLACK = 1.15   # the noise LEVEL itself: rms of (x - o64) over all elements
 
 
+def float64_everywhere():
+    """TLN_TEST_FLOAT64=all: the float64 oracle also runs in the three longest full-size cases (the 8 x 120k recurrence, the
+    1.0M-vertex cloud, three of the four sequences of the timed configuration) — +7 minutes of CPU time on the GPU box;
+    profiles/r04_parity_errors.json was recorded that way.  Default: those cases keep the fp32 comparison and the float64
+    reading is asserted on the 4 x 120k sequences, config 2, one sequence of the timed configuration, the accumulated
+    clouds at sigma 0.6 and the smaller recurrences."""
+    import os
+    return os.environ.get("TLN_TEST_FLOAT64", "") == "all"
+
+
 def check_logits(got, want32, want64, what, rel_tol=NORTH_STAR_TOL, abs_ceiling=None):
     """The 1e-4 bar settled with a float64 reference.  Recorded per comparison: the max-abs and the rms
     of HIP - o64, o32 - o64 (and max-abs HIP - o32).  Asserted:
@@ -81,6 +91,15 @@ def check_logits(got, want32, want64, what, rel_tol=NORTH_STAR_TOL, abs_ceiling=
         comparable; `abs_ceiling` (when given) bounds the absolute error as a regression tripwire."""
     import torch
     got = got.detach().cpu()
+    if want64 is None:          # (a case that runs the fp32 oracle only, see float64_everywhere)
+        assert got.shape == want32.shape
+        scale = max(1.0, float(want32.abs().max()))
+        e_h32 = float((got - want32).abs().max())
+        parity_log(what, e_h32, scale, tuple(got.shape), hip_vs_o32=e_h32)
+        assert e_h32 <= rel_tol * scale, "%s: |HIP - o32| = %.3e (scale %.2f)" % (what, e_h32, scale)
+        if abs_ceiling is not None:
+            assert e_h32 <= abs_ceiling, "%s: max abs err %.3e exceeds the recorded absolute level" % (what, e_h32)
+        return e_h32
     assert got.shape == want32.shape == want64.shape, (got.shape, want32.shape, want64.shape)
     scale = max(1.0, float(want64.abs().max()))
     d_h, d_o = got.double() - want64, want32.double() - want64
