@@ -1633,6 +1633,36 @@ __device__ __forceinline__ uint32_t bk_bucket(uint64_t K, uint64_t slot_mask, in
   return K == TLN_KEY_EMPTY ? 0u : (uint32_t)((tln_mix64(K) & slot_mask) >> shift);
 }
 
+// MEASURED AND NOT KEPT (round 4, -DTLN_K1_NT=1): the streams of K1 — row records read once by each bucket kernel, bin
+// records written once — as NON-TEMPORAL accesses, so that the frame's packed points (1.9 MB, gathered by row id, every
+// line wanted ~4 times per XCD) would stay in an XCD's 4 MB L2.  k_bk_place 171.8 -> 211.6 us per batch of eight frames,
+// k_bk_insert 59.3 -> 66.6, fetched bytes unchanged (555 against 565 MB): the runs are 64 bytes, two to four lanes share a
+// line, and the non-temporal loads gave that sharing up.
+#ifndef TLN_K1_NT
+#define TLN_K1_NT 0
+#endif
+typedef unsigned int bk_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 bk_load_rec(const uint4* p) {
+#if TLN_K1_NT
+  const bk_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const bk_u32x4*>(p));
+  return make_uint4(v.x, v.y, v.z, v.w);
+#else
+  return *p;
+#endif
+}
+__device__ __forceinline__ void bk_store_stream(uint4* p, const uint4& v) {
+#if TLN_K1_NT
+  bk_u32x4 w;
+  w.x = v.x;
+  w.y = v.y;
+  w.z = v.z;
+  w.w = v.w;
+  __builtin_nontemporal_store(w, reinterpret_cast<bk_u32x4*>(p));
+#else
+  *p = v;
+#endif
+}
+
 // exclusive prefix sum over the threads of a block (whole waves, at most 16); *total = sum of all (valid after the call
 // for every thread)
 __device__ __forceinline__ uint32_t bk_block_scan(uint32_t v, uint32_t* wtmp /* [16] shared */, uint32_t* total) {
@@ -1786,7 +1816,7 @@ __global__ void __launch_bounds__(1024) k_bk_split(const BkJobs jobs) {
   if (J.stage) {
     __syncthreads();
     const int nrec = (int)(4 * (p1 - p0));
-    for (int i = tid; i < nrec; i += T) region[i] = stage[i];
+    for (int i = tid; i < nrec; i += T) bk_store_stream(&region[i], stage[i]);
   }
 }
 
@@ -1842,6 +1872,7 @@ __device__ __forceinline__ void bk_runs_of(const uint32_t* __restrict__ off, con
 }
 __device__ __forceinline__ const uint4* bk_rec_of(const BkRuns& rn, int k) { return rn.at + k * rn.step; }
 
+
 __global__ void __launch_bounds__(TLN_BK_THREADS) k_bk_insert(const BkJobs jobs) {
   const BkJob& J = jobs.j[blockIdx.y];
   if ((int)blockIdx.x >= J.B) return;
@@ -1863,7 +1894,7 @@ __global__ void __launch_bounds__(TLN_BK_THREADS) k_bk_insert(const BkJobs jobs)
   uint4 kb[BK_KEEP];
 #pragma unroll
   for (int k = 0; k < BK_KEEP; ++k)
-    if (k < rn.total) kb[k] = *bk_rec_of(rn, k);
+    if (k < rn.total) kb[k] = bk_load_rec(bk_rec_of(rn, k));
   __syncthreads();
   auto touch_row = [&](const uint4& bb) {
     const uint64_t K = ((uint64_t)bb.w << 32) | bb.z;
@@ -1875,7 +1906,7 @@ __global__ void __launch_bounds__(TLN_BK_THREADS) k_bk_insert(const BkJobs jobs)
 #pragma unroll
   for (int k = 0; k < BK_KEEP; ++k)
     if (k < rn.total) touch_row(kb[k]);
-  for (int k = BK_KEEP; k < rn.total; ++k) touch_row(*bk_rec_of(rn, k));
+  for (int k = BK_KEEP; k < rn.total; ++k) touch_row(bk_load_rec(bk_rec_of(rn, k)));
   const uint32_t nrows = (uint32_t)rn.total;
   uint32_t R;
   bk_block_scan(nrows, wtmp, &R);   // (barriers: the table is complete behind it)
@@ -2014,7 +2045,7 @@ __global__ void __launch_bounds__(TLN_BK_THREADS) __attribute__((amdgpu_waves_pe
   uint4 kb[BK_KEEP];
 #pragma unroll
   for (int k = 0; k < BK_KEEP; ++k)
-    if (k < rn.total) kb[k] = *bk_rec_of(rn, k);
+    if (k < rn.total) kb[k] = bk_load_rec(bk_rec_of(rn, k));
   const float4* __restrict__ posv = J.posv;
 #ifdef TLN_K1_KO_GATHER   // measurement builds only (results wrong): where do k_bk_place's HBM-side bytes come from?
   auto payload = [&](uint32_t row) { return make_float4(1.f, 2.f, 3.f, (float)(row & 7)); };
@@ -2042,7 +2073,7 @@ __global__ void __launch_bounds__(TLN_BK_THREADS) __attribute__((amdgpu_waves_pe
   for (int k = 0; k < BK_KEEP; ++k)
     if (k < rn.total) count_row(ka[k], kb[k]);
   for (int k = BK_KEEP; k < rn.total; ++k) {
-    const uint4 bb = *bk_rec_of(rn, k);
+    const uint4 bb = bk_load_rec(bk_rec_of(rn, k));
     count_row(payload(bb.y), bb);
   }
   __syncthreads();
@@ -2155,7 +2186,7 @@ __global__ void __launch_bounds__(TLN_BK_THREADS) __attribute__((amdgpu_waves_pe
   for (int k = 0; k < BK_KEEP; ++k)
     if (k < rn.total) place_row(ka[k], kb[k]);
   for (int k = BK_KEEP; k < rn.total; ++k) {
-    const uint4 bb = *bk_rec_of(rn, k);
+    const uint4 bb = bk_load_rec(bk_rec_of(rn, k));
     place_row(payload(bb.y), bb);
   }
   __syncthreads();
@@ -2165,7 +2196,7 @@ __global__ void __launch_bounds__(TLN_BK_THREADS) __attribute__((amdgpu_waves_pe
     const uint4* src = reinterpret_cast<const uint4*>(bstage);
     uint4* dst = reinterpret_cast<uint4*>(bin_rec + bin0);
 #ifndef TLN_K1_KO_BINS
-    for (int i = tid; i < 2 * nst; i += TLN_BK_THREADS) dst[i] = src[i];
+    for (int i = tid; i < 2 * nst; i += TLN_BK_THREADS) bk_store_stream(&dst[i], src[i]);
 #endif
   }
 }

@@ -70,8 +70,9 @@ RMS_SLACK = 1.15   # the noise LEVEL itself: rms of (x - o64) over all elements
 
 
 def float64_everywhere():
-    """TLN_TEST_FLOAT64=all: the float64 oracle also runs in the three longest full-size cases (the 8 x 120k recurrence, the
-    1.0M-vertex cloud, three of the four sequences of the timed configuration) — +7 minutes of CPU time on the GPU box;
+    """TLN_TEST_FLOAT64=all: the float64 oracle also runs in the longest full-size cases (the 8 x 120k and 8 x 30k
+    recurrences, the 1.0M-vertex cloud, three of the four sequences of the timed configuration, vis_aflow) — +7 minutes of
+    CPU time on the GPU box;
     profiles/r04_parity_errors.json was recorded that way.  Default: those cases keep the fp32 comparison and the float64
     reading is asserted on the 4 x 120k sequences, config 2, one sequence of the timed configuration, the accumulated
     clouds at sigma 0.6 and the smaller recurrences."""
