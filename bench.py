@@ -199,6 +199,10 @@ def run_frames_extra(args, rank, world, barrier, agree):
         env = dict(os.environ)
         env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 29 * (attempt + 1))
         env["TLN_HANDOFF_TIMEOUT_S"] = env.get("TLN_HANDOFF_TIMEOUT_S", "60")
+        # (under torch.distributed.run the workers are CLIENTS of the agent's store: the children rendezvous on a port of
+        #  their own, where their rank 0 must host the store itself)
+        for k in ("TORCHELASTIC_USE_AGENT_STORE",):
+            env.pop(k, None)
         cmd = [sys.executable, os.path.abspath(__file__), "--frames-child", backend, "--steps", str(n_f), "--warmup",
                str(max(1, args.warmup // 2)), "--points", str(args.points), "--frames", str(args.frames), "--sigma",
                str(args.sigma), "--rnn", args.rnn] + (["--same-device"] if args.same_device else []) + \

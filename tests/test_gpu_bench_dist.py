@@ -74,3 +74,26 @@ def test_bench_frame_sharding(gpu, world):
     _check_line(d, world)
     assert "sharded over %d ranks" % world in d["config"]["parallelism"]
     assert d["frames_mode"]["latency_ms_per_sequence"] > 0 and d["frames_mode"]["steady_state_clouds_per_s"] > 0
+
+
+def test_bench_under_torch_distributed_run(gpu):
+    """exactly the driver's launch line for N > 1 — `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...` — with two ranks on the one GPU over gloo: the elastic
+    agent hosts the rendezvous store of the job, the children of `--frames-extra` must host their own"""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--points", "6000", "--dist-backend", "gloo", "--same-device", "--no-cpu-baseline", "--streams", "2", "--pairs", "2"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    _check_line(d, 2)
+    fm = d["frames_mode"]
+    assert "error" not in fm, fm
+    assert fm["ranks_per_sequence"] == 2 and fm["steady_state_clouds_per_s"] > 0 and fm["backend"] == "gloo"
