@@ -126,6 +126,9 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();
+  // (decided in uniform code: read under the divergent branch below, the arguments of a shared launch came by vector loads
+  //  and cost the GRU kernel 14 registers.  fold_taps: the GRU launch's switch for the skip, host)
+  const bool gru_skip_h = GRU && g.fold_taps != 0 && m0 >= (int64_t)g.s[1].src_rows;
   // every wave builds the same list of present taps (identical values to the same words: no further barrier)
   if (lane == 0) {
     unsigned mask = 0;
@@ -134,7 +137,7 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
     // GRU: a block whose rows all lie past the hidden state (vertices born in this frame: 8-22 % of a frame's rows on
     // the headline workload, at the end of the vertex order) has nothing but zero rows of h: its h chunks — half its K
     // loop — would add exact zeros and are skipped (same bits)
-    if (GRU && g.fold_taps && m0 >= (int64_t)g.s[1].src_rows) mask = 1u;   // (fold_taps: the GRU launch's switch for this, host)
+    if (gru_skip_h) mask = 1u;
     int n_present = 0, prev_group = -1;
     for (int k = 0; k < taps; ++k)
       if ((mask >> k) & 1u) {
@@ -669,14 +672,20 @@ __global__ void __launch_bounds__(64 * WM * WN, (v2_min_waves<WM, WN, TM, TN, ST
   v2_body<WM, WN, TM, TN, W_NK, PRO, false, STAGES>(g);
 }
 
+// (V2_GRU_WAVES: the fused cell's register cap, as the second launch bound.  At its natural 140 (144 allocated, two waves per SIMD: 288 of a SIMD's 512)
+//  a GRU workgroup cannot share a CU with another stream's 128-column workgroup since that one keeps a second accumulator
+//  set (122 -> 128 allocated x 2 = 256); at 128 it can)
+#ifndef V2_GRU_WAVES
+#define V2_GRU_WAVES 4      // waves per SIMD the cell must allow: 4 = at most 128 VGPRs
+#endif
 template <int STAGES>
-__global__ void __launch_bounds__(512) k_gather_gemm_v2_gru(const GemmArgs g) {
+__global__ void __launch_bounds__(512, V2_GRU_WAVES) k_gather_gemm_v2_gru(const GemmArgs g) {
   v2_body<4, 2, 1, 3, true, false, true, STAGES>(g);
 }
 
 // the GRU cells of lock-stepped sequences in one launch (blockIdx.z = sequence; same weights, own x / h / out)
 template <int STAGES>
-__global__ void __launch_bounds__(512) k_gather_gemm_v2_gru_multi(const GemmArgsN<TLN_GEMM_MULTI_MAX> gg) {
+__global__ void __launch_bounds__(512, V2_GRU_WAVES) k_gather_gemm_v2_gru_multi(const GemmArgsN<TLN_GEMM_MULTI_MAX> gg) {
   const GemmArgs& g = gg.a[blockIdx.z];
   if ((int64_t)blockIdx.x * 128 >= g.M) return;   // (the grid is sized for the largest lattice)
   v2_body<4, 2, 1, 3, true, false, true, STAGES>(g);
