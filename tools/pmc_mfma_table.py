@@ -33,8 +33,10 @@ for k, v in ker.items():
                  v["SQ_INSTS_VALU"][0] / max(1.0, v["SQ_INSTS_MFMA"][0]), v["SQ_WAIT_INST_ANY"][0] / v["SQ_WAVE_CYCLES"][0]))
 tot = sum(r[0] for r in rows)
 print("%-64s %8s %7s %10s %10s %6s" % ("kernel", "samples", "weight", "mfma_busy", "valu/mfma", "wait"))
-acc = 0.0
+acc = gtot = 0.0
 for w, name, n, busy, vm, wait in sorted(rows, reverse=True):
-    acc += busy * w
+    if "gather_gemm" in name:        # (the summary line is over the gather-GEMM kernels only, whatever else was profiled)
+        acc += busy * w
+        gtot += w
     print("%-64s %8d %6.1f%% %9.1f%% %10.1f %5.0f%%" % (name[:64], n, 100 * w / tot, 100 * busy, vm, 100 * wait))
-print("# all gather-GEMM kernels, time-weighted: mfma_busy %.1f %%" % (100 * acc / tot))
+print("# all gather-GEMM kernels, time-weighted: mfma_busy %.1f %%" % (100 * acc / max(gtot, 1e-30)))
