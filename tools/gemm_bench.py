@@ -6,14 +6,14 @@ import os
 import sys
 
 import torch
-from temporal_latticenet_amd import options as OPT  # noqa: E402
-
-OPT.push()   # kernel-selection options of this host thread (tln_options; the library has no process-wide switch)
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from temporal_latticenet_amd import _lib, ops                      # noqa: E402
 from temporal_latticenet_amd.lattice import Lattice                # noqa: E402
 from temporal_latticenet_amd.synthetic import make_sequence        # noqa: E402
+from temporal_latticenet_amd import options as OPT  # noqa: E402
+
+OPT.push()   # kernel-selection options of this host thread (tln_options; the library has no process-wide switch)
 
 
 def main():

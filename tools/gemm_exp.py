@@ -2,13 +2,13 @@
 """one heavy shape, direct kernel, G in (1, 2, 4): time per launch (for kernel experiments)"""
 import os, sys
 import torch
-from temporal_latticenet_amd import options as OPT  # noqa: E402
-
-OPT.push()   # kernel-selection options of this host thread (tln_options; the library has no process-wide switch)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from temporal_latticenet_amd import _lib, ops
 from temporal_latticenet_amd.lattice import Lattice
 from temporal_latticenet_amd.synthetic import make_sequence
+from temporal_latticenet_amd import options as OPT  # noqa: E402
+
+OPT.push()   # kernel-selection options of this host thread (tln_options; the library has no process-wide switch)
 cin, cout = int(sys.argv[1]), int(sys.argv[2])
 seq = make_sequence(120000, 4, seed=1234)
 lat = Lattice.from_params([0.6] * 3, 1 << 18)
