@@ -191,7 +191,7 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
     } else {
       const int r = e >> 3, q = e & 7;
       int n = n0 + r;
-      if (GRU) n = ((r % 96) >> 5) * s.cin + 64 * (int)blockIdx.y + 32 * (r / 96) + (r & 31);
+      if (GRU) n = ((r % 96) >> 5) * s.cin + 32 * WN * (int)blockIdx.y + 32 * (r / 96) + (r & 31);
       ok = n < g.N && (!B_PAD || e < BN * 8);
       off = 4u * ((unsigned)n * (unsigned)g.ldw + 4u * (unsigned)(q ^ ((r >> 1) & 7)));
     }
@@ -566,9 +566,9 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
   // 32x32 tile at once from clamped (always valid) addresses: a per-element "load or not" makes the compiler branch
   // around every load and wait for each one.
   if constexpr (GRU) {
-    static_assert(TM == 1 && TN == 3 && WN == 2 && W_NK && !PRO, "the GRU epilogue is written for the 128 x 192 tile");
+    static_assert(TM == 1 && TN == 3 && (WN == 2 || WN == 1) && W_NK && !PRO, "the GRU epilogue is written for waves of 32 x 96");
     const int C = s.cin;
-    const int ch = 64 * (int)blockIdx.y + 32 * wn + l31;
+    const int ch = 32 * WN * (int)blockIdx.y + 32 * wn + l31;
     // r, z: one bias for the sum; n: the two halves apart
     const float br = g.bias[ch] + g.bias2[ch], bz = g.bias[C + ch] + g.bias2[C + ch];
     const float bni = g.bias[2 * C + ch], bnh = g.bias2[2 * C + ch];
@@ -678,17 +678,17 @@ __global__ void __launch_bounds__(64 * WM * WN, (v2_min_waves<WM, WN, TM, TN, ST
 #ifndef V2_GRU_WAVES
 #define V2_GRU_WAVES 4      // waves per SIMD the cell must allow: 4 = at most 128 VGPRs
 #endif
-template <int STAGES>
-__global__ void __launch_bounds__(512, V2_GRU_WAVES) k_gather_gemm_v2_gru(const GemmArgs g) {
-  v2_body<4, 2, 1, 3, true, false, true, STAGES>(g);
+template <int STAGES, int GWN = 2>
+__global__ void __launch_bounds__(256 * GWN, V2_GRU_WAVES) k_gather_gemm_v2_gru(const GemmArgs g) {
+  v2_body<4, GWN, 1, 3, true, false, true, STAGES>(g);
 }
 
 // the GRU cells of lock-stepped sequences in one launch (blockIdx.z = sequence; same weights, own x / h / out)
-template <int STAGES>
-__global__ void __launch_bounds__(512, V2_GRU_WAVES) k_gather_gemm_v2_gru_multi(const GemmArgsN<TLN_GEMM_MULTI_MAX> gg) {
+template <int STAGES, int GWN = 2>
+__global__ void __launch_bounds__(256 * GWN, V2_GRU_WAVES) k_gather_gemm_v2_gru_multi(const GemmArgsN<TLN_GEMM_MULTI_MAX> gg) {
   const GemmArgs& g = gg.a[blockIdx.z];
   if ((int64_t)blockIdx.x * 128 >= g.M) return;   // (the grid is sized for the largest lattice)
-  v2_body<4, 2, 1, 3, true, false, true, STAGES>(g);
+  v2_body<4, GWN, 1, 3, true, false, true, STAGES>(g);
 }
 
 // several products of one shape class in one launch (blockIdx.z = product): the coarse levels of lock-stepped
@@ -932,6 +932,13 @@ int tln_gemm_v2_launch_multi(GemmArgs* g, int n, bool w_is_nk, hipStream_t s, co
   return pro ? dispatch_v2_multi<false, true>(g, n, s, o) : dispatch_v2_multi<false, false>(g, n, s, o);
 }
 
+// (measurement: TLN_GRU_HALF=1 runs the cell on 128 x 96 tiles of four waves — 32 channels x 3 gates, two workgroups per
+//  CU's LDS, one's epilogue beside the other's K loop — instead of 128 x 192 tiles of eight)
+static bool v2_gru_half() {
+  static const bool on = getenv("TLN_GRU_HALF") != nullptr && atoi(getenv("TLN_GRU_HALF")) != 0;
+  return on;
+}
+
 // h' = GRUCell(x, pad(h)) as one two-source product with the cell in its epilogue (see v2_body)
 bool tln_gemm_v2_gru_ok(int64_t V, int64_t Vh, int C, const tln_options& o) {
   static const bool off = getenv("TLN_GRU_FUSED_OFF") != nullptr;
@@ -972,6 +979,13 @@ int tln_gemm_v2_launch_gru(const float* d_x, const float* d_h, int64_t Vh, int64
   v2_gru_args(g, d_x, d_h, Vh, V, C, d_w_ih, d_w_hh, d_b_ih, d_b_hh, d_out);
   constexpr int BM = 128, BN = 192;
   const bool two = (v2_two_stage() & 8) != 0;
+  if (v2_gru_half()) {   // 128 x 96 tile of four waves, two workgroups per CU
+    const size_t lds = (size_t)2 * (BM + 96) * 128 + (size_t)BM * TLN_TAPS * 4 + (size_t)2 * C * 4 + (size_t)(BM + 32) * 4;
+    static thread_local TlnLdsAttr attrh;
+    TLN_HIP(tln_set_max_lds(attrh, reinterpret_cast<const void*>(k_gather_gemm_v2_gru<2, 1>), (int)lds));
+    hipLaunchKernelGGL((k_gather_gemm_v2_gru<2, 1>), dim3((unsigned)tln_cdiv(V, BM), (unsigned)(C / 32), 1), dim3(256), lds, s, g);
+    return TLN_OK;
+  }
   const size_t lds = (size_t)(two ? 2 : 3) * (BM + BN) * 128 + (size_t)BM * TLN_TAPS * 4 + (size_t)2 * C * 4 + (size_t)(BM + 32) * 4;
   dim3 grid((unsigned)tln_cdiv(V, BM), (unsigned)(3 * C / BN), 1);
   if (two) {
@@ -999,6 +1013,13 @@ int tln_gemm_v2_launch_gru_multi(int n, const float* const* d_x, const float* co
   }
   constexpr int BM = 128, BN = 192;
   const bool two = (v2_two_stage() & 8) != 0;
+  if (v2_gru_half()) {
+    const size_t lds = (size_t)2 * (BM + 96) * 128 + (size_t)BM * TLN_TAPS * 4 + (size_t)2 * C * 4 + (size_t)(BM + 32) * 4;
+    static thread_local TlnLdsAttr attrh;
+    TLN_HIP(tln_set_max_lds(attrh, reinterpret_cast<const void*>(k_gather_gemm_v2_gru_multi<2, 1>), (int)lds));
+    hipLaunchKernelGGL((k_gather_gemm_v2_gru_multi<2, 1>), dim3((unsigned)tln_cdiv(vmax, BM), (unsigned)(C / 32), (unsigned)n), dim3(256), lds, s, gg);
+    return TLN_OK;
+  }
   const size_t lds = (size_t)(two ? 2 : 3) * (BM + BN) * 128 + (size_t)BM * TLN_TAPS * 4 + (size_t)2 * C * 4 + (size_t)(BM + 32) * 4;
   dim3 grid((unsigned)tln_cdiv(vmax, BM), (unsigned)(3 * C / BN), (unsigned)n);
   if (two) {
