@@ -76,6 +76,27 @@ __device__ __forceinline__ int tln_wave_sum(int v) {
   return v;
 }
 
+// Jobs of a batched launch <-> XCDs (grid = [blocks, jobs], blockIdx.y = job: the frames / lattices of lock-stepped
+// sequences).  Workgroups are dealt round-robin over the eight XCDs in their linear order (observed; used for speed only,
+// nothing depends on it) and every XCD has an L2 of its own, so with the job taken from the LOW bits of the linear block
+// index all blocks of a job run on one XCD (8 jobs; a pair with 4, four with 2): what they gather from or scatter into —
+// one frame's points, one lattice's values — meets in ONE 4 MB L2 instead of passing through all eight.
+__device__ __forceinline__ void tln_xcd_block(int on, int& bx, int& job) {
+  bx = (int)blockIdx.x;
+  job = (int)blockIdx.y;
+  const unsigned ny = gridDim.y;
+  if (on && (ny == 8u || ny == 4u || ny == 2u)) {
+    const unsigned L = blockIdx.x + gridDim.x * blockIdx.y;
+    job = (int)(L & (ny - 1u));
+    bx = (int)(L / ny);
+  }
+}
+// (host: env TLN_XCD=0 switches the mapping off everywhere, for measurements)
+static inline int tln_xcd_on() {
+  static const int on = (getenv("TLN_XCD") != nullptr && atoi(getenv("TLN_XCD")) == 0) ? 0 : 1;
+  return on;
+}
+
 // ONE arithmetic for the GRU cell wherever it is evaluated (torch.nn.GRUCell, reference lattice_modules.py:62): the fused
 // large-lattice cell (gemm_v2.hip epilogue) and the small-lattice gates kernel (fused.hip k_gru_gates) call this, so a
 // lattice that crosses the size threshold does not change its gate arithmetic.  Accurate library exp / tanh and a

@@ -460,10 +460,13 @@ struct AflowJobs {
     float* weights;
     int32_t* nbr_idx;
   } j[TLN_FUSED_MAXJOBS];
+  int xcd;   // sequences dealt to the XCDs (common.h: tln_xcd_block)
 };
 __global__ void __launch_bounds__(256) k_aflow(const AflowJobs jobs, int C, float alpha, float beta, float pad,
                                                int use_center, const float* __restrict__ bias) {
-  const auto& J = jobs.j[blockIdx.y];
+  int bx, job;
+  tln_xcd_block(jobs.xcd, bx, job);
+  const auto& J = jobs.j[job];
   const float* __restrict__ x = J.x;
   const float* __restrict__ h = J.h;
   const int64_t V = J.V, Vh = J.Vh;
@@ -471,7 +474,7 @@ __global__ void __launch_bounds__(256) k_aflow(const AflowJobs jobs, int C, floa
   float* __restrict__ out = J.out;
   float* __restrict__ weights = J.weights;
   int32_t* __restrict__ nbr_idx = J.nbr_idx;
-  const int64_t v = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t v = ((int64_t)bx * blockDim.x + threadIdx.x) >> 6;
   if (v >= V) return;
   const int lane = threadIdx.x & 63;
   int idx[TLN_TAPS];
@@ -538,6 +541,7 @@ extern "C" int tln_aflow_multi(const tln_aflow_call* c, int n, int C, float alph
   for (int i0 = 0; i0 < n; i0 += TLN_FUSED_MAXJOBS) {
     const int m = n - i0 < TLN_FUSED_MAXJOBS ? n - i0 : TLN_FUSED_MAXJOBS;
     AflowJobs jobs;
+    jobs.xcd = tln_xcd_on();
     int64_t vmax = 0;
     for (int i = 0; i < TLN_FUSED_MAXJOBS; ++i) {
       const tln_aflow_call& a = c[i0 + (i < m ? i : 0)];
@@ -641,14 +645,17 @@ struct SliceJobs {
     float* out;
     float* logsm;
   } j[TLN_FUSED_MAXJOBS];
+  int xcd;   // sequences dealt to the XCDs (common.h: tln_xcd_block)
 };
 template <int CB>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) k_slice_deform(const SliceJobs jobs, int C,
                                                       const float* __restrict__ w_pre, const float* __restrict__ w_dw,
                                                       const float* __restrict__ b_dw, const float* __restrict__ bias) {
-  const auto& J = jobs.j[blockIdx.y];
+  int bx, job;
+  tln_xcd_block(jobs.xcd, bx, job);
+  const auto& J = jobs.j[job];
   const int64_t n = J.n, V = J.V;
-  if ((int64_t)blockIdx.x * 64 >= n) return;   // (the grid is sized for the largest cloud; uniform per block)
+  if ((int64_t)bx * 64 >= n) return;   // (the grid is sized for the largest cloud; uniform per block)
   const float* __restrict__ b = J.b;
   const float* __restrict__ scores = J.scores;
   const int32_t* __restrict__ indices = J.indices;
@@ -677,7 +684,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
   for (int i = threadIdx.x; i < 4 * G; i += blockDim.x) wd_s[i] = w_dw[i];
   __syncthreads();
   const int pl = threadIdx.x >> 2, q = threadIdx.x & 3;     // point in block, quarter of the hidden layer
-  const int64_t p0 = (int64_t)blockIdx.x * PPB;
+  const int64_t p0 = (int64_t)bx * PPB;
   const int64_t p = p0 + pl;
   if (p < n) {
     int idx[4];
@@ -796,6 +803,7 @@ extern "C" int tln_slice_deform_multi(const tln_slice_call* c, int n, int cb, in
   for (int i0 = 0; i0 < n; i0 += TLN_FUSED_MAXJOBS) {
     const int m = n - i0 < TLN_FUSED_MAXJOBS ? n - i0 : TLN_FUSED_MAXJOBS;
     SliceJobs jobs;
+    jobs.xcd = tln_xcd_on();
     int64_t nmax = 0;
     const bool ls = c[i0].d_logsm != nullptr;
     for (int i = 0; i < TLN_FUSED_MAXJOBS; ++i) {

@@ -53,6 +53,7 @@ struct GemmArgs {
 template <int NP>
 struct GemmArgsN {
   GemmArgs a[NP];
+  int xcd = 0;   // gemm_v2's shared launches: products dealt to the XCDs (v2_multi_block)
 };
 
 // lattice.hip: the row order that belongs to a tap table, if it was built for exactly `rows` rows

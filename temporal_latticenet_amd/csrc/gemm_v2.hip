@@ -50,7 +50,7 @@ typedef double f64x8 __attribute__((ext_vector_type(8)));
 // g.bias = b_ih, g.bias2 = b_hh, g.out = h' [M, C].
 // STAGES = 3: DMAs two chunks ahead; STAGES = 2 (128 x 128 tile): one chunk ahead, but two workgroups fit a CU's LDS
 template <int WM, int WN, int TM, int TN, bool W_NK, bool PRO, bool GRU = false, int STAGES = V2_STAGES>
-__device__ __forceinline__ void v2_body(const GemmArgs& g) {
+__device__ __forceinline__ void v2_body(const GemmArgs& g, const int bx, const int by) {
 #if __HIP_DEVICE_COMPILE__   // (the buffer-resource type of the LDS-DMAs exists in the device pass only)
   constexpr int NT = 64 * WM * WN;
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
@@ -78,8 +78,8 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
   const int wm = wv / WN, wn = wv % WN;
   const int l31 = lane & 31, half = lane >> 5;
   // (blocks start in index order: with a launch order the heaviest blocks — most taps present — come first)
-  const int64_t m0 = (int64_t)((BM == 128 && s.order) ? s.order[blockIdx.x] : (int)blockIdx.x) * BM;
-  const int n0 = blockIdx.y * BN;
+  const int64_t m0 = (int64_t)((BM == 128 && s.order) ? s.order[bx] : bx) * BM;
+  const int n0 = by * BN;
   const bool has_table = s.table != nullptr;
   const int src_rows = (int)s.src_rows;
   const int ld_bytes = (int)s.ld * 4;
@@ -191,7 +191,7 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
     } else {
       const int r = e >> 3, q = e & 7;
       int n = n0 + r;
-      if (GRU) n = ((r % 96) >> 5) * s.cin + 32 * WN * (int)blockIdx.y + 32 * (r / 96) + (r & 31);
+      if (GRU) n = ((r % 96) >> 5) * s.cin + 32 * WN * by + 32 * (r / 96) + (r & 31);
       ok = n < g.N && (!B_PAD || e < BN * 8);
       off = 4u * ((unsigned)n * (unsigned)g.ldw + 4u * (unsigned)(q ^ ((r >> 1) & 7)));
     }
@@ -481,7 +481,7 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
     const unsigned long long tb2 = __builtin_amdgcn_s_memtime();
     st_dma += tb1 - tb0;
     st_bar += tb2 - tb1;
-    if (g.dbg && lane == 0 && blockIdx.x == 37 && blockIdx.y == 0 && blockIdx.z == 0 && t < 60) {   // one block's timeline
+    if (g.dbg && lane == 0 && bx == 37 && by == 0 && blockIdx.z == 0 && t < 60) {   // one block's timeline
       g.dbg[32 + (t * 8 + wv) * 2] = tb1;
       g.dbg[32 + (t * 8 + wv) * 2 + 1] = tb2;
     }
@@ -531,7 +531,7 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
     }
   }
 #ifdef TLN_V2_STAMPS
-  if (g.dbg && lane == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (blockIdx.x % 37) == 0) {   // a sample of blocks, every wave
+  if (g.dbg && lane == 0 && by == 0 && blockIdx.z == 0 && (bx % 37) == 0) {   // a sample of blocks, every wave
     const unsigned long long st_end = __builtin_amdgcn_s_memtime();
     atomicAdd(&g.dbg[16], st_end - st_begin);
     atomicAdd(&g.dbg[17], st_dma);
@@ -568,7 +568,7 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g) {
   if constexpr (GRU) {
     static_assert(TM == 1 && TN == 3 && (WN == 2 || WN == 1) && W_NK && !PRO, "the GRU epilogue is written for waves of 32 x 96");
     const int C = s.cin;
-    const int ch = 32 * WN * (int)blockIdx.y + 32 * wn + l31;
+    const int ch = 32 * WN * by + 32 * wn + l31;
     // r, z: one bias for the sum; n: the two halves apart
     const float br = g.bias[ch] + g.bias2[ch], bz = g.bias[C + ch] + g.bias2[C + ch];
     const float bni = g.bias[2 * C + ch], bnh = g.bias2[2 * C + ch];
@@ -669,7 +669,27 @@ constexpr int v2_min_waves() {
 
 template <int WM, int WN, int TM, int TN, bool W_NK, bool PRO, int STAGES = V2_STAGES>
 __global__ void __launch_bounds__(64 * WM * WN, (v2_min_waves<WM, WN, TM, TN, STAGES>())) k_gather_gemm_v2(const GemmArgs g) {
-  v2_body<WM, WN, TM, TN, W_NK, PRO, false, STAGES>(g);
+  v2_body<WM, WN, TM, TN, W_NK, PRO, false, STAGES>(g, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// Products of a shared launch <-> XCDs.  Workgroups are dealt round-robin over the eight XCDs in their linear order
+// (observed; used for speed only), and every XCD has an L2 of its own: with blockIdx.z = product, the tiles of ONE product
+// ran on all eight XCDs and each L2 saw the gathered rows of all eight sources (eight level-0 tensors: 61-188 MB through
+// 4 MB).  With the product taken from the LOW bits of the linear block index, an XCD gathers from one source only
+// (8 products; a pair of XCDs with 4, four with 2) — level 1 (4.5 MB) and level 2 then sit in its L2 — and the launch
+// starts the heaviest tiles of ALL products first instead of product after product.
+__device__ __forceinline__ void v2_multi_block(int xcd, int& bx, int& by, int& bz) {
+  bx = (int)blockIdx.x;
+  by = (int)blockIdx.y;
+  bz = (int)blockIdx.z;
+  const unsigned nz = gridDim.z;
+  if (xcd && (nz == 8u || nz == 4u || nz == 2u)) {
+    const unsigned L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    bz = (int)(L & (nz - 1u));
+    const unsigned r = L / nz;
+    by = (int)(r / gridDim.x);
+    bx = (int)(r - (unsigned)by * gridDim.x);
+  }
 }
 
 // (V2_GRU_WAVES: the fused cell's register cap, as the second launch bound.  At its natural 140 (144 allocated, two waves per SIMD: 288 of a SIMD's 512)
@@ -680,24 +700,28 @@ __global__ void __launch_bounds__(64 * WM * WN, (v2_min_waves<WM, WN, TM, TN, ST
 #endif
 template <int STAGES, int GWN = 2>
 __global__ void __launch_bounds__(256 * GWN, V2_GRU_WAVES) k_gather_gemm_v2_gru(const GemmArgs g) {
-  v2_body<4, GWN, 1, 3, true, false, true, STAGES>(g);
+  v2_body<4, GWN, 1, 3, true, false, true, STAGES>(g, (int)blockIdx.x, (int)blockIdx.y);
 }
 
 // the GRU cells of lock-stepped sequences in one launch (blockIdx.z = sequence; same weights, own x / h / out)
 template <int STAGES, int GWN = 2>
 __global__ void __launch_bounds__(256 * GWN, V2_GRU_WAVES) k_gather_gemm_v2_gru_multi(const GemmArgsN<TLN_GEMM_MULTI_MAX> gg) {
-  const GemmArgs& g = gg.a[blockIdx.z];
-  if ((int64_t)blockIdx.x * 128 >= g.M) return;   // (the grid is sized for the largest lattice)
-  v2_body<4, GWN, 1, 3, true, false, true, STAGES>(g);
+  int bx, by, bz;
+  v2_multi_block(gg.xcd, bx, by, bz);
+  const GemmArgs& g = gg.a[bz];
+  if ((int64_t)bx * 128 >= g.M) return;   // (the grid is sized for the largest lattice)
+  v2_body<4, GWN, 1, 3, true, false, true, STAGES>(g, bx, by);
 }
 
 // several products of one shape class in one launch (blockIdx.z = product): the coarse levels of lock-stepped
 // sequences, whose rows only together fill the chip with 128-row tiles
 template <int WM, int WN, int TM, int TN, bool W_NK, bool PRO, int STAGES = V2_STAGES>
 __global__ void __launch_bounds__(64 * WM * WN, (v2_min_waves<WM, WN, TM, TN, STAGES>())) k_gather_gemm_v2_multi(const GemmArgsN<TLN_GEMM_MULTI_MAX> gg) {
-  const GemmArgs& g = gg.a[blockIdx.z];
-  if ((int64_t)blockIdx.x * (32 * TM * WM) >= g.M) return;   // (the grid is sized for the longest product)
-  v2_body<WM, WN, TM, TN, W_NK, PRO, false, STAGES>(g);
+  int bx, by, bz;
+  v2_multi_block(gg.xcd, bx, by, bz);
+  const GemmArgs& g = gg.a[bz];
+  if ((int64_t)bx * (32 * TM * WM) >= g.M) return;   // (the grid is sized for the longest product)
+  v2_body<WM, WN, TM, TN, W_NK, PRO, false, STAGES>(g, bx, by);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -764,6 +788,12 @@ static const int32_t* v2_perm_of(const GemmArgs& g, const tln_options& o) {
 static int v2_two_stage() {
   static const int v = getenv("TLN_V2_STAGES2") ? atoi(getenv("TLN_V2_STAGES2")) : 15;
   return v;
+}
+
+// (measurement: TLN_V2_XCD=0 keeps blockIdx.z = product in the shared launches, see v2_multi_block)
+static int v2_xcd() {
+  static const int on = (getenv("TLN_V2_XCD") != nullptr && atoi(getenv("TLN_V2_XCD")) == 0) ? 0 : 1;
+  return on && tln_xcd_on();
 }
 
 template <int WM, int WN, int TM, int TN, int STAGES>
@@ -865,6 +895,7 @@ static int launch_v2_multi(GemmArgs* g, int n, hipStream_t s, const tln_options&
   static thread_local TlnLdsAttr attr;   // (one per template instantiation)
   TLN_HIP(tln_set_max_lds(attr, reinterpret_cast<const void*>(kern), (int)lds));
   GemmArgsN<TLN_GEMM_MULTI_MAX> gg;
+  gg.xcd = v2_xcd();
   int64_t mmax = 0;
   for (int i = 0; i < TLN_GEMM_MULTI_MAX; ++i) {
     gg.a[i] = g[i < n ? i : 0];
@@ -1005,6 +1036,7 @@ int tln_gemm_v2_launch_gru_multi(int n, const float* const* d_x, const float* co
                                  int C, const float* d_w_ih, const float* d_w_hh, const float* d_b_ih, const float* d_b_hh,
                                  float* const* d_out, hipStream_t s) {
   GemmArgsN<TLN_GEMM_MULTI_MAX> gg;
+  gg.xcd = v2_xcd();
   int64_t vmax = 0;
   for (int i = 0; i < TLN_GEMM_MULTI_MAX; ++i) {
     const int k = i < n ? i : 0;

@@ -1720,12 +1720,19 @@ struct BkJob {
 };
 struct BkJobs {
   BkJob j[TLN_BK_MAXJOBS];
+  int xcd;   // 1: the frames of a batch are dealt to the XCDs (bk_block)
 };
 
+// frames of a batch <-> XCDs: common.h's tln_xcd_block — the frame's packed points (gathered by row id), its indices
+// (scattered 4-byte stores) and the lines of its buckets meet in one L2
+__device__ __forceinline__ void bk_block(const BkJobs& jobs, int& job, int& bx) { tln_xcd_block(jobs.xcd, bx, job); }
+
 __global__ void __launch_bounds__(1024) k_bk_split(const BkJobs jobs) {
-  const BkJob& J = jobs.j[blockIdx.y];
+  int job, bx;
+  bk_block(jobs, job, bx);
+  const BkJob& J = jobs.j[job];
   const int nblk = J.nblk;
-  if ((int)blockIdx.x >= nblk) return;   // (the grid is sized for the job with the most split blocks)
+  if (bx >= nblk) return;   // (the grid is sized for the job with the most split blocks)
   extern __shared__ uint32_t bk_hist[];   // [B] bucket counts of this block, then the write cursors
   __shared__ uint32_t wtmp[16];
   const int tid = threadIdx.x, T = blockDim.x;   // T: 256, 512 or 1024 (a power of two, as B)
@@ -1737,11 +1744,11 @@ __global__ void __launch_bounds__(1024) k_bk_split(const BkJobs jobs) {
   const int shift = J.shift;
   const int64_t n = J.n;
   // what k_bk_insert accumulates into: the bit mask of the first-touch rows, their number
-  for (int i = blockIdx.x * T + tid; i < J.nr_words; i += nblk * T) J.first_bits[i] = 0u;
-  if (blockIdx.x == 0 && tid == 0) J.ctr[CTR_OVERFLOW] = 0;   // accumulated by k_bk_place
+  for (int i = bx * T + tid; i < J.nr_words; i += nblk * T) J.first_bits[i] = 0u;
+  if (bx == 0 && tid == 0) J.ctr[CTR_OVERFLOW] = 0;   // accumulated by k_bk_place
   for (int i = tid; i < B; i += T) bk_hist[i] = 0;
   __syncthreads();
-  const int64_t p0 = (int64_t)blockIdx.x * ppb;
+  const int64_t p0 = (int64_t)bx * ppb;
   const int64_t p1 = p0 + ppb < n ? p0 + ppb : n;
   float* __restrict__ weights = J.weights;
   float* __restrict__ dist = J.dist;
@@ -1787,16 +1794,16 @@ __global__ void __launch_bounds__(1024) k_bk_split(const BkJobs jobs) {
   for (int k = 0; k < per; ++k) {
     const uint32_t c = bk_hist[tid * per + k];
     bk_hist[tid * per + k] = run;
-    off[(size_t)(tid * per + k) * nblk + blockIdx.x] = run;
+    off[(size_t)(tid * per + k) * nblk + bx] = run;
     run += c;
   }
-  if (tid == 0) off[(size_t)B * nblk + blockIdx.x] = total;
+  if (tid == 0) off[(size_t)B * nblk + bx] = total;
   __syncthreads();
   // the 16-byte records: weight, row, key.  The position / value of a row are re-read by k_bk_place from the frame's
   // own arrays (1.9 MB, cache resident) — carrying them along made the record 32 bytes, written once and pulled twice.
   // They go to the block's region grouped by bucket THROUGH LDS (J.stage): scattered 16-byte stores to ~1000 runs per
   // block reached memory as partial lines (2.3 x the bytes, PMC WRITE_SIZE); the staged image leaves as whole lines.
-  uint4* region = J.rec + (size_t)blockIdx.x * (4 * (size_t)ppb);
+  uint4* region = J.rec + (size_t)bx * (4 * (size_t)ppb);
   uint4* stage = reinterpret_cast<uint4*>(bk_hist + ((B + 3) & ~3));
   uint4* dst = J.stage ? stage : region;
   for (int64_t p = p0 + tid; p < p1; p += T) {
@@ -1874,13 +1881,15 @@ __device__ __forceinline__ const uint4* bk_rec_of(const BkRuns& rn, int k) { ret
 
 
 __global__ void __launch_bounds__(TLN_BK_THREADS) k_bk_insert(const BkJobs jobs) {
-  const BkJob& J = jobs.j[blockIdx.y];
-  if ((int)blockIdx.x >= J.B) return;
+  int job, bx;
+  bk_block(jobs, job, bx);
+  const BkJob& J = jobs.j[job];
+  if (bx >= J.B) return;
   __shared__ unsigned long long hk[TLN_BK_HT];
   __shared__ uint32_t htouch[TLN_BK_HT];
   __shared__ uint32_t claimed[TLN_BK_HT];   // slots this workgroup has taken in this launch (open addressing, 0 = free)
   __shared__ uint32_t wtmp[16];
-  const int tid = threadIdx.x, b = blockIdx.x;
+  const int tid = threadIdx.x, b = bx;
   const TableRef t = J.t;
   for (int i = tid; i < TLN_BK_HT; i += TLN_BK_THREADS) {
     hk[i] = TLN_KEY_EMPTY;
@@ -2011,8 +2020,10 @@ __global__ void __launch_bounds__(TLN_BK_THREADS) k_bk_prefix(const BkJobs jobs)
 }
 
 __global__ void __launch_bounds__(TLN_BK_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) k_bk_place(const BkJobs jobs) {
-  const BkJob& J = jobs.j[blockIdx.y];
-  if ((int)blockIdx.x >= J.B) return;
+  int job, bx;
+  bk_block(jobs, job, bx);
+  const BkJob& J = jobs.j[job];
+  if (bx >= J.B) return;
   if (J.ctr[CTR_BUCKET_FULL] != 0) return;             // (uniform) the frame is redone by the per-row-atomic kernels
   __shared__ unsigned long long hk[TLN_BK_HT];
   __shared__ uint32_t hcnt[TLN_BK_HT];                 // rows per entry, then the entry's write cursor
@@ -2027,7 +2038,7 @@ __global__ void __launch_bounds__(TLN_BK_THREADS) __attribute__((amdgpu_waves_pe
   TlnBinRec* bstage = reinterpret_cast<TlnBinRec*>(hv + TLN_BK_HT);
   __shared__ uint32_t wtmp[16];
   __shared__ uint32_t s_tail;
-  const int tid = threadIdx.x, b = blockIdx.x;
+  const int tid = threadIdx.x, b = bx;
   const TableRef t = J.t;
   for (int i = tid; i < TLN_BK_HT; i += TLN_BK_THREADS) {
     hk[i] = TLN_KEY_EMPTY;
@@ -2362,6 +2373,8 @@ static int bk_launch(BkJobs& jobs, int n, int split_t, hipEvent_t ev, hipStream_
   if (stage) split_lds = staged;
   for (int i = 0; i < n; ++i) jobs.j[i].stage = stage ? 1 : 0;
   for (int i = n; i < TLN_BK_MAXJOBS; ++i) jobs.j[i] = jobs.j[0];   // (never indexed: the grids have n rows)
+  static const bool xcd_off = getenv("TLN_K1_XCD") != nullptr && atoi(getenv("TLN_K1_XCD")) == 0;   // (measurement)
+  jobs.xcd = (xcd_off || !tln_xcd_on()) ? 0 : 1;
   static thread_local TlnLdsAttr split_attr;
   TLN_HIP(tln_set_max_lds(split_attr, reinterpret_cast<const void*>(k_bk_split), (int)split_lds));
   hipLaunchKernelGGL(k_bk_split, dim3((unsigned)maxblk, (unsigned)n), dim3(split_t), split_lds, s, jobs);
