@@ -951,8 +951,13 @@ static int dispatch_v2_multi(GemmArgs* g, int n, hipStream_t s, const tln_option
     }
     return (v2_two_stage() & 1) ? launch_v2_multi<4, 2, 1, 2, W_NK, PRO, 2>(g, n, s, o) : launch_v2_multi<4, 2, 1, 2, W_NK, PRO>(g, n, s, o);
   }
-  if (nn == 64)
+  if (nn == 64) {
+    // (measurement: TLN_V2_N64_WAVES=4 — four waves of 32 x 64 instead of eight of 32 x 32: every A fragment transformed once
+    //  and used by two MFMA columns, half the vector instructions per block)
+    static const int w64 = getenv("TLN_V2_N64_WAVES") ? atoi(getenv("TLN_V2_N64_WAVES")) : 8;
+    if (w64 == 4) return launch_v2_multi<4, 1, 1, 2, W_NK, PRO, 2>(g, n, s, o);
     return (v2_two_stage() & 2) ? launch_v2_multi<4, 2, 1, 1, W_NK, PRO, 2>(g, n, s, o) : launch_v2_multi<4, 2, 1, 1, W_NK, PRO>(g, n, s, o);
+  }
   if (nn == 96) return launch_v2_multi<4, 1, 1, 3, W_NK, PRO>(g, n, s, o);
   return (v2_two_stage() & 2) ? launch_v2_multi<4, 1, 1, 2, W_NK, PRO, 2>(g, n, s, o) : launch_v2_multi<4, 1, 1, 2, W_NK, PRO>(g, n, s, o);
 }
