@@ -78,7 +78,11 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g, const int bx, const i
   const int wm = wv / WN, wn = wv % WN;
   const int l31 = lane & 31, half = lane >> 5;
   // (blocks start in index order: with a launch order the heaviest blocks — most taps present — come first)
-  const int64_t m0 = (int64_t)((BM == 128 && s.order) ? s.order[bx] : bx) * BM;
+  // (64-row tiles: the two halves of the 128-row tiles the launch order is made of, in that order)
+  const int64_t m0 = (BM == 128 && s.order) ? (int64_t)s.order[bx] * BM
+                     : (BM == 64 && s.order) ? (int64_t)s.order[bx >> 1] * 128 + (bx & 1) * 64
+                                             : (int64_t)bx * BM;
+  if (m0 >= g.M) return;   // (uniform: the second half of a last 128-row tile, a grid sized for a longer product)
   const int n0 = by * BN;
   const bool has_table = s.table != nullptr;
   const int src_rows = (int)s.src_rows;
@@ -661,7 +665,10 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g, const int bx, const i
 // otherwise settle a few registers above those steps and lose a workgroup per CU.
 template <int WM, int WN, int TM, int TN, int STAGES>
 constexpr int v2_min_waves() {
-  if (STAGES == 2 && WM == 4 && WN == 2 && TM == 1 && TN == 1) return 6;
+#ifndef V2_N64_MIN_WAVES
+#define V2_N64_MIN_WAVES 6
+#endif
+  if (STAGES == 2 && WM == 4 && WN == 2 && TM == 1 && TN == 1) return V2_N64_MIN_WAVES;
   if (STAGES == 2 && WM == 4 && WN == 2 && TM == 1 && TN == 2) return 4;
   if (STAGES == 2 && WM == 2 && WN == 2 && TM == 1 && TN == 2) return 3;
   return 1;
@@ -698,19 +705,19 @@ __device__ __forceinline__ void v2_multi_block(int xcd, int& bx, int& by, int& b
 #ifndef V2_GRU_WAVES
 #define V2_GRU_WAVES 4      // waves per SIMD the cell must allow: 4 = at most 128 VGPRs
 #endif
-template <int STAGES, int GWN = 2>
-__global__ void __launch_bounds__(256 * GWN, V2_GRU_WAVES) k_gather_gemm_v2_gru(const GemmArgs g) {
-  v2_body<4, GWN, 1, 3, true, false, true, STAGES>(g, (int)blockIdx.x, (int)blockIdx.y);
+template <int STAGES, int GWN = 2, int GWM = 4>
+__global__ void __launch_bounds__(64 * GWM * GWN, (GWM == 4 ? V2_GRU_WAVES : 2)) k_gather_gemm_v2_gru(const GemmArgs g) {
+  v2_body<GWM, GWN, 1, 3, true, false, true, STAGES>(g, (int)blockIdx.x, (int)blockIdx.y);
 }
 
 // the GRU cells of lock-stepped sequences in one launch (blockIdx.z = sequence; same weights, own x / h / out)
-template <int STAGES, int GWN = 2>
-__global__ void __launch_bounds__(256 * GWN, V2_GRU_WAVES) k_gather_gemm_v2_gru_multi(const GemmArgsN<TLN_GEMM_MULTI_MAX> gg) {
+template <int STAGES, int GWN = 2, int GWM = 4>
+__global__ void __launch_bounds__(64 * GWM * GWN, (GWM == 4 ? V2_GRU_WAVES : 2)) k_gather_gemm_v2_gru_multi(const GemmArgsN<TLN_GEMM_MULTI_MAX> gg) {
   int bx, by, bz;
   v2_multi_block(gg.xcd, bx, by, bz);
   const GemmArgs& g = gg.a[bz];
-  if ((int64_t)bx * 128 >= g.M) return;   // (the grid is sized for the largest lattice)
-  v2_body<4, GWN, 1, 3, true, false, true, STAGES>(g, bx, by);
+  if ((int64_t)bx * (32 * GWM) >= g.M) return;   // (the grid is sized for the largest lattice)
+  v2_body<GWM, GWN, 1, 3, true, false, true, STAGES>(g, bx, by);
 }
 
 // several products of one shape class in one launch (blockIdx.z = product): the coarse levels of lock-stepped
@@ -720,7 +727,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (v2_min_waves<WM, WN, TM, TN, ST
   int bx, by, bz;
   v2_multi_block(gg.xcd, bx, by, bz);
   const GemmArgs& g = gg.a[bz];
-  if ((int64_t)bx * (32 * TM * WM) >= g.M) return;   // (the grid is sized for the longest product)
+  if ((int64_t)(32 * TM * WM == 64 ? (bx >> 1) * 128 : bx * (32 * TM * WM)) >= g.M) return;   // (the grid is sized for the longest product)
   v2_body<WM, WN, TM, TN, W_NK, PRO, false, STAGES>(g, bx, by);
 }
 
@@ -811,13 +818,40 @@ static int launch_v2(GemmArgs& g, hipStream_t s, const tln_options& o) {
   auto kern = k_gather_gemm_v2<WM, WN, TM, TN, W_NK, PRO, STAGES>;
   static thread_local TlnLdsAttr attr;   // (one per template instantiation)
   TLN_HIP(tln_set_max_lds(attr, reinterpret_cast<const void*>(kern), (int)lds));
-  dim3 grid((unsigned)tln_cdiv(g.M, BM), (unsigned)tln_cdiv(g.N, BN), 1);
+  dim3 grid((unsigned)(BM == 64 ? 2 * tln_cdiv(g.M, 128) : tln_cdiv(g.M, BM)), (unsigned)tln_cdiv(g.N, BN), 1);
   g.splits = 1;
   g.s[0].perm = v2_perm_of(g, o);
   g.fold_taps = v2_fold_taps(g.s[0].cin);
   g.s[0].order = g.s[0].perm ? tln_table_tile_order(g.s[0].table, g.M) : nullptr;
   hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, s, g);
   return TLN_OK;
+}
+
+static int v2_cu_count() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      cus = prop.multiProcessorCount;
+    else
+      cus = 256;
+  }
+  return cus;
+}
+
+// 64-row tiles of four waves where a launch has few tiles per CU, 128-row tiles of eight where it has many.  A product of
+// one sequence alone has 235 tiles of 128 rows for 256 CUs — one eight-wave workgroup per CU, its prologue and epilogue
+// exposed, 21 CUs idle; as 470 tiles of 64 rows two to four independent workgroups share a CU (LDS: 36 / 53 / 69 KB for
+// 64 / 128 / 192 columns), each a barrier domain of four waves.  The price is the weight tile staged once per 64 rows
+// instead of 128 — L2 -> LDS traffic, of which there is enough.  MEASURED (round 4, same box): one sequence alone 664 ->
+// 672 (64 columns) -> 678 (+ 128) -> 681 clouds/s (+ 192); four streams x 8: 64 columns 1457 -> 1462, 192 columns
+// 1484 -> 1487 with the replay of a group's products 0.740 -> 0.748 of the peak.  Launches with many tiles per CU (the
+// 1M-vertex lattices of SURVEY 8d's config 5) keep the 128-row tiles.  TLN_V2_ROWS64: 1 always, 0 never (measurements).
+static bool v2_rows64(int64_t tiles128) {
+  static const int env = getenv("TLN_V2_ROWS64") ? atoi(getenv("TLN_V2_ROWS64")) : -1;
+  if (env >= 0) return env != 0;
+  return tiles128 < (int64_t)16 * v2_cu_count();
 }
 
 template <bool W_NK, bool PRO>
@@ -827,6 +861,11 @@ static int dispatch_v2(GemmArgs& g, hipStream_t s, const tln_options& o) {
   // faster than four waves of twice the tile on every shape of the workload (TLN_V2_WAVES=4 brings those back)
   static const int waves = getenv("TLN_V2_WAVES") ? atoi(getenv("TLN_V2_WAVES")) : 8;
   if (waves == 8) {
+    if (v2_rows64(tln_cdiv(g.M, 128) * tln_cdiv(n, n % 192 == 0 ? 192 : (n % 128 == 0 ? 128 : 64)))) {
+      if (n % 192 == 0) return launch_v2<2, 2, 1, 3, W_NK, PRO, 2>(g, s, o);
+      if (n % 128 == 0) return launch_v2<2, 2, 1, 2, W_NK, PRO, 2>(g, s, o);
+      if (n == 64) return launch_v2<2, 2, 1, 1, W_NK, PRO, 2>(g, s, o);
+    }
     if (n % 192 == 0)   // 128 x 192, 8 waves of 32 x 96
       return (v2_two_stage() & 4) ? launch_v2<4, 2, 1, 3, W_NK, PRO, 2>(g, s, o) : launch_v2<4, 2, 1, 3, W_NK, PRO>(g, s, o);
     if (n % 128 == 0) {   // 128 x 128, 8 waves of 32 x 64
@@ -873,18 +912,6 @@ bool tln_gemm_v2_multi_ok(const GemmArgs* g, int n, bool w_is_nk, const bool* ve
   return total >= (multi_min > 0 ? multi_min : v2_min_m(o));
 }
 
-static int v2_cu_count() {
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-      cus = prop.multiProcessorCount;
-    else
-      cus = 256;
-  }
-  return cus;
-}
 
 template <int WM, int WN, int TM, int TN, bool W_NK, bool PRO, int STAGES = V2_STAGES>
 static int launch_v2_multi(GemmArgs* g, int n, hipStream_t s, const tln_options& o) {
@@ -905,7 +932,18 @@ static int launch_v2_multi(GemmArgs* g, int n, hipStream_t s, const tln_options&
     gg.a[i].s[0].order = gg.a[i].s[0].perm ? tln_table_tile_order(gg.a[i].s[0].table, gg.a[i].M) : nullptr;
     if (i < n && g[i].M > mmax) mmax = g[i].M;
   }
-  dim3 grid((unsigned)tln_cdiv(mmax, BM), (unsigned)tln_cdiv(g[0].N, BN), (unsigned)n);
+  dim3 grid((unsigned)(BM == 64 ? 2 * tln_cdiv(mmax, 128) : tln_cdiv(mmax, BM)), (unsigned)tln_cdiv(g[0].N, BN), (unsigned)n);
+  {   // (measurement: TLN_V2_OCC=1 prints, once per tile class, how many workgroups of it the runtime fits on a CU)
+    static const bool occ = getenv("TLN_V2_OCC") != nullptr;
+    static thread_local bool said = false;
+    if (occ && !said) {
+      said = true;
+      int nb = -1;
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 64 * WM * WN, lds);
+      fprintf(stderr, "[v2 occupancy] multi<%d,%d,%d,%d,%d,%d,%d> cin %d: %zu B of LDS, %d workgroups per CU\n", WM, WN, TM, TN,
+              (int)W_NK, (int)PRO, STAGES, g[0].s[0].cin, lds, nb);
+    }
+  }
   hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, s, gg);
   return TLN_OK;
 }
@@ -913,8 +951,13 @@ static int launch_v2_multi(GemmArgs* g, int n, hipStream_t s, const tln_options&
 template <bool W_NK, bool PRO>
 static int dispatch_v2_multi(GemmArgs* g, int n, hipStream_t s, const tln_options& o) {
   const int nn = g[0].N;
-  if (nn % 192 == 0)
+  int64_t tiles128 = 0;
+  for (int i = 0; i < n; ++i) tiles128 += tln_cdiv(g[i].M, 128);
+  tiles128 *= tln_cdiv(nn, nn % 192 == 0 ? 192 : (nn % 128 == 0 ? 128 : 64));
+  if (nn % 192 == 0) {
+    if (v2_rows64(tiles128)) return launch_v2_multi<2, 2, 1, 3, W_NK, PRO, 2>(g, n, s, o);
     return (v2_two_stage() & 4) ? launch_v2_multi<4, 2, 1, 3, W_NK, PRO, 2>(g, n, s, o) : launch_v2_multi<4, 2, 1, 3, W_NK, PRO>(g, n, s, o);
+  }
   if (nn % 128 == 0) {
     // Tile height against the quantisation of the launch: two workgroups of this tile share a CU, and a CU's time is
     // (workgroups it gets) x (rows per workgroup).  The lock-stepped level-1 products have 52k-72k rows together — 407 to
@@ -956,6 +999,7 @@ static int dispatch_v2_multi(GemmArgs* g, int n, hipStream_t s, const tln_option
     //  and used by two MFMA columns, half the vector instructions per block)
     static const int w64 = getenv("TLN_V2_N64_WAVES") ? atoi(getenv("TLN_V2_N64_WAVES")) : 8;
     if (w64 == 4) return launch_v2_multi<4, 1, 1, 2, W_NK, PRO, 2>(g, n, s, o);
+    if (v2_rows64(tiles128)) return launch_v2_multi<2, 2, 1, 1, W_NK, PRO, 2>(g, n, s, o);   // 64 x 64 tile of four waves: four workgroups per CU
     return (v2_two_stage() & 2) ? launch_v2_multi<4, 2, 1, 1, W_NK, PRO, 2>(g, n, s, o) : launch_v2_multi<4, 2, 1, 1, W_NK, PRO>(g, n, s, o);
   }
   if (nn == 96) return launch_v2_multi<4, 1, 1, 3, W_NK, PRO>(g, n, s, o);
@@ -973,6 +1017,12 @@ int tln_gemm_v2_launch_multi(GemmArgs* g, int n, bool w_is_nk, hipStream_t s, co
 static bool v2_gru_half() {
   static const bool on = getenv("TLN_GRU_HALF") != nullptr && atoi(getenv("TLN_GRU_HALF")) != 0;
   return on;
+}
+
+// (measurement: TLN_GRU_ROWS64=1 always / 0 never / 2 by v2_rows64's rule: the cell on 64 x 192 tiles of four waves)
+static bool v2_gru_rows64(int64_t tiles128) {
+  static const int env = getenv("TLN_GRU_ROWS64") ? atoi(getenv("TLN_GRU_ROWS64")) : 0;
+  return env == 1 || (env == 2 && v2_rows64(tiles128));
 }
 
 // h' = GRUCell(x, pad(h)) as one two-source product with the cell in its epilogue (see v2_body)
@@ -1015,6 +1065,13 @@ int tln_gemm_v2_launch_gru(const float* d_x, const float* d_h, int64_t Vh, int64
   v2_gru_args(g, d_x, d_h, Vh, V, C, d_w_ih, d_w_hh, d_b_ih, d_b_hh, d_out);
   constexpr int BM = 128, BN = 192;
   const bool two = (v2_two_stage() & 8) != 0;
+  if (v2_gru_rows64(tln_cdiv(V, 128) * (C / 64))) {   // 64 x 192 tile of four waves, two workgroups per CU
+    const size_t lds = (size_t)2 * (64 + BN) * 128 + (size_t)64 * TLN_TAPS * 4 + (size_t)2 * C * 4 + (size_t)(64 + 32) * 4;
+    static thread_local TlnLdsAttr attrr;
+    TLN_HIP(tln_set_max_lds(attrr, reinterpret_cast<const void*>(k_gather_gemm_v2_gru<2, 2, 2>), (int)lds));
+    hipLaunchKernelGGL((k_gather_gemm_v2_gru<2, 2, 2>), dim3((unsigned)tln_cdiv(V, 64), (unsigned)(C / 64), 1), dim3(256), lds, s, g);
+    return TLN_OK;
+  }
   if (v2_gru_half()) {   // 128 x 96 tile of four waves, two workgroups per CU
     const size_t lds = (size_t)2 * (BM + 96) * 128 + (size_t)BM * TLN_TAPS * 4 + (size_t)2 * C * 4 + (size_t)(BM + 32) * 4;
     static thread_local TlnLdsAttr attrh;
@@ -1050,6 +1107,15 @@ int tln_gemm_v2_launch_gru_multi(int n, const float* const* d_x, const float* co
   }
   constexpr int BM = 128, BN = 192;
   const bool two = (v2_two_stage() & 8) != 0;
+  int64_t tiles128 = 0;
+  for (int i = 0; i < n; ++i) tiles128 += tln_cdiv(V[i], 128) * (C / 64);
+  if (v2_gru_rows64(tiles128)) {
+    const size_t lds = (size_t)2 * (64 + BN) * 128 + (size_t)64 * TLN_TAPS * 4 + (size_t)2 * C * 4 + (size_t)(64 + 32) * 4;
+    static thread_local TlnLdsAttr attrr;
+    TLN_HIP(tln_set_max_lds(attrr, reinterpret_cast<const void*>(k_gather_gemm_v2_gru_multi<2, 2, 2>), (int)lds));
+    hipLaunchKernelGGL((k_gather_gemm_v2_gru_multi<2, 2, 2>), dim3((unsigned)tln_cdiv(vmax, 64), (unsigned)(C / 64), (unsigned)n), dim3(256), lds, s, gg);
+    return TLN_OK;
+  }
   if (v2_gru_half()) {
     const size_t lds = (size_t)2 * (BM + 96) * 128 + (size_t)BM * TLN_TAPS * 4 + (size_t)2 * C * 4 + (size_t)(BM + 32) * 4;
     static thread_local TlnLdsAttr attrh;
