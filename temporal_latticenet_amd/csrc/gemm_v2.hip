@@ -659,15 +659,17 @@ __device__ __forceinline__ void v2_body(const GemmArgs& g, const int bx, const i
 #endif
 }
 
-// Waves per SIMD a tile must keep for the workgroups per CU its LDS footprint allows (two-stage rings): the 128 x 64 tile
-// three workgroups of eight waves (6 per SIMD: 80 registers), the 64-row tile three of four waves (3 per SIMD: 168).
-// Given to the compiler as the second launch bound: with the split accumulation's second accumulator set it would
-// otherwise settle a few registers above those steps and lose a workgroup per CU.
+// Waves per SIMD a tile must keep for the workgroups per CU its LDS footprint allows (two-stage rings; LDS is granted in
+// granules of 2 KB on this chip: TLN_V2_OCC=1 prints what the runtime fits): the 128 x 128 tile two workgroups of eight
+// waves (4 per SIMD: 128 registers), the 64-row tile of 128 columns three of four waves (3 per SIMD: 168), the 128 x 64 tile
+// two of eight.  Given to the compiler as the second launch bound: with the split accumulation's second accumulator set it
+// would otherwise settle a few registers above those steps and lose a workgroup per CU.
 template <int WM, int WN, int TM, int TN, int STAGES>
 constexpr int v2_min_waves() {
 #ifndef V2_N64_MIN_WAVES
-#define V2_N64_MIN_WAVES 6
-#endif
+#define V2_N64_MIN_WAVES 4   // (6 until round 4's last day: TLN_V2_OCC=1 showed TWO workgroups of the 128 x 64 tile per CU, not
+#endif                       //  three — its 54 912 B round up to 27 LDS granules of 2 KB, 3 x 27 > 80 —, so the cap at 80 registers
+                             //  bought four spilled lane constants and nothing else; measured equal, 1457 either way)
   if (STAGES == 2 && WM == 4 && WN == 2 && TM == 1 && TN == 1) return V2_N64_MIN_WAVES;
   if (STAGES == 2 && WM == 4 && WN == 2 && TM == 1 && TN == 2) return 4;
   if (STAGES == 2 && WM == 2 && WN == 2 && TM == 1 && TN == 2) return 3;
