@@ -653,6 +653,9 @@ def main():
             "config": {"workload": "%d-frame sequence, %d pts/frame, sigma=%s, rnn_modules=[%s], 26 classes, "
                                    "full U-Net lattice encoder/decoder, inference" % (args.frames, args.points, args.sigma, args.rnn),
                        "parallelism": par, "vertices_per_frame_V0_V1_V2": vcounts,
+                       "outputs": "last frame of every sequence: log-softmax + raw class scores [N, 26]; the early-return "
+                                  "frames' lattice values stay in the fusion modules' state buffers (the reference returns "
+                                  "that tensor itself, models.py:430, and its loops drop it; TLN_KEEP_EARLY=1 copies them out)",
                        "lattice_scale_constant": "%.6f (%s)" % (lattice.scale_constant(),
                                                               "Adams 2010's (d+1)*sqrt(2/3), the default"
                                                               if args.scale_constant in (None, "adams") else

@@ -533,8 +533,9 @@ int tln_program_begin_frame_group(tln_program_t* const* programs, tln_lattice_t*
                                   const float* const* d_positions, const float* const* d_values, const int64_t* n,
                                   int count, int val_dim, int reset_hashmap, int subtract_mean, int need_indices,
                                   int64_t* v_out, void* stream);
-/* the rest of the frame.  early != 0: stop at the program's STOP_IF_EARLY op and copy that slot to d_out;
- * else the TLN_SLOT_OUT slot is d_out.  d_out must hold out_rows x out_cols floats (checked). */
+/* the rest of the frame.  early != 0: stop at the program's STOP_IF_EARLY op and copy that slot to d_out (d_out NULL:
+ * no copy — the caller drops the early-return value, as the reference's train / test loops do with the tensor
+ * models.py:430 hands them); else the TLN_SLOT_OUT slot is d_out.  d_out must hold out_rows x out_cols floats (checked). */
 int tln_program_run(tln_program_t* p, int early, float* d_out, int64_t out_rows, int out_cols, void* stream);
 /* measurement (bench.py roofline): with capture on, tln_program_run remembers the resolved arguments of every
  * gather-GEMM it launches; replay launches that list `reps` times back to back between two HIP events on `stream`

@@ -664,10 +664,12 @@ int walk(tln_program* p, int mode, int early, float* d_out, int64_t out_rows, in
         if (nolaunch) break;
         const tln_slot& ss = p->slots[o.s0.slot];
         const int64_t rows = p->rt[o.s0.slot].rows;
-        TLN_REQUIRE(d_out && rows == out_rows && ss.cols == out_cols,
+        // (d_out NULL: the caller does not want the value — the reference returns the hidden-state tensor itself there,
+        //  models.py:430, and its loops drop it; here it would be a copy out of the program's state buffer)
+        TLN_REQUIRE(!d_out || (rows == out_rows && ss.cols == out_cols),
                     "early-return value is [%lld,%d], caller gave [%lld,%d]", (long long)rows, ss.cols,
                     (long long)out_rows, out_cols);
-        if (rows > 0)
+        if (rows > 0 && d_out)
           TLN_HIP(hipMemcpyAsync(d_out, fptr(o.s0.slot), (size_t)rows * ss.cols * sizeof(float),
                                  hipMemcpyDeviceToDevice, s));
         break;

@@ -415,8 +415,11 @@ class FrameProgram:
     def _rows(self, code, n):
         return n if code == ROWS_POINTS else (4 * n if code == ROWS_POINT_ROWS else int(self._v[code]))
 
-    def run_frame(self, ls, positions, values, reset_hashmap, early_return):
-        """-> (tensor, ls): the early-return lattice values [V, C] or the class scores [N, nr_classes]"""
+    def run_frame(self, ls, positions, values, reset_hashmap, early_return, keep_early=True):
+        """-> (tensor, ls): the early-return lattice values [V, C] or the class scores [N, nr_classes].
+        keep_early=False: an early-return frame hands back None instead of the [V, C] values — the reference returns its
+        hidden-state tensor itself there (models.py:430) and its loops drop it; here the value would be a copy out of the
+        program's state buffer (23 MB per frame on the headline workload)"""
         positions = positions.contiguous().float()
         n = positions.shape[0]
         if values is None or values.numel() == 0:
@@ -436,13 +439,15 @@ class FrameProgram:
         early = bool(early_return) and self.stop_shape is not None
         rows_code, cols = self.stop_shape if early else self.out_shape
         rows = self._rows(rows_code, n)
-        out = torch.empty((rows, cols), dtype=torch.float32, device="cuda")
+        out = None if (early and not keep_early) else torch.empty((rows, cols), dtype=torch.float32, device="cuda")
         self.last_logsm = None
         if not early and self.fused_logsm:
             self.last_logsm = torch.empty_like(out)
             _lib.check(lib.tln_program_set_aux_out(self._h, self.last_logsm.data_ptr()), "tln_program_set_aux_out")
-        _lib.check(lib.tln_program_run(self._h, 1 if early else 0, out.data_ptr(), rows, cols, s), "tln_program_run")
-        ls.set_values(out)
+        _lib.check(lib.tln_program_run(self._h, 1 if early else 0, out.data_ptr() if out is not None else None, rows, cols, s),
+                   "tln_program_run")
+        if out is not None:
+            ls.set_values(out)
         return out, ls
 
     def take_logsm(self):
@@ -479,8 +484,9 @@ class FrameProgram:
         return early, torch.empty((self._rows(rows_code, n), cols), dtype=torch.float32, device="cuda")
 
     @staticmethod
-    def run_frame_group(progs, lattices, positions, values, reset_hashmap, early_return):
-        """2..8 sequences in lock-step on the current stream (tln_program_run_group): -> [(tensor, ls), ...]"""
+    def run_frame_group(progs, lattices, positions, values, reset_hashmap, early_return, keep_early=True):
+        """2..8 sequences in lock-step on the current stream (tln_program_run_group): -> [(tensor, ls), ...]
+        (keep_early=False: None instead of the early-return values, see run_frame)"""
         n = len(progs)
         # the frames of all sequences begun by ONE native call: a single batch of K1 launches (blockIdx.y = sequence),
         # one wait for the vertex counters
@@ -513,23 +519,26 @@ class FrameProgram:
                 p._v[i] = vout[k * MAX_LEVELS + i]
             early_k = bool(early_return) and p.stop_shape is not None
             rows_code, cols = p.stop_shape if early_k else p.out_shape
-            begun.append((early_k, torch.empty((p._rows(rows_code, int(ns[k])), cols), dtype=torch.float32, device="cuda")))
+            shape = (p._rows(rows_code, int(ns[k])), cols)
+            begun.append((early_k, shape, None if (early_k and not keep_early) else
+                          torch.empty(shape, dtype=torch.float32, device="cuda")))
         started = (pos, vals)                          # the inputs stay alive until the frames have been enqueued
-        early, outs = begun[0][0], [x[1] for x in begun]
-        assert all(x[0] == early for x in begun) and all(o.shape[1] == outs[0].shape[1] for o in outs)
+        early, shapes, outs = begun[0][0], [x[1] for x in begun], [x[2] for x in begun]
+        assert all(x[0] == early for x in begun) and all(sh[1] == shapes[0][1] for sh in shapes)
         for p, o in zip(progs, outs):
             p.last_logsm = None
             if not early and p.fused_logsm:
                 p.last_logsm = torch.empty_like(o)
                 _lib.check(_lib.lib().tln_program_set_aux_out(p._h, p.last_logsm.data_ptr()), "tln_program_set_aux_out")
         hs = (C.c_void_p * n)(*[p._h for p in progs])
-        ptrs = (C.c_void_p * n)(*[o.data_ptr() for o in outs])
-        rows = (C.c_int64 * n)(*[o.shape[0] for o in outs])
-        _lib.check(_lib.lib().tln_program_run_group(hs, n, 1 if early else 0, ptrs, rows, outs[0].shape[1], stream_ptr()),
+        ptrs = (C.c_void_p * n)(*[o.data_ptr() if o is not None else None for o in outs])
+        rows = (C.c_int64 * n)(*[sh[0] for sh in shapes])
+        _lib.check(_lib.lib().tln_program_run_group(hs, n, 1 if early else 0, ptrs, rows, shapes[0][1], stream_ptr()),
                    "tln_program_run_group")
         del started                                    # the inputs stayed alive until the frames were enqueued
         for ls, o in zip(lattices, outs):
-            ls.set_values(o)
+            if o is not None:
+                ls.set_values(o)
         return list(zip(outs, lattices))
 
     run_frame_pair = run_frame_group

@@ -73,6 +73,11 @@ class LNN_SEQ(torch.nn.Module):
         self.sequence_learning = model_config["sequence_learning"]
         self.h_lv = None
         self.first_sequence = True
+        # True (the reference's contract, models.py:430): an early-return frame hands back the lattice values it stopped
+        # at.  A caller that drops them — as train_ln.py / test_ln.py do for every frame but the last — may set this False:
+        # the frame program then returns None there instead of copying the values out of its state buffer (the
+        # reference returns the module's own tensor: no copy on its side either)
+        self.keep_early_values = True
         self.rnn_modules = [x.lower() for x in model_config["rnn_modules"]]
         for i in range(len(self.rnn_modules)):
             if self.rnn_modules[i] not in ["linear", "maxpool", "cga", "aflow", "lstm", "gru"]:
@@ -217,7 +222,7 @@ class LNN_SEQ(torch.nn.Module):
             reset_hashmap = False
         prog = self._program_for_this_frame(vis_aflow)
         if prog is not None:
-            out, ls = prog.run_frame(ls, positions, values, reset_hashmap, early_return)
+            out, ls = prog.run_frame(ls, positions, values, reset_hashmap, early_return, self.keep_early_values)
             self.first_sequence = False
             if early_return and prog.stop_shape is not None:
                 return out, out, ls
@@ -362,7 +367,8 @@ def forward_group(models, lattices, positions, values, early_return=False):
     if len(models) < 2 or len(models) > 8 or any(p is None for p in progs) or any(r != resets[0] for r in resets) or \
             len(set(id(p) for p in progs)) != len(progs):
         return [mod(ls, p, v, early_return, False) for mod, ls, p, v in zip(models, lattices, positions, values)]
-    res = engine.FrameProgram.run_frame_group(progs, lattices, positions, values, resets[0], early_return)
+    res = engine.FrameProgram.run_frame_group(progs, lattices, positions, values, resets[0], early_return,
+                                              any(mod.keep_early_values for mod in models))
     out = []
     for mod, prog, (o, ls) in zip(models, progs, res):
         mod.first_sequence = False

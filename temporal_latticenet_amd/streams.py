@@ -125,6 +125,18 @@ class SequenceStreams:
         return ps, vs
 
     def _work(self, i, sequences, keep_outputs):
+        # (run() hands back last-frame outputs only: the early-return values of the other frames are not materialised)
+        mine = self.models[self.group * i:self.group * i + self.group] if self.pairs else [self.models[i]]
+        before = [m.keep_early_values for m in mine]
+        for m in mine:
+            m.keep_early_values = bool(os.environ.get("TLN_KEEP_EARLY"))      # (measurement: the copies back in)
+        try:
+            return self._work_inner(i, sequences, keep_outputs)
+        finally:
+            for m, b in zip(mine, before):
+                m.keep_early_values = b
+
+    def _work_inner(self, i, sequences, keep_outputs):
         try:
             outs = []
             with torch.no_grad(), torch.cuda.stream(self.streams[i]):

@@ -82,6 +82,53 @@ def test_program_matches_oracle(gpu):
         assert err <= 1e-4 * max(1.0, float(want.abs().max())), "frame %d: %.3e" % (t, err)
 
 
+def test_early_return_values_are_optional(gpu):
+    """keep_early_values = False: an early-return frame hands back None (the value the reference's loops drop is not
+    copied out of the program's state buffer, tln_program_run with d_out = NULL) and the last frame's outputs — one
+    sequence alone and a lock-step group — do not change by a bit"""
+    from temporal_latticenet_amd.models import forward_group
+    from temporal_latticenet_amd.streams import share_parameters
+    contents = make_config(rnn_modules=("gru", "gru", "aflow", "gru"), frames=3, sigma=0.7)
+    seq = make_sequence(9000, 3, seed=23)
+    model = _prepared(contents, seq, gpu)
+    model.use_frame_program = True
+    ref, used = _run(model, contents, seq, gpu)
+    assert all(used)
+    model.keep_early_values = False
+    lat = make_lattice(contents)
+    with torch.no_grad():
+        for t, (pos, val) in enumerate(seq):
+            a, b, lat = model(lat, torch.from_numpy(pos).to(gpu), torch.from_numpy(val).to(gpu), t != 2, False)
+            if t != 2:
+                assert a is None and b is None
+    model.reset_sequence()
+    assert torch.equal(b, ref[2][1]) and torch.equal(a, ref[2][0])
+    # a lock-step group of two (the second one a replica sharing the parameters)
+    other = build_model(contents).eval()
+    other.use_frame_program = False
+    _run(other, contents, seq, gpu)
+    other = share_parameters(other, model)
+    other.use_frame_program = True
+    kept = None
+    for keep in (True, False):
+        model.keep_early_values = other.keep_early_values = keep
+        lats = [make_lattice(contents), make_lattice(contents)]
+        with torch.no_grad():
+            for t, (pos, val) in enumerate(seq):
+                p, v = torch.from_numpy(pos).to(gpu), torch.from_numpy(val).to(gpu)
+                res = forward_group([model, other], lats, [p, p], [v, v], t != 2)
+                lats = [r[2] for r in res]
+                if t != 2:
+                    assert all((r[1] is None) == (not keep) for r in res)
+        model.reset_sequence()
+        other.reset_sequence()
+        if keep:
+            kept = [r[1].clone() for r in res]
+        else:
+            for r, w in zip(res, kept):
+                assert torch.equal(r[1], w)
+
+
 def test_hidden_states_follow_a_frame_that_needs_the_operator_route(gpu):
     """frames 0-1 through the program, frames 2-3 through the modules: the states are handed over"""
     contents = make_config(rnn_modules=("gru", "gru", "aflow", "gru"), frames=4, sigma=0.7)
