@@ -41,7 +41,8 @@ int tln_version(void);
 typedef struct tln_options {
   int k1_legacy;         /* K1: 0 = partitioned kernels (default), 1 = one global atomic per row (always taken for val_dim > 1) */
   int k1_bucket_rows;    /* K1: rows per bucket the partitioned kernels aim at; 0 = default (512) */
-  int pool_mode;         /* K2: -1 = default, 0 = VALU fma chains, 1 / 2 = wide layers on the matrix cores (same bits) */
+  int pool_mode;         /* K2: -1 = default, 0 = VALU fma chains, 1 / 2 = wide layers on the matrix cores, 3 = VALU, two rows per
+                            step (all the same bits) */
   int gemm_direct;       /* small-M "direct" kernel: 0 = heuristic, 1 = whenever eligible, -1 = never */
   int gemm_pair_off;     /* 1 = tln_gather_gemm_pair / _multi as separate launches */
   int gemm_tn;           /* force the column tile of the tiled kernel (1 / 2: 64 / 128 columns; 0 = heuristic) */

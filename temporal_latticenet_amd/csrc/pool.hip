@@ -335,6 +335,164 @@ __global__ void __launch_bounds__(256) k_pool_bins(const PoolJobs jobs, int min_
 }
 
 // ---------------------------------------------------------------------------------------
+// k_pool_bins with TWO rows per step (round 4; the 4/3-16-32-64 MLP only).  k_pool_bins's last layer has lane = channel and
+// fetches the 32 activations of ONE row per step by eight broadcast ds_read_b128 — four LDS cycles each whatever the number
+// of distinct addresses per lane group, 32 LDS cycles per row and wave, the CU's LDS the busiest unit of the launch.  A
+// ds_read_b128 serves its four groups of 16 lanes one address each, and every group lies inside one half of the wave: with
+// the lower half on row t and the upper half on row 32 + t of the chunk the same eight reads deliver TWO rows.  Each lane
+// then owns two channels (c and c + 32: two weight rows in registers, two fma chains per step — the same 32 fmas per row
+// and wave as before), and each half walks its 32-row block by itself: vertex, row id and flags of a row come from small LDS
+// arrays (one address per half), the running maxima and the flush are per lane.  A vertex whose rows cross the block
+// boundary is not "whole" for either half — decided from the first-row / last-row flags as before — and goes through the
+// packed atomicMax and k_pool_bins_finalize (which tests block boundaries of 32 rows for this kernel).  Same chains, same
+// tie rule: bit for bit k_pool_bins.
+template <int CIN>
+__global__ void __launch_bounds__(256) k_pool_bins2(const PoolJobs jobs, int min_points, const float* __restrict__ w1,
+                                                    const float* __restrict__ b1, const float* __restrict__ w2,
+                                                    const float* __restrict__ b2, const float* __restrict__ w3,
+                                                    const float* __restrict__ b3) {
+  constexpr int H1 = 16, H2 = 32, COUT = 64, HL = 32, TS = 36;
+  const PoolJob& J = jobs.j[blockIdx.y];
+  const TlnBins& bn = J.bn;
+  const int64_t rows = J.rows;
+  unsigned long long* __restrict__ packed = J.packed;
+  float* __restrict__ out = J.out;
+  int32_t* __restrict__ argrow = J.argrow;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float* tile = smem + wid * (64 * TS + 4 * 64);
+  float* tw = tile + 64 * TS;                       // [64] barycentric weight of the chunk's rows
+  int* tv = reinterpret_cast<int*>(tw + 64);        // [64] vertex
+  int* tr = tv + 64;                                // [64] row id
+  int* tf = tr + 64;                                // [64] flags
+  const int64_t chunk = (int64_t)blockIdx.x * 4 + wid;
+  const int64_t j0 = chunk * 64;
+  if (j0 >= rows) return;  // no block barrier below: the tile is private to the wave
+  const int cnt = (int)((rows - j0) < 64 ? (rows - j0) : 64);
+  const int nv = bn.ctr[0];
+  const float w0 = bn.weights[0];   // lm:514
+
+  // ---- phase 1: lane = row (as k_pool_bins)
+  if (lane < cnt) {
+    const int64_t at = j0 + lane;
+    float4 q = bn.rec[at].a;
+    const uint4 meta = bn.rec[at].m;
+    const int v = (int)meta.z;
+    int flags = 0, vv = 0;
+    if (v >= 0) {
+      vv = v;
+      if (bn.subtract) {
+        q.x -= bn.mean[3 * v];
+        q.y -= bn.mean[3 * v + 1];
+        q.z -= bn.mean[3 * v + 2];
+      }
+      if (v != 0) {
+        const int st = bn.vstart[v], c = bn.vcnt[v];
+        if ((int64_t)st == at) flags |= 1;
+        if ((int64_t)st + c == at + 1) flags |= 2;
+        if (c < min_points) flags |= 4;
+      }
+    }
+    const float xin[4] = {q.x, q.y, q.z, q.w};
+    float x[CIN];
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) x[c] = xin[c];
+    float h1[H1], hl[HL];
+    dense<CIN, H1, true>(w1, b1, x, h1);
+    dense<H1, H2, true>(w2, b2, h1, hl);
+#pragma unroll
+    for (int c = 0; c < HL; ++c) tile[lane * TS + c] = hl[c];
+    tw[lane] = __uint_as_float(meta.x);
+    tv[lane] = vv;
+    tr[lane] = (int)meta.y;
+    tf[lane] = flags;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  // ---- phase 2: lane = (block of 32 rows, channels cl and cl + 32)
+  const int half = lane >> 5, cl = lane & 31;
+  float wa[HL], wb[HL];
+#pragma unroll
+  for (int i = 0; i < HL; ++i) {
+    wa[i] = w3[cl * HL + i];
+    wb[i] = w3[(cl + 32) * HL + i];
+  }
+  const float bias_a = b3[cl], bias_b = b3[cl + 32];
+  const int base = half * 32;
+  const int mine = cnt - base < 0 ? 0 : (cnt - base > 32 ? 32 : cnt - base);   // rows of this half's block
+  const int steps = cnt < 32 ? cnt : 32;                                       // (wave-uniform: the lower block's rows)
+  // one vertex segment of this half: (cur, flags of its first row, flags of its latest row), the two running maxima
+  int cur = -1, f_first = 0, f_last = 0;
+  float best_a = 0.0f, best_b = 0.0f;
+  int bj_a = 0, bj_b = 0, brow_a = 0, brow_b = 0;
+  auto flush = [&]() {
+    const bool whole = (f_first & 1) && (f_last & 2);
+    if (whole) {
+      const bool masked = (f_first & 4) != 0;
+      const float bary_a = brow_a > nv ? w0 : tw[bj_a];
+      const float bary_b = brow_b > nv ? w0 : tw[bj_b];
+      float* o = out + (int64_t)cur * (2 * COUT);
+      o[cl] = masked ? 0.0f : best_a;
+      o[cl + 32] = masked ? 0.0f : best_b;
+      o[COUT + cl] = masked ? 0.0f : bary_a;
+      o[COUT + cl + 32] = masked ? 0.0f : bary_b;
+      if (argrow) {
+        argrow[(int64_t)cur * COUT + cl] = masked ? -1 : brow_a;
+        argrow[(int64_t)cur * COUT + cl + 32] = masked ? -1 : brow_b;
+      }
+    } else {
+      const unsigned long long pa = ((unsigned long long)tln_f2ord(best_a) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)brow_a);
+      const unsigned long long pb = ((unsigned long long)tln_f2ord(best_b) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)brow_b);
+      atomicMax(&packed[(int64_t)cur * COUT + cl], pa);
+      atomicMax(&packed[(int64_t)cur * COUT + cl + 32], pb);
+    }
+  };
+  for (int t = 0; t < steps; ++t) {
+    const bool valid = t < mine;
+    const int j = valid ? base + t : 0;        // (a half without this row reads row 0 and drops the result)
+    const float* h = tile + j * TS;
+    float va = bias_a, vb = bias_b;            // ONE fma chain per channel in ascending i
+#pragma unroll
+    for (int i = 0; i < HL; i += 4) {
+      const float4 q = *reinterpret_cast<const float4*>(h + i);   // one address per half of the wave
+      va = fmaf(wa[i], q.x, va);
+      vb = fmaf(wb[i], q.x, vb);
+      va = fmaf(wa[i + 1], q.y, va);
+      vb = fmaf(wb[i + 1], q.y, vb);
+      va = fmaf(wa[i + 2], q.z, va);
+      vb = fmaf(wb[i + 2], q.z, vb);
+      va = fmaf(wa[i + 3], q.w, va);
+      vb = fmaf(wb[i + 3], q.w, vb);
+    }
+    const int v = tv[j], rj = tr[j], f = tf[j];
+    if (valid) {
+      if (v != cur) {
+        if (cur >= 0) flush();
+        cur = v;
+        f_first = f;
+        best_a = va;
+        best_b = vb;
+        bj_a = bj_b = j;
+        brow_a = brow_b = rj;
+      } else {
+        const bool ga = va > best_a || (va == best_a && rj < brow_a);   // ties: the smallest row id
+        const bool gb = vb > best_b || (vb == best_b && rj < brow_b);
+        best_a = ga ? va : best_a;
+        bj_a = ga ? j : bj_a;
+        brow_a = ga ? rj : brow_a;
+        best_b = gb ? vb : best_b;
+        bj_b = gb ? j : bj_b;
+        brow_b = gb ? rj : brow_b;
+      }
+      f_last = f;
+    }
+  }
+  if (cur >= 0) flush();
+}
+
+// ---------------------------------------------------------------------------------------
 // The 4-16-32-64 pool with its two wide layers on the matrix cores AND the per-vertex max taken where the accumulator
 // leaves the values (round 3).  v_mfma_f32_32x32x2_f32 accumulates like a chain of fp32 fmas in ascending k
 // (tools/micro/mfma_chain.hip), so C = bias followed by K/2 MFMAs reproduces the pinned summation order
@@ -657,7 +815,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 
 // what k_pool_bins left open: vertices without rows (zeros, torch_scatter's empty segment), vertices whose segment
 // crosses a 64-row chunk boundary and vertex 0 (packed accumulators -> value, barycentric weight, mask)
-__global__ void __launch_bounds__(256) k_pool_bins_finalize(const PoolJobs jobs, int cout, int min_points) {
+__global__ void __launch_bounds__(256) k_pool_bins_finalize(const PoolJobs jobs, int cout, int min_points, int block_shift) {
   const PoolJob& J = jobs.j[blockIdx.y];
   const TlnBins& bn = J.bn;
   const int nv = J.nv;
@@ -672,7 +830,8 @@ __global__ void __launch_bounds__(256) k_pool_bins_finalize(const PoolJobs jobs,
   const bool visited = bn.vstamp == nullptr || bn.vstamp[v] == bn.stamp;
   const int st = visited ? bn.vstart[v] : 0;
   int count = visited ? bn.vcnt[v] : 0;
-  const bool crossing = v == 0 || (count > 0 && (st >> 6) != ((st + count - 1) >> 6));
+  // (block_shift: 6 = k_pool_bins's 64-row chunks, 5 = the 32-row blocks of k_pool_bins2)
+  const bool crossing = v == 0 || (count > 0 && (st >> block_shift) != ((st + count - 1) >> block_shift));
   if (v == 0) count += bn.ctr[2];                  // the rows without a vertex (counted by K1) fold into vertex 0
   if (count > 0 && !crossing) return;              // written by k_pool_bins
   float val = 0.0f, bary = 0.0f;
@@ -748,14 +907,15 @@ static int launch_pool(tln_lattice* l, const float* d_dist, int64_t rows, int co
 // which kernel pools the 4-16-32-64 MLP from the bins: the all-VALU k_pool_bins (default) or k_pool_bins_mfma
 // (TLN_POOL_MFMA=1 / tln_options.pool_mode = 1).  Bitwise equal results; the MFMA variant measured no faster.
 // (tln_options.pool_mode of the lattice handle, tln_lattice_set_options; -1 = env TLN_POOL_MFMA, read once, else 0)
-static int pool_mode(const tln_lattice* l) {   // 0: all-VALU k_pool_bins, 1: legacy.hip's matrix-core variant, 2: k_pool_bins_mx
+static int pool_mode(const tln_lattice* l) {   // 0: all-VALU k_pool_bins, 1: legacy.hip's matrix-core variant, 2: k_pool_bins_mx,
+                                               // 3: k_pool_bins2 (two rows per step)
   static const int env_mode = [] {
     const char* e = getenv("TLN_POOL_MFMA");
     const int m = e ? atoi(e) : TLN_POOL_DEFAULT_MODE;
-    return (m < 0 || m > 2) ? TLN_POOL_DEFAULT_MODE : m;
+    return (m < 0 || m > 3) ? TLN_POOL_DEFAULT_MODE : m;
   }();
   const int m = tln_lat_options(l).pool_mode;
-  return (m < 0 || m > 2) ? env_mode : m;
+  return (m < 0 || m > 3) ? env_mode : m;
 }
 
 // the bins route for 1..TLN_POOL_MAXJOBS frames that share the MLP: *taken = false when the shape has no bins kernel
@@ -769,7 +929,25 @@ static int pool_bins_jobs(PoolJobs& jobs, int n, int nr_layers, const float* con
   const bool shape_wide = nr_layers == 3 && dims[1] == 16 && dims[2] == 32 && dims[3] == 64 && (cin == 4 || cin == 3);
   const bool wide = n == 1 && shape_wide && mode == 1;
   const PoolJob& j0 = jobs.j[0];
-  if (shape_wide && mode == 2) {
+  int block_shift = 6;
+  if (shape_wide && mode == 3) {
+    int64_t rmax = 0;
+    for (int i = 0; i < n; ++i)
+      if (jobs.j[i].rows > rmax) rmax = jobs.j[i].rows;
+    const size_t lds = (size_t)(4 * (64 * 36 + 4 * 64)) * sizeof(float);   // 40 KB: four workgroups per CU
+    const dim3 grid((unsigned)tln_cdiv(tln_cdiv(rmax, 64), 4), (unsigned)n);
+    if (cin == 4) {
+      static thread_local TlnLdsAttr attr4;
+      TLN_HIP(tln_set_max_lds(attr4, reinterpret_cast<const void*>(k_pool_bins2<4>), (int)lds));
+      hipLaunchKernelGGL(k_pool_bins2<4>, grid, dim3(256), lds, s, jobs, min_points, d_w[0], d_b[0], d_w[1], d_b[1], d_w[2], d_b[2]);
+    } else {
+      static thread_local TlnLdsAttr attr3;
+      TLN_HIP(tln_set_max_lds(attr3, reinterpret_cast<const void*>(k_pool_bins2<3>), (int)lds));
+      hipLaunchKernelGGL(k_pool_bins2<3>, grid, dim3(256), lds, s, jobs, min_points, d_w[0], d_b[0], d_w[1], d_b[1], d_w[2], d_b[2]);
+    }
+    TLN_LAUNCH_CHECK();
+    block_shift = 5;
+  } else if (shape_wide && mode == 2) {
     // matrix cores + the max in accumulator layout: a wave strides over chunks (weights stay in its registers)
     int64_t rmax = 0;
     for (int i = 0; i < n; ++i)
@@ -799,7 +977,7 @@ static int pool_bins_jobs(PoolJobs& jobs, int n, int nr_layers, const float* con
     if (jobs.j[i].nv > nvmax) nvmax = jobs.j[i].nv;
   const int64_t total = (int64_t)nvmax * cout;
   hipLaunchKernelGGL(k_pool_bins_finalize, dim3((unsigned)tln_cdiv(total, 256), (unsigned)n), dim3(256), 0, s, jobs, cout,
-                     min_points);
+                     min_points, block_shift);
   TLN_LAUNCH_CHECK();
   return TLN_OK;
 }

@@ -366,7 +366,8 @@ def test_pool_on_the_matrix_cores_is_bitwise_the_fma_chain(gpu, cin):
     Ws = [torch.randn(16, cin, generator=g) * 0.5, torch.randn(32, 16, generator=g) * 0.3, torch.randn(64, 32, generator=g) * 0.3]
     Bs = [torch.randn(16, generator=g) * 0.1, torch.randn(32, generator=g) * 0.1, torch.randn(64, generator=g) * 0.1]
     got = {}
-    for mfma in (2, 1, 0):      # 2: k_pool_bins_mx (max in accumulator layout), 1: legacy.hip's LDS-tile variant, 0: all-VALU
+    for mfma in (3, 2, 1, 0):   # 3: k_pool_bins2 (VALU, two rows per step), 2: k_pool_bins_mx (max in accumulator layout),
+                                # 1: legacy.hip's LDS-tile variant, 0: all-VALU
         OPT.push(pool_mode=mfma)
         try:
             lat = Lattice.from_params([0.7] * 3, 9000)
@@ -384,5 +385,5 @@ def test_pool_on_the_matrix_cores_is_bitwise_the_fma_chain(gpu, cin):
         finally:
             OPT.pop()
     assert (oi < 0).sum() > 0, "the fixture is meant to overflow on the second frame"
-    for a, b, c in zip(got[0], got[1], got[2]):
-        assert np.array_equal(a, b) and np.array_equal(a, c)
+    for a, b, c, d in zip(got[0], got[1], got[2], got[3]):
+        assert np.array_equal(a, b) and np.array_equal(a, c) and np.array_equal(a, d)
