@@ -1643,7 +1643,7 @@ __device__ __forceinline__ uint32_t bk_bucket(uint64_t K, uint64_t slot_mask, in
 #endif
 typedef unsigned int bk_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint4 bk_load_rec(const uint4* p) {
-#if TLN_K1_NT
+#if TLN_K1_NT & 1   // (bit 0: the record loads, bit 1: the bin stores)
   const bk_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const bk_u32x4*>(p));
   return make_uint4(v.x, v.y, v.z, v.w);
 #else
@@ -1651,7 +1651,7 @@ __device__ __forceinline__ uint4 bk_load_rec(const uint4* p) {
 #endif
 }
 __device__ __forceinline__ void bk_store_stream(uint4* p, const uint4& v) {
-#if TLN_K1_NT
+#if TLN_K1_NT & 2
   bk_u32x4 w;
   w.x = v.x;
   w.y = v.y;
